@@ -1,0 +1,281 @@
+"""Generate the golden fixtures under tests/golden/ from the imported reference.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+It imports the upstream reference through `ref_harness` (stubs, CPU), runs the
+reference's own modules on seeded inputs and stores inputs, weights (reference
+`state_dict()` layouts) and outputs as `.npz`.  The fixtures are DATA; no reference
+source travels.  While generating it also cross-checks the oracle restatement and
+prints the max abs difference per item.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_harness as rh  # noqa: E402
+from oracle import ccvs_oracle as O  # noqa: E402
+
+
+def sd_np(prefix, module):
+    return {f"{prefix}/{k}": v.detach().cpu().numpy() for k, v in module.state_dict().items()
+            if not k.endswith(".mask") and not k.endswith(".kernel")}
+
+
+def report(name, a, b):
+    d = (a.float() - b.float()).abs().max().item() if a.numel() else 0.0
+    print(f"  oracle vs reference  {name:40s} max|diff| = {d:.3e}")
+    return d
+
+
+def tiny_end_to_end(ns):
+    opt = rh.parse_reference_options(rh.TINY_ARGV)
+    qopt, xopt = opt["qvid_generator"], opt["transformer"]
+    torch.manual_seed(0)
+    qv = ns.qvm.QVidModel(qopt, is_train=False, is_main=True).eval()
+    tr = ns.tm.Transformer(xopt, is_train=False, is_main=True).eval()
+    # give the positional tables non-zero values (they are zero-initialised, mingpt.py:152-153)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        tr.net_t.s_emb.normal_(0, 0.02, generator=g)
+        tr.net_t.t_emb.normal_(0, 0.02, generator=g)
+    torch.manual_seed(1)
+    vid = torch.rand(2, 4, 3, 32, 32) * 2 - 1
+    out = {}
+    with torch.no_grad():
+        enc0 = qv({"vid": vid.clone()}, mode="vid_encoder")
+        # documented synthetic codebook: randn * std(z_e) (SURVEY section 7 hard part 2)
+        z_e, _ = qv.net_e(vid)
+        torch.manual_seed(4)
+        qv.net_q.embedding.weight.copy_(torch.randn_like(qv.net_q.embedding.weight) * z_e.std())
+        enc = qv({"vid": vid.clone()}, mode="vid_encoder")
+        out["z_e"] = z_e
+        out["enc_code"] = enc["code"]
+        for i, f in enumerate(enc["inter"]):
+            out[f"enc_inter{i}"] = f
+        # top-2 distance gap audit for the argmin
+        zf = z_e.transpose(-3, -1).transpose(-3, -2).reshape(-1, z_e.shape[2])
+        cb = qv.net_q.embedding.weight
+        d = (zf ** 2).sum(1, keepdim=True) + (cb ** 2).sum(1) - 2 * zf @ cb.t()
+        top2 = torch.topk(d, 2, dim=1, largest=False)[0]
+        out["vq_min_gap"] = (top2[:, 1] - top2[:, 0]).min()
+
+        # generate_vid sequence (helpers/generator.py:83-164), greedy sampling for determinism
+        size = 64
+        crop_prop = xopt.cond_len / (size * xopt.vid_len)
+        code_c = enc["code"][:, :int(crop_prop * enc["code"].size(1))]
+        inter_c = [f[:, :int(crop_prop * f.size(1))].contiguous() for f in enc["inter"]]
+        total_len = xopt.vid_len * size
+        xopt.sample = False
+        xopt.top_k = 10
+        fake_enc = tr({"code": code_c.clone()}, mode="inference", total_len=total_len)
+        out["gen_code_greedy"] = fake_enc["code"]
+        # teacher-forced logits on the generated stream
+        out["gpt_logits"] = tr.net_t(fake_enc["code"][:, :-1])
+        with rh.patched_overlapping_shift():
+            fake = qv({"code": fake_enc["code"].clone(), "inter": [f.clone() for f in inter_c]}, mode="vid_decoder")
+        out["fake_vid"] = fake["vid"]
+        # reconstruction of the conditioning frame alone through the decoder graph
+        rec0, _, fl, oc, _ = qv.net_g(enc["z"][:, :1].contiguous(), [[f[:, :1] for f in enc["inter"]]], return_all=True)
+        out["dec_cond_vid"] = rec0
+        for i, (a, b) in enumerate(zip(fl, oc)):
+            out[f"dec_cond_flow{i}"] = a
+            out[f"dec_cond_occ{i}"] = b
+        # sampled path: logits -> multinomial with a seeded generator
+        xopt.sample = True
+        torch.manual_seed(7)
+        samp = tr({"code": code_c.clone()}, mode="inference", total_len=64 + 8)
+        out["gen_code_sampled_seed7"] = samp["code"]
+        # step decoder: one frame
+        with rh.patched_overlapping_shift():
+            step = qv({"code": fake_enc["code"][:, 64:128].clone(), "inter": [f.clone() for f in inter_c]},
+                      mode="vid_step_decoder")
+        out["step_vid"] = step["vid"]
+        out["step_code"] = step["code"]
+
+    # oracle cross-check
+    nets = {"e": qv.net_e.state_dict(), "q": qv.net_q.state_dict(), "g": qv.net_g.state_dict(), "t": tr.net_t.state_dict()}
+    xo = O.namespace(**vars(xopt))
+    xo.sample, xo.top_k = False, 10
+    with torch.no_grad():
+        oenc = O.qvid_encode(nets, qopt, vid)
+        report("tiny/enc_code (mismatches)", (oenc["code"] != enc["code"]).float(), torch.zeros(1))
+        for i, f in enumerate(oenc["inter"]):
+            report(f"tiny/enc_inter{i}", f, enc["inter"][i])
+        ocode = O.generate_fake(nets["t"], xo, code_c, total_len)
+        report("tiny/gen_code_greedy (mismatches)", (ocode != fake_enc["code"]).float(), torch.zeros(1))
+        report("tiny/gpt_logits", O.gpt_forward(nets["t"], xo, fake_enc["code"][:, :-1]), out["gpt_logits"])
+        ofake = O.qvid_decode(nets, qopt, fake_enc["code"], [f.clone() for f in inter_c])
+        report("tiny/fake_vid", ofake, fake["vid"])
+        xo.sample = True
+        torch.manual_seed(7)
+        osamp = O.generate_fake(nets["t"], xo, code_c, 64 + 8)
+        report("tiny/gen_code_sampled (mismatches)", (osamp != samp["code"]).float(), torch.zeros(1))
+        ostep = O.qvid_step_decode(nets, qopt, fake_enc["code"][:, 64:128], [f.clone() for f in inter_c])
+        report("tiny/step_vid", ostep["vid"], step["vid"])
+
+    arrays = {"vid": vid.numpy()}
+    arrays.update({k: v.detach().cpu().numpy() for k, v in out.items()})
+    arrays.update(sd_np("e", qv.net_e))
+    arrays.update(sd_np("q", qv.net_q))
+    arrays.update(sd_np("g", qv.net_g))
+    arrays.update(sd_np("t", tr.net_t))
+    np.savez_compressed(os.path.join(HERE, "tiny_e2e.npz"), **arrays)
+    print("  wrote tiny_e2e.npz", sum(a.nbytes for a in arrays.values()) / 1e6, "MB raw")
+    return qopt, xopt
+
+
+def op_fixtures(ns):
+    """Per-op vectors at a few real channel counts on small maps."""
+    sae = ns.sae
+    arrays = {}
+    g = torch.Generator().manual_seed(11)
+
+    def rnd(*s):
+        return torch.randn(*s, generator=g)
+
+    with torch.no_grad():
+        # Blur / upfirdn2d (modules/upfirdn2d.py:162-203): down pad, up pad (x4), up=2
+        x = rnd(2, 5, 12, 10)
+        arrays["blur/x"] = x.numpy()
+        k1 = sae.make_kernel([1, 3, 3, 1])
+        for name, kw in {"down3": dict(pad=(2, 2)), "down1": dict(pad=(1, 1)), "up3": dict(pad=(1, 1), gain=4.0),
+                         "up1": dict(pad=(2, 2), gain=4.0), "upsample2": dict(pad=(2, 1), up=2, gain=4.0)}.items():
+            gain = kw.pop("gain", 1.0)
+            y = ns.upfirdn2d.upfirdn2d(x, k1 * gain, **kw)
+            arrays[f"blur/{name}"] = y.numpy()
+            report(f"blur/{name}", O.upfirdn2d(x, O.make_fir_kernel(gain=gain), **kw), y)
+
+        # ConvLayer variants (skip_autoencoder.py:66-102)
+        torch.manual_seed(21)
+        for name, (cin, cout, k, kw) in {
+            "plain3": (24, 40, 3, {}), "plain1": (96, 24, 1, {}), "down3": (16, 32, 3, dict(downsample=True)),
+            "down1": (16, 32, 1, dict(downsample=True, activate=False, bias=False)),
+            "up3": (32, 16, 3, dict(upsample=True)), "up1": (32, 16, 1, dict(upsample=True, activate=False, bias=False)),
+            "head9": (32, 2, 9, dict(activate=False)), "head5": (32, 1, 5, dict(activate=False)),
+        }.items():
+            m = sae.ConvLayer(cin, cout, k, **kw)
+            for p in m.parameters():
+                if p.ndim == 1:
+                    p.normal_(0, 0.5)
+            x = rnd(2, cin, 16, 16)
+            y = m(x)
+            arrays[f"conv/{name}/x"] = x.numpy()
+            arrays[f"conv/{name}/y"] = y.numpy()
+            sd = {f"m.{kk}": v for kk, v in m.state_dict().items()}
+            for kk, v in sd.items():
+                if not kk.endswith("kernel"):
+                    arrays[f"conv/{name}/{kk}"] = v.numpy()
+            okw = {kk: v for kk, v in kw.items() if kk != "bias"}
+            report(f"conv/{name}", O.conv_layer(sd, "m", x, **okw), y)
+
+        # ResBlock down / up (skip_autoencoder.py:105-117)
+        for name, kw in {"down": dict(downsample=True), "up": dict(upsample=True)}.items():
+            m = sae.ResBlock(16, 24, **kw)
+            x = rnd(2, 16, 16, 16)
+            y = m(x)
+            arrays[f"res/{name}/x"] = x.numpy()
+            arrays[f"res/{name}/y"] = y.numpy()
+            sd = {f"m.{kk}": v for kk, v in m.state_dict().items()}
+            for kk, v in sd.items():
+                if not kk.endswith("kernel"):
+                    arrays[f"res/{name}/{kk}"] = v.numpy()
+            report(f"res/{name}", O.res_block(sd, "m", x, **kw), y)
+
+        # backwarp (skip_autoencoder.py:120-128)
+        x = rnd(2, 6, 12, 16)
+        flow = rnd(2, 2, 12, 16) * 3
+        grid = sae.get_backwarp_grid(12, 16)
+        y = sae.backwarp(x, flow, grid)
+        arrays["warp/x"], arrays["warp/flow"], arrays["warp/y"] = x.numpy(), flow.numpy(), y.numpy()
+        report("warp", O.backwarp(x, flow, O.backwarp_grid(12, 16)), y)
+
+        # VQ: default init (U(+-1/n_e), tie-prone) and scaled-normal codebook
+        for name, scale_normal in {"default": False, "randn": True}.items():
+            q = ns.quantize.VectorQuantizer(64, 32, beta=0.25)
+            z = rnd(3, 32, 8, 8) * 0.5
+            if scale_normal:
+                q.embedding.weight.copy_(rnd(64, 32) * z.std())
+            zq, _, info = q(z)
+            arrays[f"vq/{name}/z"] = z.numpy()
+            arrays[f"vq/{name}/codebook"] = q.embedding.weight.numpy()
+            arrays[f"vq/{name}/idx"] = info[2].view(-1).numpy()
+            arrays[f"vq/{name}/zq"] = zq.numpy()
+            report(f"vq/{name} (mismatches)", (O.vq_indices(z, q.embedding.weight) != info[2].view(-1)).float(), torch.zeros(1))
+            report(f"vq/{name}/zq", O.vq_quantize(z, q.embedding.weight)[0], zq)
+            arrays[f"vq/{name}/embed"] = q.embed_code(info[2].view(3, 8, 8)).numpy()
+
+        # InterBlock at decoder level 3 geometry (5x5 heads, stride-2 correlation, carried flow), k = 2
+        opt = O.namespace(no_corr=False, use_masked_flow=False, use_deformed_conv=False, use_tradeoff=False, no_proj=False)
+        torch.manual_seed(31)
+        ib = sae.InterBlock(opt, 16, 16, flow_mult=8, kernel=5, feat_size=24, corr_stride=2, first=False)
+        inp = rnd(2, 24, 16, 16)
+        inters = [rnd(2, 24, 16, 16), rnd(2, 24, 16, 16)]
+        flows = rnd(4, 2, 8, 8) * 0.2
+        occs = rnd(4, 1, 8, 8)
+        y, f2, o2, _ = ib(inp, inters, flows, occs)
+        arrays["ib/inp"], arrays["ib/inter0"], arrays["ib/inter1"] = inp.numpy(), inters[0].numpy(), inters[1].numpy()
+        arrays["ib/flows"], arrays["ib/occs"] = flows.numpy(), occs.numpy()
+        arrays["ib/y"], arrays["ib/flows_out"], arrays["ib/occs_out"] = y.numpy(), f2.numpy(), o2.numpy()
+        sd = {f"m.{kk}": v for kk, v in ib.state_dict().items()}
+        for kk, v in sd.items():
+            if not kk.endswith("kernel"):
+                arrays[f"ib/{kk}"] = v.numpy()
+        oy, of, oo = O.inter_block_forward(sd, "m", 3, 24, inp, inters, flows, occs, O.backwarp_grid(16, 16), opt)
+        report("ib/y", oy, y)
+        report("ib/flows", of, f2)
+        report("ib/occs", oo, o2)
+
+        # correlation: harness brute force vs oracle (parity unpinned by the reference, see docstrings)
+        a, b = rnd(2, 24, 9, 11), rnd(2, 24, 9, 11)
+        for s in (1, 2):
+            y = rh.correlation_bruteforce(a, b, s)
+            arrays[f"corr/s{s}"] = y.numpy()
+            report(f"corr/s{s}", O.correlation(a, b, s), y)
+        arrays["corr/a"], arrays["corr/b"] = a.numpy(), b.numpy()
+
+        # GPT block + full GPT with p2p conditioning prefix (mingpt.py:232-305)
+        torch.manual_seed(41)
+        gpt = ns.mingpt.GPT(vocab_size=50, block_size=192, num_blocks=4, n_layer=2, n_head=4, n_embd=64,
+                            emb_mode="temporal", shape=[4, 4])
+        gpt.s_emb.normal_(0, 0.02)
+        gpt.t_emb.normal_(0, 0.02)
+        idx = torch.randint(0, 50, (3, 37), generator=g)
+        cond = torch.randint(0, 50, (3, 16), generator=g)
+        dl = torch.tensor([3, 3, 3])
+        arrays["gpt/idx"], arrays["gpt/cond"], arrays["gpt/delta"] = idx.numpy(), cond.numpy(), dl.numpy()
+        y0 = gpt(idx)
+        y1 = gpt(idx, cond_idx=cond, delta_length_cond=dl)
+        arrays["gpt/logits"], arrays["gpt/logits_p2p"] = y0.numpy(), y1.numpy()
+        sd = gpt.state_dict()
+        for kk, v in sd.items():
+            if not kk.endswith("mask"):
+                arrays[f"gpt/w/{kk}"] = v.numpy()
+        cfg = O.namespace(z_shape=[4, 4], emb_mode="temporal", n_layer=2, n_head=4, z_len=192)
+        report("gpt/logits", O.gpt_forward(sd, cfg, idx), y0)
+        report("gpt/logits_p2p", O.gpt_forward(sd, cfg, idx, cond, dl), y1)
+
+        # top-k masking + greedy pick (transformer_model.py:256-260,395-409)
+        logits = rnd(4, 1, 50)
+        tr = ns.tm.Transformer.__new__(ns.tm.Transformer)
+        masked = ns.tm.Transformer.top_k_logits(tr, logits[:, -1], 7)
+        icode, _ = ns.tm.Transformer.get_icode(tr, logits, 0.7, 7, False)
+        arrays["topk/logits"], arrays["topk/masked"], arrays["topk/icode"] = logits.numpy(), masked.numpy(), icode.numpy()
+        report("topk/masked", torch.nan_to_num(O.top_k_logits(logits[:, -1], 7), neginf=-1e30), torch.nan_to_num(masked, neginf=-1e30))
+
+    np.savez_compressed(os.path.join(HERE, "ops.npz"), **arrays)
+    print("  wrote ops.npz", sum(a.nbytes for a in arrays.values()) / 1e6, "MB raw")
+
+
+if __name__ == "__main__":
+    ns = rh.load_reference()
+    print("== op fixtures")
+    op_fixtures(ns)
+    print("== tiny end-to-end")
+    tiny_end_to_end(ns)
