@@ -1,0 +1,211 @@
+// Cost volume, bilinear back-warp and the confidence fusion / occlusion blend of the
+// decoder's InterBlock (reference skip_autoencoder.py:120-128,179-265).  HBM / LDS bound.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------
+// 7x7 displacement correlation (modules/correlation.py:11-100):
+//   out[n][7*(dy+3)+(dx+3)][y][x] = (1/C) sum_c A[n/div][c][y*s][x*s] * B[n][c][(y+dy)*s][(x+dx)*s]
+// One workgroup = 8x32 output pixels, one lane per pixel with 49 running sums in
+// registers; per chunk of CORR_CC channels the B halo tile ((7+6)*s+1 x (31+6)*s+1) is
+// staged in LDS (zero outside the image: the reference's padded `rearrange` copy is never
+// materialised).
+// ---------------------------------------------------------------------------------------
+#define CORR_CC 4
+
+template <int S>
+__global__ __launch_bounds__(256) void correlation7x7_kernel(const float* __restrict__ first, const float* __restrict__ second,
+                                                             float* __restrict__ out, int C, int H, int W, int Ho, int Wo,
+                                                             int first_div, int lrelu, int tiles_x) {
+    constexpr int TH = 8, TW = 32;
+    constexpr int IH = (TH - 1) * S + 6 * S + 1, IW = (TW - 1) * S + 6 * S + 1;
+    __shared__ float bt[CORR_CC][IH * IW];
+    const int tid = threadIdx.x;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int n = blockIdx.y;
+    const int py = tid >> 5, px = tid & 31;
+    const int oy = ty * TH + py, ox = tx * TW + px;
+    const bool live = (oy < Ho && ox < Wo);
+    const int iy0 = ty * TH * S - 3 * S, ix0 = tx * TW * S - 3 * S;
+    const float* A = first + (long)(n / first_div) * C * H * W;
+    const float* B = second + (long)n * C * H * W;
+
+    float acc[49];
+#pragma unroll
+    for (int d = 0; d < 49; ++d) acc[d] = 0.f;
+
+    for (int c0 = 0; c0 < C; c0 += CORR_CC) {
+        __syncthreads();
+        for (int e = tid; e < IH * IW; e += 256) {
+            const int r = e / IW, c = e - r * IW;
+            const int gy = iy0 + r, gx = ix0 + c;
+            const bool ok = (gy >= 0 && gy < H && gx >= 0 && gx < W);
+#pragma unroll
+            for (int cc = 0; cc < CORR_CC; ++cc)
+                bt[cc][e] = (ok && c0 + cc < C) ? B[(long)(c0 + cc) * H * W + (long)gy * W + gx] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < CORR_CC; ++cc) {
+            const float a = (live && c0 + cc < C) ? A[(long)(c0 + cc) * H * W + (long)(oy * S) * W + ox * S] : 0.f;
+            const float* bp = &bt[cc][(py * S) * IW + px * S];
+#pragma unroll
+            for (int dy = 0; dy < 7; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 7; ++dx) acc[dy * 7 + dx] += a * bp[(dy * S) * IW + dx * S];
+        }
+    }
+    if (live) {
+        const float inv = 1.f / (float)C;
+        float* o = out + (long)n * 49 * Ho * Wo + (long)oy * Wo + ox;
+#pragma unroll
+        for (int d = 0; d < 49; ++d) {
+            float v = acc[d] * inv;
+            if (lrelu) v = lrelu01(v);
+            o[(long)d * Ho * Wo] = v;
+        }
+    }
+}
+
+extern "C" int ccvs_correlation7x7(const float* first, const float* second, float* out, int32_t N, int32_t C, int32_t H, int32_t W,
+                                   int32_t stride, int32_t first_div, int32_t lrelu, void* stream) {
+    CCVS_REQUIRE(first && second && out, "ccvs_correlation7x7: null pointer");
+    CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && first_div >= 1, "ccvs_correlation7x7: bad shape");
+    CCVS_REQUIRE(stride == 1 || stride == 2, "ccvs_correlation7x7: stride %d unsupported", stride);
+    CCVS_REQUIRE(N <= 65535, "ccvs_correlation7x7: batch too large");
+    const int Ho = cdiv(H, stride), Wo = cdiv(W, stride);
+    const int tiles_x = cdiv(Wo, 32), tiles_y = cdiv(Ho, 8);
+    dim3 grid(tiles_x * tiles_y, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (stride == 1)
+        hipLaunchKernelGGL((correlation7x7_kernel<1>), grid, dim3(256), 0, st, first, second, out, C, H, W, Ho, Wo, first_div, lrelu, tiles_x);
+    else
+        hipLaunchKernelGGL((correlation7x7_kernel<2>), grid, dim3(256), 0, st, first, second, out, C, H, W, Ho, Wo, first_div, lrelu, tiles_x);
+    CCVS_CHECK_LAUNCH("ccvs_correlation7x7");
+    return CCVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// backwarp: grid_sample(bilinear, zeros, align_corners=False) on the pixel-centre grid
+// (skip_autoencoder.py:120-128).  Sample position in input pixels, following the
+// reference's arithmetic: g = (2x+1)/W - 1 + f / ((W-1)/2);  ix = ((g+1)*W - 1)/2.
+// ---------------------------------------------------------------------------------------
+struct Bilin {
+    int o00, o01, o10, o11;  // plane offsets, -1 when outside
+    float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ Bilin bilin_setup(int x, int y, float fx, float fy, int H, int W) {
+    const float gx = ((2.f * x + 1.f) / W - 1.f) + fx / ((W - 1.0f) / 2.0f);
+    const float gy = ((2.f * y + 1.f) / H - 1.f) + fy / ((H - 1.0f) / 2.0f);
+    const float ix = ((gx + 1.f) * W - 1.f) * 0.5f;
+    const float iy = ((gy + 1.f) * H - 1.f) * 0.5f;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float tx = ix - x0f, ty = iy - y0f;
+    Bilin b;
+    b.w00 = (1.f - tx) * (1.f - ty); b.w01 = tx * (1.f - ty); b.w10 = (1.f - tx) * ty; b.w11 = tx * ty;
+    // clamp before the int conversion so that huge flows cannot overflow
+    const float xc = fminf(fmaxf(x0f, -2.f), (float)W + 1.f), yc = fminf(fmaxf(y0f, -2.f), (float)H + 1.f);
+    const int x0 = (int)xc, y0 = (int)yc, x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = (x0 >= 0 && x0 < W), vx1 = (x1 >= 0 && x1 < W), vy0 = (y0 >= 0 && y0 < H), vy1 = (y1 >= 0 && y1 < H);
+    b.o00 = (vx0 && vy0) ? y0 * W + x0 : -1;
+    b.o01 = (vx1 && vy0) ? y0 * W + x1 : -1;
+    b.o10 = (vx0 && vy1) ? y1 * W + x0 : -1;
+    b.o11 = (vx1 && vy1) ? y1 * W + x1 : -1;
+    return b;
+}
+
+__device__ __forceinline__ float bilin_sample(const float* __restrict__ plane, const Bilin& b) {
+    float v = 0.f;
+    if (b.o00 >= 0) v += plane[b.o00] * b.w00;
+    if (b.o01 >= 0) v += plane[b.o01] * b.w01;
+    if (b.o10 >= 0) v += plane[b.o10] * b.w10;
+    if (b.o11 >= 0) v += plane[b.o11] * b.w11;
+    return v;
+}
+
+#define WARP_CCH 16  // channels per thread
+
+__global__ __launch_bounds__(256) void backwarp_kernel(const float* __restrict__ x, long x_sN, long x_sC,
+                                                       const float* __restrict__ flow, long flow_sN, float mult,
+                                                       float* __restrict__ y, long y_sN, long y_sC, int C, int H, int W) {
+    const int HW = H * W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int n = blockIdx.z, c0 = blockIdx.y * WARP_CCH;
+    const int py = pix / W, px = pix - py * W;
+    const float fx = flow[(long)n * flow_sN + pix] * mult, fy = flow[(long)n * flow_sN + HW + pix] * mult;
+    const Bilin b = bilin_setup(px, py, fx, fy, H, W);
+    const int cend = min(c0 + WARP_CCH, C);
+    for (int c = c0; c < cend; ++c)
+        y[(long)n * y_sN + (long)c * y_sC + pix] = bilin_sample(x + (long)n * x_sN + (long)c * x_sC, b);
+}
+
+extern "C" int ccvs_backwarp(const float* x, int64_t x_sN, int64_t x_sC, const float* flow, int64_t flow_sN, float flow_mult, float* y,
+                             int64_t y_sN, int64_t y_sC, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    CCVS_REQUIRE(x && flow && y, "ccvs_backwarp: null pointer");
+    CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535, "ccvs_backwarp: bad shape");
+    dim3 grid(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
+    hipLaunchKernelGGL(backwarp_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (long)x_sN, (long)x_sC, flow, (long)flow_sN, flow_mult, y,
+                       (long)y_sN, (long)y_sC, C, H, W);
+    CCVS_CHECK_LAUNCH("ccvs_backwarp");
+    return CCVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// InterBlock tail (skip_autoencoder.py:254-264): warp each of the k context features with
+// its final flow, fuse with confidences 1 - sigmoid(occ_k) + eps, blend into the decoder
+// feature with sigmoid of the fused occlusion.  One lane per pixel, WARP_CCH channels per
+// thread; the per-k sample set-up is recomputed per channel chunk (3 floats per k).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void warp_fuse_blend_kernel(float* __restrict__ dec, long dec_sN, long dec_sC,
+                                                              const float* __restrict__ ctx, const float* __restrict__ flows,
+                                                              long flows_sN, const float* __restrict__ occs, long occs_sN,
+                                                              float mult, int k, int C, int H, int W) {
+    const int HW = H * W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int n = blockIdx.z, c0 = blockIdx.y * WARP_CCH;
+    const int py = pix / W, px = pix - py * W;
+    const int cn = min(WARP_CCH, C - c0);
+    float acc[WARP_CCH];
+#pragma unroll
+    for (int j = 0; j < WARP_CCH; ++j) acc[j] = 0.f;
+    float sum_conf = 0.f, sum_occ = 0.f;
+    for (int kk = 0; kk < k; ++kk) {
+        const long nk = (long)n * k + kk;
+        const float fx = flows[nk * flows_sN + pix] * mult, fy = flows[nk * flows_sN + HW + pix] * mult;
+        const float oc = occs[nk * occs_sN + pix];
+        const float conf = (k > 1) ? (1.f - sigmoidf_(oc)) + 1e-6f : 1.f;
+        sum_conf += conf;
+        sum_occ += oc * conf;
+        const Bilin b = bilin_setup(px, py, fx, fy, H, W);
+        const float* base = ctx + (nk * C + c0) * HW;
+#pragma unroll
+        for (int j = 0; j < WARP_CCH; ++j)
+            if (j < cn) acc[j] += conf * bilin_sample(base + (long)j * HW, b);
+    }
+    const float occ = (k > 1) ? sum_occ / sum_conf : sum_occ;
+    const float m = sigmoidf_(occ);
+#pragma unroll
+    for (int j = 0; j < WARP_CCH; ++j) {
+        if (j < cn) {
+            float* d = dec + (long)n * dec_sN + (long)(c0 + j) * dec_sC + pix;
+            const float wv = (k > 1) ? acc[j] / sum_conf : acc[j];
+            *d = m * (*d) + (1.f - m) * wv;
+        }
+    }
+}
+
+extern "C" int ccvs_warp_fuse_blend(float* dec, int64_t dec_sN, int64_t dec_sC, const float* ctx, const float* flows, int64_t flows_sN,
+                                    const float* occs, int64_t occs_sN, float flow_mult, int32_t N, int32_t k, int32_t C, int32_t H,
+                                    int32_t W, void* stream) {
+    CCVS_REQUIRE(dec && ctx && flows && occs, "ccvs_warp_fuse_blend: null pointer");
+    CCVS_REQUIRE(N > 0 && k > 0 && C > 0 && H > 0 && W > 0 && N <= 65535, "ccvs_warp_fuse_blend: bad shape");
+    dim3 grid(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
+    hipLaunchKernelGGL(warp_fuse_blend_kernel, grid, dim3(256), 0, (hipStream_t)stream, dec, (long)dec_sN, (long)dec_sC, ctx, flows,
+                       (long)flows_sN, occs, (long)occs_sN, flow_mult, k, C, H, W);
+    CCVS_CHECK_LAUNCH("ccvs_warp_fuse_blend");
+    return CCVS_OK;
+}

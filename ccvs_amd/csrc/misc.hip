@@ -1,0 +1,43 @@
+// Error reporting and the uint8 output pack.
+#include <stdarg.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void ccvs_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* ccvs_last_error(void) { return g_err; }
+extern "C" int ccvs_abi_version(void) { return 1; }
+
+// save_video_batch (helpers/generator.py:306-309): clamp to [lo,hi], rescale to [0,1],
+// x255, truncate to uint8, NCHW -> NHWC.
+__global__ __launch_bounds__(256) void pack_u8_kernel(const float* __restrict__ vid, uint8_t* __restrict__ out, long N, int HW, float lo,
+                                                      float hi) {
+    const long total = N * HW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / HW;
+        const int p = (int)(i - n * HW);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = vid[(n * 3 + c) * HW + p];
+            v = fminf(fmaxf(v, lo), hi);
+            v = (v - lo) / (hi - lo);
+            out[i * 3 + c] = (uint8_t)(v * 255.f);
+        }
+    }
+}
+
+extern "C" int ccvs_pack_u8(const float* vid, uint8_t* out, int64_t N, int32_t H, int32_t W, float lo, float hi, void* stream) {
+    CCVS_REQUIRE(vid && out, "ccvs_pack_u8: null pointer");
+    CCVS_REQUIRE(N > 0 && H > 0 && W > 0 && hi > lo, "ccvs_pack_u8: bad arguments");
+    const long total = (long)N * H * W;
+    const int blocks = (int)(cdiv64(total, 256) < 1048576 ? cdiv64(total, 256) : 1048576);
+    hipLaunchKernelGGL(pack_u8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, vid, out, (long)N, H * W, lo, hi);
+    CCVS_CHECK_LAUNCH("ccvs_pack_u8");
+    return CCVS_OK;
+}

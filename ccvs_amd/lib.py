@@ -1,0 +1,81 @@
+"""ctypes binding of libccvs_hip.so (the C ABI declared in include/ccvs_hip.h).
+
+The product has no CPU fallback: if the shared library is missing or a call fails this
+module raises.  Build the library with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C ccvs_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libccvs_hip.so")
+
+# every symbol include/ccvs_hip.h declares
+EXPORTS = [
+    "ccvs_last_error", "ccvs_abi_version", "ccvs_conv2d", "ccvs_upfirdn2d", "ccvs_dwconvT4x4s2",
+    "ccvs_correlation7x7", "ccvs_backwarp", "ccvs_warp_fuse_blend", "ccvs_vq_argmin", "ccvs_embed_gather",
+    "ccvs_gpt_embed", "ccvs_layernorm", "ccvs_gemm_nt", "ccvs_attention", "ccvs_kv_append", "ccvs_sample_topk",
+    "ccvs_pack_u8",
+]
+
+
+class ConvDesc(C.Structure):
+    """Mirror of `ccvs_conv_desc`."""
+    _fields_ = [
+        ("N", C.c_int32), ("Cin", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
+        ("in_sN", C.c_int64), ("in_sC", C.c_int64),
+        ("Cout", C.c_int32), ("CoutPad", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
+        ("out_sN", C.c_int64), ("out_sC", C.c_int64), ("res_sN", C.c_int64), ("res_sC", C.c_int64),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("transposed", C.c_int32),
+        ("act", C.c_int32), ("accumulate", C.c_int32), ("out_scale", C.c_float),
+    ]
+
+
+class CcvsError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; fail loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CcvsError(f"{LIB_PATH} not found: the HIP kernel library is not built "
+                        f"(run `make -C {os.path.dirname(LIB_PATH)}`); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.ccvs_last_error.restype = C.c_char_p
+    lib.ccvs_last_error.argtypes = []
+    lib.ccvs_abi_version.restype = C.c_int
+    sigs = {
+        "ccvs_conv2d": [vp, vp, vp, vp, vp, C.POINTER(ConvDesc), vp],
+        "ccvs_upfirdn2d": [vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, i32, f32, vp],
+        "ccvs_dwconvT4x4s2": [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp],
+        "ccvs_correlation7x7": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+        "ccvs_backwarp": [vp, i64, i64, vp, i64, f32, vp, i64, i64, i32, i32, i32, i32, vp],
+        "ccvs_warp_fuse_blend": [vp, i64, i64, vp, vp, i64, vp, i64, f32, i32, i32, i32, i32, i32, vp],
+        "ccvs_vq_argmin": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+        "ccvs_embed_gather": [vp, vp, vp, i32, i32, i32, i32, vp],
+        "ccvs_gpt_embed": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+        "ccvs_layernorm": [vp, vp, vp, vp, i32, i32, vp],
+        "ccvs_gemm_nt": [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp],
+        "ccvs_attention": [vp, i64, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+        "ccvs_kv_append": [vp, vp, i64, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+        "ccvs_sample_topk": [vp, i64, vp, vp, i64, i32, i32, i32, f32, vp],
+        "ccvs_pack_u8": [vp, vp, i64, i32, i32, f32, f32, vp],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, name):
+    if rc != 0:
+        raise CcvsError(f"{name} failed ({rc}): {load().ccvs_last_error().decode()}")

@@ -1,0 +1,277 @@
+"""Tensor-level wrappers over the C ABI (include/ccvs_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every call below hands raw
+device pointers and sizes to libccvs_hip.so.  There is no fallback: a CPU tensor or a missing
+library raises.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as _lib
+
+ACT_NONE, ACT_LRELU = 0, 1
+EPI_NONE, EPI_GELU, EPI_RESIDUAL = 0, 1, 2
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.CcvsError("ccvs_amd ops need device tensors: the HIP path has no CPU fallback")
+
+
+def _rows_dense(t):
+    return t.stride(-1) == 1 and t.stride(-2) == t.shape[-1]
+
+
+def _as_rows_dense(t):
+    return t if _rows_dense(t) else t.contiguous()
+
+
+# ------------------------------------------------------------------ convolution
+def pack_conv_weight(weight):
+    """[Cout,Cin,k,k] parameter -> [k*k][Cin][CoutPad] with the EqualConv2d scale
+    1/sqrt(Cin*k*k) multiplied in (skip_autoencoder.py:44,55,58)."""
+    cout, cin, kh, kw = weight.shape
+    scale = 1 / math.sqrt(cin * kh * kw)
+    cpad = -(-cout // 64) * 64 if cout >= 64 else 32 * (-(-cout // 32))
+    w = (weight.detach().float() * scale).permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
+    out = torch.zeros(kh * kw, cin, cpad, dtype=torch.float32, device=weight.device)
+    out[:, :, :cout] = w
+    return out.contiguous()
+
+
+def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=False, residual=None,
+           out_scale=1.0, out=None, accumulate=False):
+    _need_gpu(x, w_packed, bias, residual, out)
+    x = _as_rows_dense(x)
+    n, cin, h, w = x.shape
+    assert w_packed.shape[0] == k * k and w_packed.shape[1] == cin, (w_packed.shape, k, cin)
+    if transposed:
+        ho, wo = 2 * h + k - 2, 2 * w + k - 2
+    else:
+        ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    if out is None:
+        out = torch.empty(n, cout, ho, wo, dtype=torch.float32, device=x.device)
+    assert out.shape == (n, cout, ho, wo) and _rows_dense(out), (out.shape, (n, cout, ho, wo))
+    d = _lib.ConvDesc()
+    d.N, d.Cin, d.Hin, d.Win = n, cin, h, w
+    d.in_sN, d.in_sC = x.stride(0), x.stride(1)
+    d.Cout, d.CoutPad, d.Hout, d.Wout = cout, w_packed.shape[2], ho, wo
+    d.out_sN, d.out_sC = out.stride(0), out.stride(1)
+    if residual is not None:
+        residual = _as_rows_dense(residual)
+        assert residual.shape == out.shape
+        d.res_sN, d.res_sC = residual.stride(0), residual.stride(1)
+    d.kh = d.kw = k
+    d.stride, d.pad, d.transposed = stride, pad, 1 if transposed else 0
+    d.act = ACT_LRELU if act else ACT_NONE
+    d.accumulate = 1 if accumulate else 0
+    d.out_scale = out_scale
+    L = _lib.load()
+    _lib.check(L.ccvs_conv2d(_p(x), _p(w_packed), _p(bias), _p(residual), _p(out), C.byref(d), _stream()), "ccvs_conv2d")
+    return out
+
+
+# ------------------------------------------------------------------ resampling
+def upfirdn2d(x, up=1, down=1, pad=(0, 0), gain=1.0, act=False, residual=None, out_scale=1.0):
+    _need_gpu(x, residual)
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    ho = (h * up + pad[0] + pad[1] - 4) // down + 1
+    wo = (w * up + pad[0] + pad[1] - 4) // down + 1
+    y = torch.empty(n, c, ho, wo, dtype=torch.float32, device=x.device)
+    if residual is not None:
+        residual = residual.contiguous()
+        assert residual.shape == y.shape
+    L = _lib.load()
+    _lib.check(L.ccvs_upfirdn2d(_p(x), _p(y), _p(residual), n * c, h, w, up, down, pad[0], pad[1], gain,
+                                ACT_LRELU if act else ACT_NONE, out_scale, _stream()), "ccvs_upfirdn2d")
+    return y
+
+
+def _planes_dense(t):
+    """[N,C,H,W] whose channel planes are dense and consecutive (only the batch stride is free)."""
+    return _rows_dense(t) and (t.shape[1] == 1 or t.stride(1) == t.shape[2] * t.shape[3])
+
+
+def dwconvT4x4s2(x, w, out=None):
+    _need_gpu(x, w, out)
+    if not _planes_dense(x):
+        x = x.contiguous()
+    n, c, h, ww = x.shape
+    if out is None:
+        out = torch.empty(n, c, 2 * h, 2 * ww, dtype=torch.float32, device=x.device)
+    assert out.shape == (n, c, 2 * h, 2 * ww) and _planes_dense(out)
+    L = _lib.load()
+    _lib.check(L.ccvs_dwconvT4x4s2(_p(x), x.stride(0), _p(w.contiguous()), _p(out), out.stride(0), n, c, h, ww, _stream()),
+               "ccvs_dwconvT4x4s2")
+    return out
+
+
+# ------------------------------------------------------------------ cost volume / warp
+def correlation7x7(first, second, stride, first_div=1, lrelu=False):
+    _need_gpu(first, second)
+    first, second = first.contiguous(), second.contiguous()
+    n, c, h, w = second.shape
+    assert first.shape[0] * first_div == n and first.shape[1:] == second.shape[1:]
+    out = torch.empty(n, 49, -(-h // stride), -(-w // stride), dtype=torch.float32, device=second.device)
+    L = _lib.load()
+    _lib.check(L.ccvs_correlation7x7(_p(first), _p(second), _p(out), n, c, h, w, stride, first_div, 1 if lrelu else 0, _stream()),
+               "ccvs_correlation7x7")
+    return out
+
+
+def backwarp(x, flow, flow_mult=1.0, out=None):
+    _need_gpu(x, flow, out)
+    x = _as_rows_dense(x)
+    if not _planes_dense(flow):
+        flow = flow.contiguous()
+    n, c, h, w = x.shape
+    assert flow.shape == (n, 2, h, w)
+    if out is None:
+        out = torch.empty(n, c, h, w, dtype=torch.float32, device=x.device)
+    assert _rows_dense(out)
+    L = _lib.load()
+    _lib.check(L.ccvs_backwarp(_p(x), x.stride(0), x.stride(1), _p(flow), flow.stride(0), flow_mult, _p(out), out.stride(0),
+                               out.stride(1), n, c, h, w, _stream()), "ccvs_backwarp")
+    return out
+
+
+def warp_fuse_blend(dec, ctx, flows, occs, flow_mult, k):
+    """In place on `dec` (a channel-slice view [N,C,H,W] of the decoder feature)."""
+    _need_gpu(dec, ctx, flows, occs)
+    assert _rows_dense(dec)
+    ctx = ctx.contiguous()
+    flows = flows if _planes_dense(flows) else flows.contiguous()
+    occs = occs if _planes_dense(occs) else occs.contiguous()
+    n, c, h, w = dec.shape
+    assert ctx.shape == (n * k, c, h, w) and flows.shape == (n * k, 2, h, w) and occs.shape == (n * k, 1, h, w)
+    L = _lib.load()
+    _lib.check(L.ccvs_warp_fuse_blend(_p(dec), dec.stride(0), dec.stride(1), _p(ctx), _p(flows), flows.stride(0), _p(occs),
+                                      occs.stride(0), flow_mult, n, k, c, h, w, _stream()), "ccvs_warp_fuse_blend")
+    return dec
+
+
+# ------------------------------------------------------------------ vector quantiser
+def vq_argmin(z, codebook_t, e_sq):
+    """z [N,C,H,W] -> int64 [N*H*W] (n,h,w raster order)."""
+    _need_gpu(z, codebook_t, e_sq)
+    z = z.contiguous()
+    n, c = z.shape[:2]
+    hw = z.shape[2] * z.shape[3]
+    idx = torch.empty(n * hw, dtype=torch.int64, device=z.device)
+    L = _lib.load()
+    _lib.check(L.ccvs_vq_argmin(_p(z), _p(codebook_t), _p(e_sq), _p(idx), n, c, hw, codebook_t.shape[1], _stream()), "ccvs_vq_argmin")
+    return idx
+
+
+def embed_gather(code, codebook, n, hw):
+    """code int64 [n*hw] -> z [n, C, hw]."""
+    _need_gpu(code, codebook)
+    code = code.contiguous()
+    n_e, c = codebook.shape
+    z = torch.empty(n, c, hw, dtype=torch.float32, device=codebook.device)
+    L = _lib.load()
+    _lib.check(L.ccvs_embed_gather(_p(code), _p(codebook), _p(z), n, c, hw, n_e, _stream()), "ccvs_embed_gather")
+    return z
+
+
+# ------------------------------------------------------------------ transformer
+def gpt_embed(idx, pos_idx, tok_emb, pos_table):
+    _need_gpu(idx, pos_idx, tok_emb, pos_table)
+    idx = idx.contiguous().view(-1)
+    rows = idx.numel()
+    c = tok_emb.shape[1]
+    x = torch.empty(rows, c, dtype=torch.float32, device=tok_emb.device)
+    L = _lib.load()
+    _lib.check(L.ccvs_gpt_embed(_p(idx), _p(pos_idx.contiguous()), _p(tok_emb), _p(pos_table), _p(x), rows, c, tok_emb.shape[0], _stream()),
+               "ccvs_gpt_embed")
+    return x
+
+
+def layernorm(x, gamma, beta, out=None):
+    _need_gpu(x, gamma, beta)
+    rows, c = x.shape
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    L = _lib.load()
+    _lib.check(L.ccvs_layernorm(_p(x), _p(gamma), _p(beta), _p(out), rows, c, _stream()), "ccvs_layernorm")
+    return out
+
+
+def gemm_nt(x, w, bias=None, epilogue=EPI_NONE, residual=None, out=None):
+    """y = epilogue(x @ w.T + bias); x [M,K] (row stride free), w [N,K] contiguous."""
+    _need_gpu(x, w, bias, residual, out)
+    m, k = x.shape
+    n = w.shape[0]
+    assert x.stride(1) == 1 and w.is_contiguous() and w.shape[1] == k
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    assert out.stride(1) == 1
+    if residual is not None:
+        assert residual.stride(1) == 1 and residual.stride(0) == out.stride(0)
+    L = _lib.load()
+    _lib.check(L.ccvs_gemm_nt(_p(x), x.stride(0), _p(w), _p(bias), _p(residual), _p(out), out.stride(0), m, n, k, epilogue, _stream()),
+               "ccvs_gemm_nt")
+    return out
+
+
+def kv_append(k, v, kcache, vcache, pos0):
+    """k, v [B,Tq,H*D] views (row stride shared) -> caches [B,H,Tmax,D] at pos0.."""
+    b, tq, hd = k.shape
+    _, h, tmax, d = kcache.shape
+    assert k.stride(2) == 1 and v.stride() == k.stride()
+    L = _lib.load()
+    _lib.check(L.ccvs_kv_append(_p(k), _p(v), k.stride(0), k.stride(1), _p(kcache), _p(vcache), b, h, tq, pos0, tmax, d, _stream()),
+               "ccvs_kv_append")
+
+
+def attention(q, kcache, vcache, pos0):
+    """q [B,Tq,H*D] view -> out [B,Tq,H*D]; query t sees cache positions 0..pos0+t."""
+    b, tq, hd = q.shape
+    _, h, tmax, d = kcache.shape
+    assert q.stride(2) == 1
+    out = torch.empty(b, tq, hd, dtype=torch.float32, device=q.device)
+    L = _lib.load()
+    _lib.check(L.ccvs_attention(_p(q), q.stride(0), q.stride(1), _p(kcache), _p(vcache), _p(out), b, h, tq, pos0, tmax, d, _stream()),
+               "ccvs_attention")
+    return out
+
+
+def sample_topk(logits, top_k, temperature, noise=None, out=None):
+    """logits [B,V] -> int64 [B]; noise None = greedy, else argmax(p / noise)."""
+    _need_gpu(logits, noise, out)
+    b, v = logits.shape
+    assert logits.stride(1) == 1
+    if out is None:
+        out = torch.empty(b, dtype=torch.int64, device=logits.device)
+    if noise is not None:
+        assert noise.shape == (b, v) and noise.is_contiguous()
+    L = _lib.load()
+    _lib.check(L.ccvs_sample_topk(_p(logits), logits.stride(0), _p(noise), _p(out), out.stride(0), b, v,
+                                  0 if top_k is None else int(top_k), float(temperature), _stream()), "ccvs_sample_topk")
+    return out
+
+
+def pack_u8(vid, lo=-1.0, hi=1.0):
+    """[..., 3, H, W] fp32 -> [..., H, W, 3] uint8 (helpers/generator.py:306-309)."""
+    _need_gpu(vid)
+    vid = vid.contiguous()
+    lead = vid.shape[:-3]
+    h, w = vid.shape[-2:]
+    n = int(math.prod(lead)) if len(lead) else 1
+    out = torch.empty(*lead, h, w, 3, dtype=torch.uint8, device=vid.device)
+    L = _lib.load()
+    _lib.check(L.ccvs_pack_u8(_p(vid), _p(out), n, h, w, lo, hi, _stream()), "ccvs_pack_u8")
+    return out

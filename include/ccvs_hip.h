@@ -1,0 +1,169 @@
+/* ccvs_hip.h -- C ABI of libccvs_hip.so, the MI355X (gfx950) kernel library behind the
+ * CCVS autoregressive synthesis hot path (frame encoder -> VQ lookup -> causal
+ * transformer -> flow-guided frame decoder).
+ *
+ * The reference has no FFI for this path: its native boundary is two pybind11 torch
+ * extensions (modules/upfirdn2d.cpp:21-23, modules/fused_bias_act.cpp:18-20), cupy
+ * launches of raw CUDA kernels (modules/correlation.py:299-331) and aten ops.  Each entry
+ * point below names the reference interface it replaces (file:line, upstream repo root).
+ *
+ * Conventions
+ *   - all tensor pointers are DEVICE pointers owned by the caller (PyTorch allocator);
+ *     outputs are pre-allocated by the caller; nothing is allocated inside;
+ *   - tensors are fp32, NCHW, rows dense (W stride 1, H stride W) unless stated; where a
+ *     channel slice of a wider tensor is read or written the batch / channel strides are
+ *     passed explicitly in ELEMENTS;
+ *   - `stream` is a hipStream_t (passed as void*); launches are asynchronous on it;
+ *   - return 0 on success, negative on error; ccvs_last_error() gives the message of the
+ *     last failing call on this host thread;
+ *   - no internal threads, no hidden state; safe from one host thread per device.
+ */
+#ifndef CCVS_HIP_H
+#define CCVS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCVS_OK 0
+#define CCVS_ERR_ARG (-1)
+#define CCVS_ERR_LAUNCH (-2)
+
+#define CCVS_ACT_NONE 0
+#define CCVS_ACT_LRELU 1 /* LeakyReLU(0.1), skip_autoencoder.py:100 */
+
+const char* ccvs_last_error(void);
+int ccvs_abi_version(void);
+
+/* ---- convolution -------------------------------------------------------------------
+ * Replaces F.conv2d / F.conv_transpose2d as called by EqualConv2d.forward
+ * (models/skip_vid_generator/models/skip_autoencoder.py:53-59) plus the bias /
+ * LeakyReLU(0.1) / residual `(a+b)/sqrt2` / `flow + head(feat)` glue around it
+ * (skip_autoencoder.py:99-100,116,204-205,225-226).
+ *
+ * w_packed: [kh*kw][Cin][CoutPad] with the 1/sqrt(Cin*k*k) scale already multiplied in
+ *           (tap-major, then input channel, then output channel, CoutPad = Cout rounded up
+ *           to 32, or to 64 when Cout >= 64; padding is zero).
+ * transposed != 0: conv_transpose2d(stride 2, padding 0); Hout = 2*Hin + kh - 2.
+ * y = [ y + ] ( act(conv + bias) [+ residual] ) * out_scale
+ *     the leading `y +` only when accumulate != 0.  bias / residual may be NULL.
+ */
+typedef struct ccvs_conv_desc {
+    int32_t N, Cin, Hin, Win;
+    int64_t in_sN, in_sC; /* element strides of x */
+    int32_t Cout, CoutPad, Hout, Wout;
+    int64_t out_sN, out_sC; /* element strides of y */
+    int64_t res_sN, res_sC; /* element strides of residual */
+    int32_t kh, kw, stride, pad, transposed;
+    int32_t act, accumulate;
+    float out_scale;
+} ccvs_conv_desc;
+
+int ccvs_conv2d(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
+                const ccvs_conv_desc* d, void* stream);
+
+/* ---- FIR resampling ------------------------------------------------------------------
+ * Replaces upfirdn2d(input, kernel, up, down, pad) (modules/upfirdn2d.py:145-159, CUDA
+ * upfirdn2d_kernel.cu:107-207, pybind upfirdn2d.cpp:21-23) for the 4-tap separable
+ * kernel outer([1,3,3,1])/64 * gain used by Blur (skip_autoencoder.py:27-37).
+ * x [N,C,H,W] dense -> y [N,C,Ho,Wo], Ho = (H*up + pad0 + pad1 - 4)/down + 1.
+ * y = ( act(fir(x)) [+ residual] ) * out_scale ; residual dense like y, may be NULL.
+ */
+int ccvs_upfirdn2d(const float* x, float* y, const float* residual, int64_t NC, int32_t H, int32_t W, int32_t up,
+                   int32_t down, int32_t pad0, int32_t pad1, float gain, int32_t act, float out_scale, void* stream);
+
+/* Depthwise ConvTranspose2d(C, C, 4, stride 2, padding 1, groups=C, bias=False)
+ * (skip_autoencoder.py:153-154,168).  w [C,1,4,4]; x [N,C,H,W] (batch stride x_sN, channel
+ * planes dense) -> y [N,C,2H,2W] (batch stride y_sN). */
+int ccvs_dwconvT4x4s2(const float* x, int64_t x_sN, const float* w, float* y, int64_t y_sN, int32_t N, int32_t C, int32_t H,
+                      int32_t W, void* stream);
+
+/* ---- cost volume / warping -----------------------------------------------------------
+ * ccvs_correlation7x7 replaces FunctionCorrelation(first, second, stride)
+ * (modules/correlation.py:279-338,405-406; kernels :11-100) fused with the
+ * F.leaky_relu(., 0.1) applied to it (skip_autoencoder.py:197).
+ * first is indexed by n / first_div (first_div = k lets one projected decoder feature
+ * serve its k context pairs without materialising the repeat of skip_autoencoder.py:251).
+ * out [N,49,ceil(H/s),ceil(W/s)].
+ */
+int ccvs_correlation7x7(const float* first, const float* second, float* out, int32_t N, int32_t C, int32_t H, int32_t W,
+                        int32_t stride, int32_t first_div, int32_t lrelu, void* stream);
+
+/* backwarp(input, flow*flow_mult, grid) (skip_autoencoder.py:120-128): grid_sample
+ * bilinear / zeros / align_corners=False on the pixel-centre grid with the flow divided by
+ * ((W-1)/2, (H-1)/2).  x [N,C,H,W] with strides, flow [N,2,H,W] (batch stride flow_sN),
+ * y strided. */
+int ccvs_backwarp(const float* x, int64_t x_sN, int64_t x_sC, const float* flow, int64_t flow_sN, float flow_mult, float* y,
+                  int64_t y_sN, int64_t y_sC, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+
+/* Tail of InterBlock.forward (skip_autoencoder.py:254-264): final back-warp of the k
+ * context features, confidence fusion over k (eps 1e-6) and occlusion blend, written in
+ * place into the first C channels of the decoder feature.
+ * dec [N,C,H,W] strided (in/out); ctx [N*k,C,H,W] dense; flows [N*k,2,H,W] and occs
+ * [N*k,1,H,W] with batch strides flows_sN / occs_sN. */
+int ccvs_warp_fuse_blend(float* dec, int64_t dec_sN, int64_t dec_sC, const float* ctx, const float* flows, int64_t flows_sN,
+                         const float* occs, int64_t occs_sN, float flow_mult, int32_t N, int32_t k, int32_t C, int32_t H,
+                         int32_t W, void* stream);
+
+/* ---- vector quantiser ----------------------------------------------------------------
+ * ccvs_vq_argmin replaces VectorQuantizer.forward's distance + argmin
+ * (modules/quantize.py:40-50): idx[n*HW + p] = argmin_j (|z|^2 + |e_j|^2) - 2 z.e_j,
+ * lowest index on ties.  z [N,C,HW] (NCHW), codebook_t [C][n_e] (transposed embedding),
+ * e_sq [n_e]; idx int64 [N*HW]. */
+int ccvs_vq_argmin(const float* z, const float* codebook_t, const float* e_sq, int64_t* idx, int32_t N, int32_t C, int32_t HW,
+                   int32_t n_e, void* stream);
+
+/* VectorQuantizer.embed_code + the transposes of QVidModel.decode
+ * (modules/quantize.py:76-83, quantized_video_model.py:832-833):
+ * z[n][c][p] = codebook[code[n*HW+p]][c]. */
+int ccvs_embed_gather(const int64_t* code, const float* codebook, float* z, int32_t N, int32_t C, int32_t HW, int32_t n_e,
+                      void* stream);
+
+/* ---- transformer ---------------------------------------------------------------------
+ * Together these replace GPT.forward (models/skip_vid_generator/models/mingpt.py:232-305)
+ * and Transformer.get_icode (models/transformer_model.py:395-409), restructured around a
+ * KV cache (the reference recomputes the whole prefix per token, transformer_model.py:350).
+ */
+/* x[r][:] = tok_emb[idx[r]] + pos_table[pos_idx[r]]  (mingpt.py:234-236,242-244).
+ * pos_table rows are the positional embeddings pre-summed by the host for the call
+ * (s_emb + t_emb[+delta_length], h/w/t_emb or pos_emb: mingpt.py:186-217). */
+int ccvs_gpt_embed(const int64_t* idx, const int32_t* pos_idx, const float* tok_emb, const float* pos_table, float* x,
+                   int32_t rows, int32_t C, int32_t vocab, void* stream);
+
+/* nn.LayerNorm over the last dim (mingpt.py:103-104,168), eps 1e-5. */
+int ccvs_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t rows, int32_t C, void* stream);
+
+/* y = epilogue(x @ W^T + bias): nn.Linear (mingpt.py:44-51,107-110,169).
+ * x [M,K] row stride ldx, W [N,K] (torch Linear layout), y [M,N] row stride ldy.
+ * epilogue: 0 none, 1 GELU(erf) (mingpt.py:109), 2 add residual (res [M,N], stride ldy). */
+int ccvs_gemm_nt(const float* x, int64_t ldx, const float* w, const float* bias, const float* res, float* y, int64_t ldy,
+                 int32_t M, int32_t N, int32_t K, int32_t epilogue, void* stream);
+
+/* Causal attention against a KV cache (mingpt.py:67-77).
+ * q [B,Tq,H*D] (batch stride q_sB, row stride ldq); kcache/vcache [B,H,Tmax,D]; query t
+ * attends cache positions 0 .. pos0+t.  out [B,Tq,H*D] dense.  D must be 64. */
+int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const float* kcache, const float* vcache, float* out, int32_t B,
+                   int32_t H, int32_t Tq, int32_t pos0, int32_t Tmax, int32_t D, void* stream);
+
+/* Scatter new K/V rows [B,Tq,H*D] (batch stride sB, row stride ld) into the caches at pos0.. */
+int ccvs_kv_append(const float* k, const float* v, int64_t sB, int64_t ld, float* kcache, float* vcache, int32_t B, int32_t H,
+                   int32_t Tq, int32_t pos0, int32_t Tmax, int32_t D, void* stream);
+
+/* get_icode: logits/temperature -> top-k mask (ties kept) -> softmax -> pick.
+ * noise == NULL: greedy argmax (sample=False, topk k=1).  noise [B,V] ~ Exp(1):
+ * argmax(p / noise), the algorithm behind torch.multinomial(p, 1).
+ * logits [B,V] row stride ld; out int64 [B] written at out[b*out_stride]. */
+int ccvs_sample_topk(const float* logits, int64_t ld, const float* noise, int64_t* out, int64_t out_stride, int32_t B, int32_t V,
+                     int32_t top_k, float temperature, void* stream);
+
+/* ---- output stage ---------------------------------------------------------------------
+ * save_video_batch's clamp / rescale / x255 / uint8 / channels-last pack
+ * (helpers/generator.py:306-309).  vid [N,3,H,W] fp32 in [lo,hi] -> out [N,H,W,3] u8. */
+int ccvs_pack_u8(const float* vid, uint8_t* out, int64_t N, int32_t H, int32_t W, float lo, float hi, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCVS_HIP_H */

@@ -1,0 +1,315 @@
+"""-m gpu: every HIP kernel, through the C ABI, against the CPU oracle and the golden
+fixtures captured from the reference (tests/golden/ops.npz)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ccvs_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4  # abs, fp32 kernels vs the fp32 CPU oracle on O(1) activations
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from ccvs_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops.npz"))
+
+
+def dev(a):
+    return torch.as_tensor(np.asarray(a)).cuda()
+
+
+def close(a, b, tol=TOL):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    d = (a - b).abs().max().item() if a.numel() else 0.0
+    assert d <= tol, f"max abs diff {d:.3e} > {tol:.1e}"
+
+
+# ------------------------------------------------------------------ blur / upfirdn2d
+@pytest.mark.parametrize("name,kw", [("down3", dict(pad=(2, 2))), ("down1", dict(pad=(1, 1))),
+                                     ("up3", dict(pad=(1, 1), gain=4.0)), ("up1", dict(pad=(2, 2), gain=4.0)),
+                                     ("upsample2", dict(pad=(2, 1), up=2, gain=4.0))])
+def test_upfirdn2d_golden(ops, gold, name, kw):
+    y = ops.upfirdn2d(dev(gold["blur/x"]), **kw)
+    close(y, torch.from_numpy(gold[f"blur/{name}"]), 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 4, 4), (2, 3, 33, 17), (1, 2, 64, 130)])
+@pytest.mark.parametrize("up,down,pad", [(1, 1, (2, 2)), (1, 1, (1, 1)), (1, 2, (1, 1)), (2, 1, (2, 1)), (1, 2, (2, 2))])
+def test_upfirdn2d_oracle(ops, shape, up, down, pad):
+    torch.manual_seed(0)
+    x = torch.randn(*shape)
+    res = None
+    ref = O.upfirdn2d(x, O.make_fir_kernel(gain=2.0), up=up, down=down, pad=pad)
+    res = torch.randn_like(ref)
+    want = (torch.nn.functional.leaky_relu(ref, 0.1) + res) * 0.5
+    got = ops.upfirdn2d(x.cuda(), up=up, down=down, pad=pad, gain=2.0, act=True, residual=res.cuda(), out_scale=0.5)
+    close(got, want, 1e-5)
+
+
+def test_dwconvT(ops):
+    torch.manual_seed(0)
+    for c, h, w in [(2, 5, 7), (49, 16, 16), (1, 1, 1)]:
+        x, wt = torch.randn(3, c, h, w), torch.randn(c, 1, 4, 4)
+        close(ops.dwconvT4x4s2(x.cuda(), wt.cuda()), O.dw_convT_x2(x, wt), 1e-5)
+
+
+# ------------------------------------------------------------------ conv
+def _conv_case(ops, gold, name, **kw):
+    pre = f"conv/{name}/m."
+    sd = {k[len(f"conv/{name}/"):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith(pre)}
+    x = torch.from_numpy(gold[f"conv/{name}/x"])
+    return sd, x, torch.from_numpy(gold[f"conv/{name}/y"])
+
+
+def test_conv_plain_golden(ops, gold):
+    for name, k in [("plain3", 3), ("plain1", 1), ("head9", 9), ("head5", 5)]:
+        sd, x, want = _conv_case(ops, gold, name)
+        w, b = sd["m.0.weight"], sd["m.0.bias"]
+        act = name.startswith("plain")
+        got = ops.conv2d(x.cuda(), ops.pack_conv_weight(w.cuda()), b.cuda(), w.shape[0], k, pad=k // 2, act=act)
+        close(got, want)
+
+
+def test_conv_down_golden(ops, gold):
+    # Blur(pad 2,2) -> 3x3 stride 2 ; Blur(pad 1,1) -> 1x1 stride 2 (skip_autoencoder.py:71-79)
+    sd, x, want = _conv_case(ops, gold, "down3")
+    w, b = sd["m.1.weight"], sd["m.1.bias"]
+    xb = ops.upfirdn2d(x.cuda(), pad=(2, 2))
+    close(ops.conv2d(xb, ops.pack_conv_weight(w.cuda()), b.cuda(), w.shape[0], 3, stride=2, act=True), want)
+    sd, x, want = _conv_case(ops, gold, "down1")
+    w = sd["m.1.weight"]
+    xb = ops.upfirdn2d(x.cuda(), pad=(1, 1))
+    close(ops.conv2d(xb, ops.pack_conv_weight(w.cuda()), None, w.shape[0], 1, stride=2), want)
+
+
+def test_conv_up_golden(ops, gold):
+    # conv_transpose 3x3 s2 (+bias) -> Blur x4 pad (1,1) -> lrelu ; 1x1 transposed == 1x1 conv + upfirdn(up=2)
+    sd, x, want = _conv_case(ops, gold, "up3")
+    w, b = sd["m.0.weight"], sd["m.0.bias"]
+    t = ops.conv2d(x.cuda(), ops.pack_conv_weight(w.cuda()), b.cuda(), w.shape[0], 3, stride=2, transposed=True)
+    close(ops.upfirdn2d(t, pad=(1, 1), gain=4.0, act=True), want)
+    sd, x, want = _conv_case(ops, gold, "up1")
+    w = sd["m.0.weight"]
+    t = ops.conv2d(x.cuda(), ops.pack_conv_weight(w.cuda()), None, w.shape[0], 1)
+    close(ops.upfirdn2d(t, up=2, pad=(2, 1), gain=4.0), want)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,hw", [(3, 8, 1, 1, (5, 7)), (49, 128, 3, 1, (40, 72)), (195, 128, 3, 1, (16, 16)),
+                                                  (16, 70, 3, 2, (35, 37)), (32, 3, 9, 1, (20, 33)), (8, 8, 3, 1, (8, 8)),
+                                                  (10, 33, 5, 1, (9, 64)), (64, 64, 1, 2, (31, 31))])
+def test_conv_oracle_shapes(ops, cin, cout, k, stride, hw):
+    torch.manual_seed(cin * 7 + cout)
+    x = torch.randn(2, cin, *hw)
+    w = torch.randn(cout, cin, k, k)
+    b = torch.randn(cout)
+    pad = k // 2 if stride == 1 else 0
+    want = torch.nn.functional.leaky_relu(O.equal_conv2d(x, w, b, stride=stride, padding=pad), 0.1)
+    got = ops.conv2d(x.cuda(), ops.pack_conv_weight(w.cuda()), b.cuda(), cout, k, stride=stride, pad=pad, act=True)
+    close(got, want)
+
+
+def test_conv_transposed_oracle(ops):
+    torch.manual_seed(5)
+    for cin, cout, hw in [(16, 24, (8, 8)), (7, 70, (17, 33)), (32, 32, (1, 1))]:
+        x, w, b = torch.randn(2, cin, *hw), torch.randn(cout, cin, 3, 3), torch.randn(cout)
+        want = O.equal_conv2d(x, w, b, stride=2, padding=0, transpose=True)
+        got = ops.conv2d(x.cuda(), ops.pack_conv_weight(w.cuda()), b.cuda(), cout, 3, stride=2, transposed=True)
+        close(got, want)
+
+
+def test_conv_views_residual_accumulate(ops):
+    """channel-slice input view, strided output view, residual (a+b)/sqrt2, y += conv."""
+    torch.manual_seed(9)
+    big = torch.randn(2, 20, 12, 16)
+    x = big[:, :12]
+    w, b = torch.randn(6, 12, 3, 3), torch.randn(6)
+    res = torch.randn(2, 6, 12, 16)
+    want = (torch.nn.functional.leaky_relu(O.equal_conv2d(x, w, b, padding=1), 0.1) + res) / math.sqrt(2)
+    outbig = torch.zeros(2, 10, 12, 16).cuda()
+    ops.conv2d(big.cuda()[:, :12], ops.pack_conv_weight(w.cuda()), b.cuda(), 6, 3, pad=1, act=True, residual=res.cuda(),
+               out_scale=1 / math.sqrt(2), out=outbig[:, 2:8])
+    close(outbig[:, 2:8], want)
+    assert outbig[:, :2].abs().max().item() == 0 and outbig[:, 8:].abs().max().item() == 0
+    base = torch.randn(2, 6, 12, 16)
+    acc = base.clone().cuda()
+    ops.conv2d(x.cuda(), ops.pack_conv_weight(w.cuda()), b.cuda(), 6, 3, pad=1, out=acc, accumulate=True)
+    close(acc, base + O.equal_conv2d(x, w, b, padding=1))
+
+
+def test_res_blocks_golden(ops, gold):
+    from ccvs_amd.models.skip_vid_generator.models import skip_autoencoder as sae
+    for name, kw in [("down", dict(downsample=True)), ("up", dict(upsample=True))]:
+        m = sae.ResBlock(16, 24, **kw).cuda()
+        sd = {k[len(f"res/{name}/m."):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith(f"res/{name}/m.")}
+        m.load_state_dict(sd, strict=False)
+        y = m(dev(gold[f"res/{name}/x"]))
+        close(y, torch.from_numpy(gold[f"res/{name}/y"]))
+
+
+# ------------------------------------------------------------------ correlation / warp
+@pytest.mark.parametrize("s", [1, 2])
+def test_correlation_golden(ops, gold, s):
+    got = ops.correlation7x7(dev(gold["corr/a"]), dev(gold["corr/b"]), s)
+    close(got, torch.from_numpy(gold[f"corr/s{s}"]), 1e-5)
+
+
+@pytest.mark.parametrize("s", [1, 2])
+def test_correlation_properties(ops, s):
+    torch.manual_seed(3)
+    a, b = torch.randn(4, 24, 40, 70), torch.randn(4, 24, 40, 70)
+    got = ops.correlation7x7(a.cuda(), b.cuda(), s).cpu()
+    close(got, O.correlation(a, b, s), 1e-5)
+    # zero-displacement channel 24 == mean_c A*B at the strided positions
+    close(got[:, 24], (a * b).mean(1)[:, ::s, ::s], 1e-5)
+    # first_div broadcast: one `first` serves k pairs; fused leaky relu
+    got2 = ops.correlation7x7(a[:2].cuda(), b.cuda(), s, first_div=2, lrelu=True).cpu()
+    a_rep = a[:2].unsqueeze(1).repeat(1, 2, 1, 1, 1).view(4, 24, 40, 70)
+    close(got2, torch.nn.functional.leaky_relu(O.correlation(a_rep, b, s), 0.1), 1e-5)
+    # zero padding at the border: displacement (-3,-3) at pixel (0,0) reads outside
+    assert got[:, 0, 0, 0].abs().max().item() == 0
+
+
+def test_backwarp_golden(ops, gold):
+    got = ops.backwarp(dev(gold["warp/x"]), dev(gold["warp/flow"]), 1.0)
+    close(got, torch.from_numpy(gold["warp/y"]), 1e-5)
+
+
+def test_backwarp_oracle(ops):
+    torch.manual_seed(2)
+    x, flow = torch.randn(3, 20, 33, 47), torch.randn(3, 2, 33, 47) * 4
+    flow[0, :, 0, 0] = 1e4  # far outside -> zeros
+    want = O.backwarp(x, flow * 2.0, O.backwarp_grid(33, 47))
+    close(ops.backwarp(x.cuda(), flow.cuda(), 2.0), want, 1e-4)
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_warp_fuse_blend(ops, k):
+    torch.manual_seed(4)
+    n, c, h, w = 2, 18, 16, 24
+    dec_full = torch.randn(n, c + 6, h, w)
+    ctx = torch.randn(n * k, c, h, w)
+    flows, occs = torch.randn(n * k, 2, h, w), torch.randn(n * k, 1, h, w)
+    inp = dec_full[:, :c]
+    grid = O.backwarp_grid(h, w)
+    warped = O.backwarp(ctx, flows * 4.0, grid)
+    if k > 1:
+        confs = (1 - torch.sigmoid(occs)).view(-1, k, 1, h, w) + 1e-6
+        wi = (warped.view(-1, k, c, h, w) * confs).sum(1) / confs.sum(1)
+        occ = (occs.view(-1, k, 1, h, w) * confs).sum(1) / confs.sum(1)
+    else:
+        wi, occ = warped, occs
+    m = torch.sigmoid(occ)
+    want = m * inp + (1 - m) * wi
+    d = dec_full.clone().cuda()
+    ops.warp_fuse_blend(d[:, :c], ctx.cuda(), flows.cuda(), occs.cuda(), 4.0, k)
+    close(d[:, :c], want, 1e-4)
+    close(d[:, c:], dec_full[:, c:], 0)
+
+
+# ------------------------------------------------------------------ VQ
+@pytest.mark.parametrize("name", ["default", "randn"])
+def test_vq_golden(ops, gold, name):
+    z = dev(gold[f"vq/{name}/z"])
+    cb = dev(gold[f"vq/{name}/codebook"])
+    idx = ops.vq_argmin(z, cb.t().contiguous(), (cb ** 2).sum(1)).cpu()
+    want = torch.from_numpy(gold[f"vq/{name}/idx"])
+    bad = (idx != want).nonzero().flatten()
+    if len(bad):  # audit against the reference's own top-2 gap (default init is tie-prone)
+        zf = torch.from_numpy(gold[f"vq/{name}/z"]).permute(0, 2, 3, 1).reshape(-1, cb.shape[1])
+        c = cb.cpu()
+        d = (zf ** 2).sum(1, keepdim=True) + (c ** 2).sum(1) - 2 * zf @ c.t()
+        for r in bad.tolist():
+            gap = (d[r, idx[r]] - d[r, want[r]]).abs().item()
+            assert gap <= 4 * torch.finfo(torch.float32).eps * d[r].abs().max().item(), f"row {r}: gap {gap}"
+        assert name == "default", "scaled-normal codebook must be bit-exact"
+    emb = ops.embed_gather(want.cuda(), cb, 3, 64).view(3, -1, 8, 8)
+    close(emb, torch.from_numpy(gold[f"vq/{name}/embed"]).permute(0, 3, 1, 2), 0)
+
+
+def test_vq_bair_shape(ops):
+    torch.manual_seed(1)
+    z = torch.randn(32, 512, 8, 8) * 0.3
+    cb = torch.randn(1024, 512) * 0.3
+    idx = ops.vq_argmin(z.cuda(), cb.cuda().t().contiguous(), (cb ** 2).sum(1).cuda()).cpu()
+    want = O.vq_indices(z, cb)
+    assert torch.equal(idx, want)
+    # ties keep the lowest index: duplicate codebook rows
+    cb2 = cb.clone()
+    cb2[777] = cb2[5]
+    idx2 = ops.vq_argmin(z.cuda(), cb2.cuda().t().contiguous(), (cb2 ** 2).sum(1).cuda()).cpu()
+    assert not (idx2 == 777).any()
+
+
+# ------------------------------------------------------------------ transformer pieces
+def test_layernorm_gemm(ops):
+    torch.manual_seed(0)
+    x, g, b = torch.randn(37, 1024), torch.randn(1024), torch.randn(1024)
+    close(ops.layernorm(x.cuda(), g.cuda(), b.cuda()), torch.nn.functional.layer_norm(x, (1024,), g, b), 1e-5)
+    for m, n, k in [(16, 1024, 1024), (16, 3072, 1024), (16, 1024, 4096), (5, 50, 64), (100, 200, 32), (64, 4096, 1024)]:
+        x, w, bias, res = torch.randn(m, k), torch.randn(n, k) * 0.05, torch.randn(n), torch.randn(m, n)
+        close(ops.gemm_nt(x.cuda(), w.cuda(), bias.cuda()), x @ w.t() + bias, 1e-4)
+        close(ops.gemm_nt(x.cuda(), w.cuda(), bias.cuda(), epilogue=ops.EPI_GELU), torch.nn.functional.gelu(x @ w.t() + bias), 1e-4)
+        close(ops.gemm_nt(x.cuda(), w.cuda(), None, epilogue=ops.EPI_RESIDUAL, residual=res.cuda()), x @ w.t() + res, 1e-4)
+
+
+def test_attention_cache(ops):
+    torch.manual_seed(0)
+    B, H, D, T = 3, 4, 64, 37
+    qkv = torch.randn(B, T, 3 * H * D)
+    q, k, v = qkv[..., :H * D], qkv[..., H * D:2 * H * D], qkv[..., 2 * H * D:]
+    qh, kh, vh = [t.view(B, T, H, D).transpose(1, 2) for t in (q, k, v)]
+    att = (qh @ kh.transpose(-2, -1)) / math.sqrt(D)
+    att = att.masked_fill(~torch.tril(torch.ones(T, T, dtype=torch.bool)), float("-inf")).softmax(-1)
+    want = (att @ vh).transpose(1, 2).reshape(B, T, H * D)
+    kc, vc = torch.zeros(B, H, 64, D).cuda(), torch.zeros(B, H, 64, D).cuda()
+    g = qkv.cuda()
+    gq, gk, gv = g[..., :H * D], g[..., H * D:2 * H * D], g[..., 2 * H * D:]
+    # prefill 30 tokens then decode 7 one by one
+    ops.kv_append(gk[:, :30], gv[:, :30], kc, vc, 0)
+    outs = [ops.attention(gq[:, :30], kc, vc, 0)]
+    for t in range(30, T):
+        step = g[:, t:t + 1].contiguous()
+        sq, sk, sv = step[..., :H * D], step[..., H * D:2 * H * D], step[..., 2 * H * D:]
+        ops.kv_append(sk, sv, kc, vc, t)
+        outs.append(ops.attention(sq, kc, vc, t))
+    close(torch.cat(outs, 1), want, 1e-5)
+
+
+def test_sample_topk(ops, gold):
+    logits = torch.from_numpy(gold["topk/logits"])[:, -1]
+    got = ops.sample_topk(logits.cuda(), 7, 0.7).cpu()
+    assert torch.equal(got, torch.from_numpy(gold["topk/icode"]).view(-1))
+    # sampled: identical to torch.multinomial on the same generator stream
+    torch.manual_seed(0)
+    lg = torch.randn(16, 1024)
+    probs = torch.softmax(O.top_k_logits(lg / 0.9, 100), -1)
+    g1, g2 = torch.Generator().manual_seed(123), torch.Generator().manual_seed(123)
+    want = torch.multinomial(probs, 1, generator=g1).view(-1)
+    noise = torch.empty(16, 1024).exponential_(1, generator=g2)
+    got = ops.sample_topk(lg.cuda(), 100, 0.9, noise=noise.cuda()).cpu()
+    assert torch.equal(got, want)
+    # picked tokens are always inside the top-k set
+    topk = torch.topk(lg, 100, dim=1)[1]
+    assert all(int(got[i]) in set(topk[i].tolist()) for i in range(16))
+
+
+def test_gpt_embed_pack(ops):
+    torch.manual_seed(0)
+    tok, pos = torch.randn(50, 32), torch.randn(20, 32)
+    idx, pidx = torch.randint(0, 50, (3, 7)), torch.randint(0, 20, (21,), dtype=torch.int32)
+    close(ops.gpt_embed(idx.cuda(), pidx.cuda(), tok.cuda(), pos.cuda()), tok[idx.view(-1)] + pos[pidx.long()], 0)
+    vid = torch.randn(2, 3, 3, 9, 11) * 1.5
+    assert torch.equal(ops.pack_u8(vid.cuda()).cpu(), O.pack_u8(vid))
