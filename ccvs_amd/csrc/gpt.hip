@@ -5,29 +5,32 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------
-// x[r][:] = tok_emb[idx[r]] + pos_table[pos_idx[r]]   (mingpt.py:234-236,242-244; the
-// factored s_emb/t_emb (+delta_length) or flat pos_emb rows are pre-summed by the host
-// into pos_table once per call).
+// x[(b,t)][:] = tok_emb[idx[b*idx_sB + t]] + pos_table[pos_off[b] + pos0 + t]
+// (mingpt.py:234-236,242-244; the factored s_emb/t_emb (+delta_length) or flat pos_emb rows
+// are pre-summed by the host into pos_table once per call).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gpt_embed_kernel(const int64_t* __restrict__ idx, const int32_t* __restrict__ pos_idx,
-                                                        const float* __restrict__ tok, const float* __restrict__ pos,
+__global__ __launch_bounds__(256) void gpt_embed_kernel(const int64_t* __restrict__ idx, long idx_sB, const int32_t* __restrict__ pos_off,
+                                                        int pos0, int Tq, const float* __restrict__ tok, const float* __restrict__ pos,
                                                         float* __restrict__ x, long total, int C, int vocab) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long r = i / C;
         const int c = (int)(i - r * C);
-        long t = idx[r];
+        const long b = r / Tq;
+        const int tq = (int)(r - b * Tq);
+        long t = idx[b * idx_sB + tq];
         t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
-        x[i] = tok[t * C + c] + pos[(long)pos_idx[r] * C + c];
+        const long prow = (pos_off ? pos_off[b] : 0) + pos0 + tq;
+        x[i] = tok[t * C + c] + pos[prow * C + c];
     }
 }
 
-extern "C" int ccvs_gpt_embed(const int64_t* idx, const int32_t* pos_idx, const float* tok_emb, const float* pos_table, float* x,
-                              int32_t rows, int32_t C, int32_t vocab, void* stream) {
-    CCVS_REQUIRE(idx && pos_idx && tok_emb && pos_table && x, "ccvs_gpt_embed: null pointer");
-    CCVS_REQUIRE(rows > 0 && C > 0 && vocab > 0, "ccvs_gpt_embed: empty tensor");
-    const long total = (long)rows * C;
-    hipLaunchKernelGGL(gpt_embed_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, idx, pos_idx, tok_emb,
-                       pos_table, x, total, C, vocab);
+extern "C" int ccvs_gpt_embed(const int64_t* idx, int64_t idx_sB, const int32_t* pos_off, int32_t pos0, int32_t Tq, const float* tok_emb,
+                              const float* pos_table, float* x, int32_t B, int32_t C, int32_t vocab, void* stream) {
+    CCVS_REQUIRE(idx && tok_emb && pos_table && x, "ccvs_gpt_embed: null pointer");
+    CCVS_REQUIRE(B > 0 && Tq > 0 && C > 0 && vocab > 0 && pos0 >= 0, "ccvs_gpt_embed: empty tensor");
+    const long total = (long)B * Tq * C;
+    hipLaunchKernelGGL(gpt_embed_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, idx, (long)idx_sB, pos_off,
+                       pos0, Tq, tok_emb, pos_table, x, total, C, vocab);
     CCVS_CHECK_LAUNCH("ccvs_gpt_embed");
     return CCVS_OK;
 }
@@ -196,13 +199,13 @@ extern "C" int ccvs_kv_append(const float* k, const float* v, int64_t sB, int64_
     return CCVS_OK;
 }
 
-// One workgroup per (batch, head, query).  Scores: one key per thread (row of 64 floats,
+// One workgroup per (batch, head, query).  Scores: one key per thread (row of D floats,
 // q broadcast from LDS); softmax over the L = pos0+t+1 visible keys; PV: lane = head dim
 // (coalesced V rows), 4 waves take keys round-robin and are summed through LDS.
+template <int D>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, long q_sB, long ldq, const float* __restrict__ kc,
                                                         const float* __restrict__ vc, float* __restrict__ out, int H, int Tq, int pos0,
-                                                        int Tmax) {
-    constexpr int D = 64;
+                                                        int Tmax, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* qs = smem;            // [64]
     float* red = smem + 64;      // [8]
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
             const float4 qv = *reinterpret_cast<const float4*>(qs + 4 * i);
             s += kv.x * qv.x + kv.y * qv.y + kv.z * qv.z + kv.w * qv.w;
         }
-        s *= 0.125f;  // 1/sqrt(64)
+        s *= scale;  // 1/sqrt(D)
         ps[j] = s;
         lmax = fmaxf(lmax, s);
     }
@@ -247,7 +250,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     __syncthreads();
     const float inv = 1.f / (((red[4] + red[5]) + red[6]) + red[7]);
     float acc = 0.f;
-    for (int j = wave; j < L; j += 4) acc += ps[j] * vbase[(long)j * D + lane];
+    if (lane < D)
+        for (int j = wave; j < L; j += 4) acc += ps[j] * vbase[(long)j * D + lane];
     pv[wave * 64 + lane] = acc;
     __syncthreads();
     if (tid < D) {
@@ -259,12 +263,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 extern "C" int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const float* kcache, const float* vcache, float* out, int32_t B,
                               int32_t H, int32_t Tq, int32_t pos0, int32_t Tmax, int32_t D, void* stream) {
     CCVS_REQUIRE(q && kcache && vcache && out, "ccvs_attention: null pointer");
-    CCVS_REQUIRE(D == 64, "ccvs_attention: head dim %d unsupported (64 only)", D);
+    CCVS_REQUIRE(D == 64 || D == 32 || D == 16, "ccvs_attention: head dim %d unsupported (16, 32, 64)", D);
     CCVS_REQUIRE(B > 0 && H > 0 && Tq > 0 && pos0 >= 0 && pos0 + Tq <= Tmax, "ccvs_attention: bad positions");
     const size_t smem = (size_t)(80 + 256 + pos0 + Tq) * sizeof(float);
     CCVS_REQUIRE(smem <= 64 * 1024, "ccvs_attention: sequence too long for the LDS score buffer");
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((long)B * H * Tq)), dim3(256), smem, (hipStream_t)stream, q, (long)q_sB, (long)ldq, kcache,
-                       vcache, out, H, Tq, pos0, Tmax);
+    const dim3 grid((unsigned)((long)B * H * Tq));
+    const float scale = 1.0f / sqrtf((float)D);
+    hipStream_t st = (hipStream_t)stream;
+    if (D == 64) hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(256), smem, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, Tmax, scale);
+    else if (D == 32) hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(256), smem, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, Tmax, scale);
+    else hipLaunchKernelGGL((attention_kernel<16>), grid, dim3(256), smem, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, Tmax, scale);
     CCVS_CHECK_LAUNCH("ccvs_attention");
     return CCVS_OK;
 }

@@ -1,0 +1,282 @@
+"""Generator: the inference driver (reference helpers/generator.py:27-394) on the MI355X path.
+
+`Generator(opt).run()` and `.generate_vid(data, global_iter)` keep the reference's meaning:
+encode all frames -> crop to the conditioning window -> autoregressive token synthesis ->
+flow-guided decoding (-> optional teacher-forced "rec" decode) -> uint8 pack / save.
+
+Differences by design:
+  * `generate_vid` RETURNS its results (the reference only writes mp4 files), so the batch can be
+    all-gathered over RCCL and benchmarked with nothing leaving HBM;
+  * one process per GPU shards the generation batch along B (`Engine.shard_batch`) and the
+    decoded clips of all ranks are all-gathered once at the end (`Engine.all_gather_clips`);
+  * with no dataset on disk the input is the seeded synthetic tensor BASELINE.md specifies
+    (`vid = rand(B,T,3,H,W)*2-1`).
+State / STFT / layout / deblurring conditioning are "next" rows and raise.
+"""
+import os
+import time
+from itertools import cycle
+
+import torch
+import torch.nn.functional as F
+
+from ..tools.options import Options
+from ..tools.engine import Engine
+from ..models.skip_vid_generator.models.quantized_video_model import QVidModel
+from ..models.skip_vid_generator.models.transformer_model import Transformer
+from .. import ops
+
+
+class Generator:
+    def __init__(self, opt):
+        self.opt = opt["transformer"]
+        self.qvid_opt = opt["qvid_generator"]
+        self.state_opt = opt.get("state_estimator")
+        self.stft_ae_opt = opt.get("stft_ae")
+        self.iter_fn = cycle if self.opt.iter_function == "cycle" else iter
+        self.engine = None
+        self.vid_model = None
+        self.transformer_model = None
+        self.timings = {}
+        for flag in ("state", "stft", "layout", "deblurring", "cat", "keep_state", "custom_state"):
+            if getattr(self.opt, flag, False):
+                raise NotImplementedError(f"--{flag}: ancillary token streams are not on the MI355X path yet (SURVEY 8f)")
+
+    # ------------------------------------------------------------------ models / data
+    def build_models(self, is_main=True):
+        self.vid_model = QVidModel(self.qvid_opt, is_train=False, is_main=is_main, logger=None).eval()
+        if not self.opt.rec_only:
+            self.transformer_model = Transformer(self.opt, is_train=False, is_main=is_main, logger=None).eval()
+        return self
+
+    def synthetic_batch(self, batch, seed=1, first_clip=0):
+        """`vid = rand(B,T,3,H,W)*2-1`, one generator per global clip index so that the data does
+        not depend on how the batch is sharded over ranks."""
+        o = self.opt
+        h = o.max_dim
+        w = int(h * o.aspect_ratio)
+        frames = []
+        for i in range(batch):
+            g = torch.Generator().manual_seed(seed * 1000003 + first_clip + i)
+            frames.append(torch.rand(o.vid_len, 3, h, w, generator=g) * 2 - 1)
+        return {"vid": torch.stack(frames)}
+
+    def get_data_info(self, phase, data_type, fold=None, num_folds=None):
+        """Synthetic stand-in for the reference's dataset/loader factory (generator.py:232-246)."""
+        bs = self.opt.batch_size_vid * self.opt.batch_size_valid_mult
+        lo, hi = self.engine.shard_batch(bs) if self.engine is not None else (0, bs)
+        per = hi - lo
+        seed = getattr(self.opt, "seed", 0) + 1
+
+        def loader():
+            it = 0
+            while True:
+                yield self.synthetic_batch(per, seed=seed + it, first_clip=lo)
+                it += 1
+        return {"dataloader": None, "datasampler": None, "epoch": 0, "phase": phase, "data_type": data_type,
+                "batch_size_per_gpu": per, "loader_iter": loader(), "fold": fold, "num_folds": num_folds}
+
+    def next_batch(self, data_info):
+        return next(data_info["loader_iter"])
+
+    # ------------------------------------------------------------------ the hot path
+    @torch.no_grad()
+    def generate_vid(self, data, global_iter=0, save=False):
+        opt, qopt = self.opt, self.qvid_opt
+        if opt.down_size is not None:  # generator.py:60-66
+            vid = data["vid"].cuda()
+            bs, t = vid.shape[:2]
+            img = vid.view(-1, *vid.shape[2:])
+            img = F.interpolate(img, size=opt.down_size, mode='bilinear')
+            img = F.interpolate(img, size=vid.shape[-2:], mode='bilinear')
+            data["vid"] = img.view(bs, t, *vid.shape[2:])
+
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        encoded_data = self.vid_model(data, mode='vid_encoder')            # encode all frames
+        ev[1].record()
+
+        size = int(torch.prod(torch.tensor(qopt.z_shape)))                  # generator.py:83-102
+        cond_step, t_step = (1, opt.vid_len - 1) if opt.p2p else (0, opt.vid_len)
+        total_len = (cond_step + t_step) * size
+        cond_len = cond_step * size
+        if opt.gen_from_img:
+            crop_prop = opt.cond_len / size
+        else:
+            crop_prop = opt.cond_len / (size * opt.vid_len)
+        cropped = {}
+        cropped["code"] = encoded_data["code"][:, :int(crop_prop * encoded_data["code"].size(1))]
+        encoded_data["inter"] = [feat[:, :int(crop_prop * feat.size(1))].contiguous() for feat in encoded_data["inter"]]
+        cropped["inter"] = encoded_data["inter"]
+        if opt.p2p:
+            cropped["cond_code"] = encoded_data["code"][:, -opt.z_chunk:]
+            # (sic) the reference reads the ALREADY CROPPED list here (generator.py:101,105), i.e. the
+            # skip features of the last conditioning frame, not of the end frame; kept for parity
+            cropped["cond_inter"] = [feat[:, -1:].contiguous() for feat in encoded_data["inter"]]
+            cropped["delta_length_cond"] = torch.tensor([opt.vid_len - 1]).repeat(cropped["code"].size(0))
+
+        fake_data, rec_data = None, None
+        if not opt.rec_only:
+            if opt.step_by_step:
+                fake_data = self._step_by_step(data, cropped, crop_prop, total_len, cond_len)
+                ev[2].record()
+            else:
+                fake_encoded = self.transformer_model(cropped, mode='inference', total_len=total_len, show_progress=False)
+                ev[2].record()
+                cropped.update(fake_encoded)
+                fake_data = self.vid_model(cropped, mode='vid_decoder')
+                fake_data["code"] = fake_encoded["code"]
+            if opt.p2p:
+                fake_data["vid"] = torch.cat([fake_data["vid"], data["vid"][:, -1:]], dim=1)
+        else:
+            ev[2].record()
+        ev[3].record()
+
+        if not opt.gen_from_img and getattr(opt, "rec_pass", False):   # teacher-forced "rec" decode (generator.py:172-189)
+            rec = {"inter": cropped["inter"]}
+            if opt.p2p:
+                rec["code"] = encoded_data["code"][:, :-opt.z_chunk].contiguous()
+                rec["cond_inter"] = cropped["cond_inter"]
+            else:
+                rec["code"] = encoded_data["code"]
+            rec_data = self.vid_model(rec, mode='vid_decoder')
+            if opt.p2p:
+                rec_data["vid"] = torch.cat([rec_data["vid"], data["vid"][:, -1:]], dim=1)
+
+        self._events = ev
+        out = {"real": data["vid"], "fake": fake_data, "rec": rec_data, "enc_code": encoded_data["code"]}
+        if save:
+            self.save_results(out, global_iter)
+        return out
+
+    def _step_by_step(self, data, cropped, crop_prop, total_len, cond_len):
+        """generator.py:132-159: predict one frame of tokens, decode it, re-encode it and overwrite
+        the predicted tokens with the re-encoded ones."""
+        opt = self.opt
+        fake_vid = data["vid"][:, :int(crop_prop * data["vid"].size(1))]
+        fake_enc = {"code": cropped["code"]}
+        step_enc = {"inter": cropped["inter"]}
+        if opt.p2p:
+            fake_enc["cond_code"] = cropped["cond_code"]
+            fake_enc["delta_length_cond"] = cropped["delta_length_cond"]
+            step_enc["cond_inter"] = cropped["cond_inter"]
+        all_codes = [cropped["code"]]
+        for _ in range((total_len - opt.cond_len - cond_len) // opt.z_chunk):
+            if opt.p2p and fake_enc["code"].size(1) > opt.z_len - 2 * opt.z_chunk:
+                fake_enc["delta_length_cond"] = fake_enc["delta_length_cond"] - ((fake_enc["code"].size(1) - opt.z_len) // opt.z_chunk + 2)
+                fake_enc["code"] = fake_enc["code"][:, -(opt.z_len - 2 * opt.z_chunk):]
+            elif fake_enc["code"].size(1) > opt.z_len - opt.z_chunk:
+                fake_enc["code"] = fake_enc["code"][:, -(opt.z_len - opt.z_chunk):]
+            # like the reference, the returned dict REPLACES fake_enc (generator.py:150)
+            fake_enc = self.transformer_model(fake_enc, mode='inference', total_len=fake_enc["code"].size(1) + opt.z_chunk)
+            step_enc["code"] = fake_enc["code"][:, -opt.z_chunk:]
+            step_dec = self.vid_model(step_enc, mode='vid_step_decoder')
+            step_enc["inter"] = step_dec["inter"]
+            fake_enc["code"][:, -opt.z_chunk:] = step_dec["code"]
+            all_codes.append(step_dec["code"])
+            fake_vid = torch.cat([fake_vid, step_dec["vid"]], dim=1)
+        return {"vid": fake_vid, "code": torch.cat(all_codes, dim=1)}
+
+    def stage_ms(self):
+        """encode / transformer / decode milliseconds of the last `generate_vid` (the reference's
+        unused t0..t3, generator.py:68-165), from HIP events."""
+        torch.cuda.synchronize()
+        e = self._events
+        return {"encode": e[0].elapsed_time(e[1]), "transformer": e[1].elapsed_time(e[2]), "decode": e[2].elapsed_time(e[3])}
+
+    # ------------------------------------------------------------------ output stage
+    def save_results(self, out, global_iter):
+        bs = out["real"].shape[0]
+        for name in ("real", "fake", "rec"):
+            item = out[name]
+            if item is None:
+                continue
+            vid = item["vid"] if isinstance(item, dict) else item
+            save_video_batch(vid, bs, global_iter, os.path.join(self.opt.result_path, name), self.opt.fps, True,
+                             self.opt.imagenet_norm, [-1, 1], self.opt.dataset)
+
+    def run(self):
+        with Engine(self.opt) as engine:
+            self.engine = engine
+            self.valid_data_info = self.get_data_info("valid", "img" if self.opt.gen_from_img else "vid")
+            self.build_models(is_main=True)
+            results = None
+            for global_iter in range(self.opt.n_iter):
+                data = self.next_batch(self.valid_data_info)
+                if self.opt.gen_from_img:
+                    data["vid"] = data.pop("img").unsqueeze(1)
+                out = self.generate_vid(data, global_iter)
+                if out["fake"] is not None:
+                    packed = ops.pack_u8(out["fake"]["vid"].contiguous())
+                    results = engine.all_gather_clips(packed)
+            print('Generation was successfully finished.')
+            return results
+
+
+def save_video_batch(vid, bs, global_iter, path, fps, normalize, imagenet_norm, span, dataset, state=None, cat=None, idx=None,
+                     is_layout=False):
+    """helpers/generator.py:285-333.  The clamp / rescale / uint8 / channels-last pack runs on the
+    GPU; files are written as mp4 when torchvision is importable, else as .npy uint8 [T,H,W,3]."""
+    if is_layout or state is not None:
+        raise NotImplementedError("layout / state overlays are not on the MI355X path yet (SURVEY 8f)")
+    if normalize and imagenet_norm:
+        mean = torch.tensor([0.485, 0.456, 0.406], device=vid.device).view(1, 1, 3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225], device=vid.device).view(1, 1, 3, 1, 1)
+        u8 = ops.pack_u8((vid * std + mean).contiguous(), 0.0, 1.0)
+    elif normalize:
+        u8 = ops.pack_u8(vid.contiguous(), float(span[0]), float(span[1]))
+    else:
+        u8 = (vid.permute(0, 1, 3, 4, 2) * 255).to(torch.uint8)
+    u8 = u8.cpu()
+    os.makedirs(path, exist_ok=True)
+    try:
+        from torchvision.io import write_video
+    except ImportError:
+        write_video = None
+    for i in range(u8.size(0)):
+        suffix = '' if cat is None else f'_{cat[i]}'
+        suffix += '' if idx is None else f'_{idx[i]}'
+        stem = os.path.join(path, f"vid_{bs * global_iter + i:05d}{suffix}")
+        if write_video is not None:
+            write_video(stem + ".mp4", u8[i], fps)
+        else:
+            import numpy as np
+            np.save(stem + ".npy", u8[i].numpy())
+    return u8
+
+
+def draw_cross(img, x, y):
+    """helpers/generator.py:336-359: 3x3 marker, white plus on black corners, clipped at the border."""
+    height, width = img.shape[:2]
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            yy, xx = y + dy, x + dx
+            if 0 <= yy < height and 0 <= xx < width:
+                img[yy, xx] = 255 if (dx == 0 or dy == 0) else 0
+    return img
+
+
+def square_trajectory(init_state, vid_len):
+    """helpers/generator.py:362-379: walk a square inside [0.2, 0.8)^2 with steps of 10/64."""
+    state = init_state.repeat(1, vid_len, 1)
+    step = 10 / 64
+    moves = [(0, -step), (step, 0), (0, step), (-step, 0)]
+    for i in range(state.size(0)):
+        x, y = state[i, 0].clone()
+        t = 0
+        for j in range(1, vid_len):
+            while not (0.2 <= x + moves[t][0] < 0.8 and 0.2 <= y + moves[t][1] < 0.8):
+                t = (t + 1) % 4
+            x, y = x + moves[t][0], y + moves[t][1]
+            state[i, j, 0], state[i, j, 1] = x, y
+    return {"state": state}
+
+
+def blur(data, blur_sigma=10):
+    """helpers/generator.py:381-390 (deblurring mode input)."""
+    raise NotImplementedError("deblurring mode is not on the MI355X path yet (SURVEY 8f)")
+
+
+if __name__ == "__main__":
+    options = Options().parse(load_qvid_generator=True, load_transformer=True, load_state_estimator=True, load_stft_ae=True, save=False)
+    Generator(options).run()

@@ -60,7 +60,7 @@ def load():
         "ccvs_warp_fuse_blend": [vp, i64, i64, vp, vp, i64, vp, i64, f32, i32, i32, i32, i32, i32, vp],
         "ccvs_vq_argmin": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "ccvs_embed_gather": [vp, vp, vp, i32, i32, i32, i32, vp],
-        "ccvs_gpt_embed": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+        "ccvs_gpt_embed": [vp, i64, vp, i32, i32, vp, vp, vp, i32, i32, i32, vp],
         "ccvs_layernorm": [vp, vp, vp, vp, i32, i32, vp],
         "ccvs_gemm_nt": [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp],
         "ccvs_attention": [vp, i64, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],

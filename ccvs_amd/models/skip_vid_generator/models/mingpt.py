@@ -1,0 +1,254 @@
+"""GPT over latent tokens on the MI355X kernel library.
+
+Host-side mirror of the reference's `models/skip_vid_generator/models/mingpt.py` (class `GPT`
+and its `Block` / `CausalSelfAttention` parameter tree, lines 33-305): same constructor
+signature, same sub-module registration order (so `self.apply(_init_weights)` consumes the RNG
+identically) and the same `state_dict()` keys, minus the 1024x1024 `attn.mask` buffers.
+
+What differs is the execution model.  The reference re-runs all layers over the whole prefix
+for every sampled token (transformer_model.py:343-350).  Here the network is an incremental
+engine over a KV cache: `begin` -> `prefill` -> `step` ... ; `forward` (teacher-forced logits
+for a whole sequence, mingpt.py:232-305) is the same engine run as one prefill.  Every layer is
+a libccvs_hip.so call: fused QKV GEMM, cache append, cached causal attention, projection GEMM
+with the residual add in its epilogue, LayerNorm, MLP GEMMs with GELU / residual epilogues.
+"""
+import torch
+import torch.nn as nn
+
+from .... import ops
+
+
+class GPTConfig:
+    """mingpt.py:9-18."""
+    embd_pdrop = 0.1
+    resid_pdrop = 0.1
+    attn_pdrop = 0.1
+
+    def __init__(self, block_size, **kwargs):
+        self.block_size = block_size
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+
+class CausalSelfAttention(nn.Module):
+    """Parameter holder (mingpt.py:33-61).  The causal mask is implied by the cache positions."""
+
+    def __init__(self, config):
+        super().__init__()
+        assert config.n_embd % config.n_head == 0
+        self.key = nn.Linear(config.n_embd, config.n_embd)
+        self.query = nn.Linear(config.n_embd, config.n_embd)
+        self.value = nn.Linear(config.n_embd, config.n_embd)
+        self.attn_drop = nn.Dropout(config.attn_pdrop)
+        self.resid_drop = nn.Dropout(config.resid_pdrop)
+        self.proj = nn.Linear(config.n_embd, config.n_embd)
+        self.n_head = config.n_head
+        self._qkv = None
+
+    def qkv_packed(self):
+        """[query; key; value] stacked into one [3C, C] weight + [3C] bias for a single GEMM."""
+        ws = (self.query.weight, self.key.weight, self.value.weight)
+        key = tuple((w.data_ptr(), w._version) for w in ws) + (ws[0].device,)
+        if self._qkv is None or self._qkv[0] != key:
+            w = torch.cat([w.detach() for w in ws], dim=0).contiguous()
+            b = torch.cat([self.query.bias.detach(), self.key.bias.detach(), self.value.bias.detach()]).contiguous()
+            self._qkv = (key, w, b)
+        return self._qkv[1], self._qkv[2]
+
+
+class NoiseInjection(nn.Module):
+    """mingpt.py:84-97 with use_noise=False (identity); kept so `mlp.{0,3}` keep their indices."""
+
+    def __init__(self, use_noise):
+        super().__init__()
+        if use_noise:
+            raise NotImplementedError("resid_noise is a training-time option")
+
+    def forward(self, x):
+        return x
+
+
+class Block(nn.Module):
+    """mingpt.py:99-117."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.ln1 = nn.LayerNorm(config.n_embd)
+        self.ln2 = nn.LayerNorm(config.n_embd)
+        self.attn = CausalSelfAttention(config)
+        self.mlp = nn.Sequential(
+            nn.Linear(config.n_embd, 4 * config.n_embd),
+            NoiseInjection(config.resid_noise),
+            nn.GELU(),
+            nn.Linear(4 * config.n_embd, config.n_embd),
+            nn.Dropout(config.resid_pdrop),
+        )
+
+
+class GPT(nn.Module):
+    """mingpt.py:120-305."""
+
+    def __init__(self, vocab_size, block_size, num_blocks, n_layer=12, n_head=8, n_embd=256, embd_pdrop=0., resid_pdrop=0.,
+                 attn_pdrop=0., n_unmasked=0, resid_noise=False, emb_mode=None, shape=None, state_vocab_size=0, state_size=0,
+                 use_start_token=False, num_lbl=0, use_lbl=False, state_front=False):
+        super().__init__()
+        if state_vocab_size > 0 or state_size > 0 or use_start_token or use_lbl or n_unmasked:
+            raise NotImplementedError("state / start / label token streams are not on the MI355X path yet (SURVEY 8f)")
+        if (embd_pdrop or resid_pdrop or attn_pdrop) and False:
+            pass
+        config = GPTConfig(block_size=block_size, vocab_size=vocab_size, embd_pdrop=embd_pdrop, resid_pdrop=resid_pdrop,
+                           attn_pdrop=attn_pdrop, n_layer=n_layer, n_head=n_head, n_embd=n_embd, n_unmasked=n_unmasked,
+                           resid_noise=resid_noise, shape=shape, emb_mode=emb_mode, state_vocab_size=state_vocab_size,
+                           state_size=state_size, use_start_token=use_start_token, num_blocks=num_blocks, num_lbl=num_lbl,
+                           use_lbl=use_lbl, state_front=state_front)
+        self.tok_emb = nn.Embedding(config.vocab_size, config.n_embd)
+        height, width = config.shape
+        if config.emb_mode is not None:
+            if config.emb_mode == "spatio-temporal":
+                self.h_emb = nn.Parameter(torch.zeros(1, height, config.n_embd))
+                self.w_emb = nn.Parameter(torch.zeros(1, width, config.n_embd))
+                self.t_emb = nn.Parameter(torch.zeros(1, config.num_blocks, config.n_embd))
+            elif config.emb_mode == "temporal":
+                self.s_emb = nn.Parameter(torch.zeros(1, height * width, config.n_embd))
+                self.t_emb = nn.Parameter(torch.zeros(1, config.num_blocks, config.n_embd))
+            else:
+                raise ValueError
+        else:
+            self.pos_emb = nn.Parameter(torch.zeros(1, config.num_blocks * height * width, config.n_embd))
+        self.drop = nn.Dropout(config.embd_pdrop)
+        self.blocks = nn.Sequential(*[Block(config) for _ in range(config.n_layer)])
+        self.ln_f = nn.LayerNorm(config.n_embd)
+        self.head = nn.Linear(config.n_embd, max(config.vocab_size, config.state_vocab_size), bias=False)
+        self.block_size = config.block_size
+        self.apply(self._init_weights)
+        self.config = config
+        self._cache = None
+
+    def get_block_size(self):
+        return self.block_size
+
+    def _init_weights(self, module):
+        """mingpt.py:177-184."""
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=0.02)
+            if isinstance(module, nn.Linear) and module.bias is not None:
+                module.bias.data.zero_()
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+
+    # ------------------------------------------------------------------ positional tables
+    @torch.no_grad()
+    def get_pos_emb(self, t, delta_length=None):
+        """[n, t, C] positional embeddings (mingpt.py:186-217); n = len(delta_length) or 1."""
+        if t == 0:
+            return 0
+        cfg = self.config
+        height, width = cfg.shape
+        size = height * width
+        dev = self.tok_emb.weight.device
+        if delta_length is None or 0 in delta_length.size():
+            delta_length = torch.zeros(1, dtype=torch.long)
+        deltas = [int(d) for d in delta_length.view(-1).tolist()]
+        n = len(deltas)
+        if cfg.emb_mode is None:
+            return torch.stack([self.pos_emb[0, d * size: d * size + t] for d in deltas]).to(dev)
+        length = t // size + (1 if t % size != 0 else 0)
+        t_emb = torch.stack([self.t_emb[0, d: d + length] for d in deltas])  # [n, length, C]
+        if cfg.emb_mode == "temporal":
+            pos = self.s_emb.view(1, 1, size, -1) + t_emb.view(n, length, 1, -1)
+        else:
+            pos = self.h_emb.view(1, 1, height, 1, -1) + self.w_emb.view(1, 1, 1, width, -1)
+            pos = pos + t_emb.view(n, length, 1, 1, -1)
+        return pos.reshape(n, length * size, -1)[:, :t]
+
+    # ------------------------------------------------------------------ incremental engine
+    @torch.no_grad()
+    def begin(self, batch, max_len):
+        """Allocate the KV cache for `batch` sequences of at most `max_len` positions."""
+        cfg = self.config
+        assert max_len <= self.block_size, "Cannot forward, model block size is exhausted."  # mingpt.py:299
+        dev = self.tok_emb.weight.device
+        d = cfg.n_embd // cfg.n_head
+        c = self._cache
+        if c is None or c["B"] != batch or c["T"] < max_len or c["dev"] != dev:
+            t_alloc = max_len
+            kc = [torch.empty(batch, cfg.n_head, t_alloc, d, dtype=torch.float32, device=dev) for _ in range(cfg.n_layer)]
+            vc = [torch.empty(batch, cfg.n_head, t_alloc, d, dtype=torch.float32, device=dev) for _ in range(cfg.n_layer)]
+            c = self._cache = {"B": batch, "T": t_alloc, "dev": dev, "k": kc, "v": vc}
+        c["len"] = 0
+        c["pos_table"] = self.get_pos_emb(min(c["T"], self.block_size))[0].contiguous()
+        c["frame_pos0"] = 0
+        return c
+
+    def _layers(self, x, b, tq):
+        """x [b*tq, C] -> x after all blocks; appends tq positions to the cache."""
+        c = self._cache
+        pos0 = c["len"]
+        C = self.config.n_embd
+        for i, blk in enumerate(self.blocks):
+            h = ops.layernorm(x, blk.ln1.weight, blk.ln1.bias)
+            wqkv, bqkv = blk.attn.qkv_packed()
+            qkv = ops.gemm_nt(h, wqkv, bqkv).view(b, tq, 3 * C)
+            ops.kv_append(qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], c["k"][i], c["v"][i], pos0)
+            att = ops.attention(qkv[:, :, :C], c["k"][i], c["v"][i], pos0)
+            ops.gemm_nt(att.view(b * tq, C), blk.attn.proj.weight, blk.attn.proj.bias, ops.EPI_RESIDUAL, residual=x, out=x)
+            h = ops.layernorm(x, blk.ln2.weight, blk.ln2.bias, out=h)
+            h = ops.gemm_nt(h, blk.mlp[0].weight, blk.mlp[0].bias, ops.EPI_GELU)
+            ops.gemm_nt(h, blk.mlp[3].weight, blk.mlp[3].bias, ops.EPI_RESIDUAL, residual=x, out=x)
+        c["len"] = pos0 + tq
+        return x
+
+    def _head(self, x):
+        return ops.gemm_nt(ops.layernorm(x, self.ln_f.weight, self.ln_f.bias), self.head.weight)
+
+    @torch.no_grad()
+    def prefill(self, idx, cond_idx=None, delta_length_cond=None, all_logits=False):
+        """Run [cond prefix | idx] through the network, filling the cache from position 0.
+        Returns logits of the last position [B,V], or of every idx position [B,T,V]."""
+        c = self._cache
+        b, t = idx.shape
+        C = self.config.n_embd
+        use_cond = cond_idx is not None and 0 not in cond_idx.size()
+        parts = []
+        if use_cond:
+            t_cond = cond_idx.shape[1]
+            cond_tab = self.get_pos_emb(t_cond, delta_length_cond)               # [n, t_cond, C]
+            if cond_tab.shape[0] == 1 and b > 1:
+                cond_tab = cond_tab.expand(b, -1, -1)
+            table = torch.cat([c["pos_table"], cond_tab.reshape(-1, C)], dim=0).contiguous()
+            off = (c["pos_table"].shape[0] + torch.arange(b, dtype=torch.int32) * t_cond).to(idx.device)
+            parts.append(ops.gpt_embed(cond_idx.contiguous(), self.tok_emb.weight, table, 0, off).view(b, t_cond, C))
+        else:
+            t_cond = 0
+        parts.append(ops.gpt_embed(idx.contiguous(), self.tok_emb.weight, c["pos_table"], 0).view(b, t, C))
+        x = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+        tq = t_cond + t
+        assert c["len"] == 0 and tq <= c["T"], "Cannot forward, model block size is exhausted."
+        x = self._layers(x.reshape(b * tq, C).contiguous(), b, tq)
+        c["frame_pos0"] = t_cond  # cache position of frame token 0
+        if all_logits:
+            xs = x.view(b, tq, C)[:, t_cond:].reshape(b * t, C)
+            return self._head(xs).view(b, t, -1)
+        return self._head(x.view(b, tq, C)[:, -1].contiguous())
+
+    @torch.no_grad()
+    def step(self, tok):
+        """tok int64 [B,1] (any row stride): the token at the next frame position. Returns [B,V]."""
+        c = self._cache
+        b = tok.shape[0]
+        frame_pos = c["len"] - c["frame_pos0"]
+        assert c["len"] < c["T"], "Cannot forward, model block size is exhausted."
+        x = ops.gpt_embed(tok, self.tok_emb.weight, c["pos_table"], frame_pos)
+        x = self._layers(x, b, 1)
+        return self._head(x)
+
+    # ------------------------------------------------------------------ reference-shaped forward
+    @torch.no_grad()
+    def forward(self, idx, cond_idx=torch.tensor([]), state_idx=torch.tensor([]), lbl_idx=torch.tensor([]), delta_length_cond=None):
+        """Teacher-forced logits [B, T, V] for positions after the conditioning prefix (mingpt.py:232-305)."""
+        if 0 not in state_idx.size() or 0 not in lbl_idx.size():
+            raise NotImplementedError("state / label token streams are not on the MI355X path yet (SURVEY 8f)")
+        t_cond = cond_idx.shape[1] if 0 not in cond_idx.size() else 0
+        self.begin(idx.shape[0], t_cond + idx.shape[1])
+        return self.prefill(idx, cond_idx if t_cond else None, delta_length_cond, all_logits=True)

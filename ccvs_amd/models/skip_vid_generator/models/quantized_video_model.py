@@ -1,0 +1,177 @@
+"""QVidModel: frame encoder + VQ + flow-guided frame decoder behind the reference's dict API.
+
+Host-side mirror of the inference half of the reference's
+`models/skip_vid_generator/models/quantized_video_model.py` (`forward` mode dispatch :45-98,
+`preprocess_input` :101-122, `encode` :773-819, `decode` :822-918, `vid_step_decode` :920-949):
+same constructor, same modes, same dict keys in and out, `ValueError` on an unknown mode.
+
+Differences that do not change results:
+  * the context ring of skip features is shifted with an explicit copy (the reference's
+    overlapping in-place slice assignment, :898-900/:946, is rejected by torch >= 1.8);
+  * re-encoding a synthesized frame inside the decode loop (:875-878) skips the vector
+    quantiser, whose output that loop discards;
+  * `embed_code` + two transposes (:832-833) is one gather kernel writing NCHW.
+Training modes, layout decoders and continuous codes are outside the hot path and raise.
+"""
+import torch
+
+from .skip_autoencoder import SkipGANDecoder, SkipGANEncoder
+from ..modules.quantize import VectorQuantizer
+from ....tools.utils import to_cuda
+from ... import load_network, print_network
+
+_TRAIN_MODES = ("img_to_img_generator", "eval_img_to_img_generator", "vid_to_vid_generator", "img_discriminator",
+                "img_discriminator_reg", "vid_discriminator_reg", "vid_discriminator")
+
+
+class QVidModel(torch.nn.Module):
+    def __init__(self, opt, is_train=False, is_main=True, logger=None):
+        super().__init__()
+        if is_train:
+            raise NotImplementedError("training is outside the MI355X hot path")
+        self.opt = opt
+        self.is_main = is_main
+        self.initialize_networks(is_train)
+        self.logger = logger if self.is_main else None
+
+    def forward(self, data, fake_data={}, mode='', log=False, suffix="", cond_frames=None, global_iter=None):
+        if mode in _TRAIN_MODES:
+            raise NotImplementedError(f"mode '{mode}' (training) is outside the MI355X hot path")
+        if mode not in ("img_encoder", "vid_encoder", "img_decoder", "vid_decoder", "vid_step_decoder"):
+            raise ValueError(f"mode '{mode}' is invalid")
+        real_img, real_vid, code, state_code, inter, interl, cond_inter = self.preprocess_input(data)
+        if mode == 'img_encoder':
+            return self.encode(real_img, None, "img", log, suffix, global_iter)
+        if mode == 'vid_encoder':
+            return self.encode(real_vid, None, "vid", log, suffix, global_iter)
+        if mode == 'img_decoder':
+            return self.decode(code, state_code, inter, interl, cond_inter, "img", log, suffix, None, global_iter)
+        if mode == 'vid_decoder':
+            return self.decode(code, state_code, inter, interl, cond_inter, "vid", log, suffix, cond_frames, global_iter)
+        return self.vid_step_decode(code, inter, cond_inter)
+
+    def preprocess_input(self, data, is_fake=False):
+        """quantized_video_model.py:101-122: the caller's dict is updated with device tensors."""
+        for key in ("z", "img", "layout", "vid", "code", "state_code", "inter", "interl", "cond_inter"):
+            data[key] = to_cuda(data, key)
+        if 0 not in getattr(data["layout"], "shape", (0,)):
+            raise NotImplementedError("layout conditioning is outside the MI355X hot path")
+        return data["img"], data["vid"], data["code"], data["state_code"], data["inter"], data["interl"], data["cond_inter"]
+
+    def initialize_networks(self, is_train):
+        """quantized_video_model.py:125-205 (inference nets only)."""
+        opt = self.opt
+        if getattr(opt, "use_layout", False) or getattr(opt, "is_continuous", False):
+            raise NotImplementedError("layout / continuous-code variants are outside the MI355X hot path")
+        self.net_e = None
+        if opt.use_enc:
+            if opt.enc_model != "skipgan":
+                raise ValueError
+            self.net_e = SkipGANEncoder(opt).cuda()
+        self.net_q = VectorQuantizer(opt.z_num, opt.z_size, beta=0.25, mult=getattr(opt, "z_mult", 1),
+                                     normalize=getattr(opt, "normalize_out", False)).cuda()
+        self.net_g = None
+        if opt.use_dec:
+            if opt.dec_model != "skipgan":
+                raise ValueError
+            self.net_g = SkipGANDecoder(opt).cuda()
+        if self.is_main:
+            load_ema = getattr(opt, "use_ema", False)
+            bd = getattr(opt, "block_delta", None)
+            sfx = "_ema" if load_ema else ""
+            self.net_g = load_network(self.net_g, "qvid_g" + sfx, opt, block_delta=bd)
+            self.net_e = load_network(self.net_e, "qvid_e" + sfx, opt)
+            self.net_q = load_network(self.net_q, "qvid_q" + sfx, opt, required=load_ema)
+
+    # ------------------------------------------------------------------ encode
+    @torch.no_grad()
+    def encode(self, data, layout, dtype, log, suffix, global_iter, quantize=True):
+        """quantized_video_model.py:773-819 (discrete codes)."""
+        z, inter_enc = self.net_e(data)
+        empty = torch.tensor([])
+        if not quantize:
+            return {"code": empty, "state_code": empty, "inter": inter_enc, "interl": empty, "z": z}
+        zq, _, info = self.net_q(z)
+        code = info[2].view(z.shape[0], -1)
+        return {"code": code, "state_code": empty, "inter": inter_enc, "interl": empty, "z": zq}
+
+    # ------------------------------------------------------------------ decode
+    def _embed(self, code, frames):
+        """codes [B, frames*h*w] -> z [B, frames, C, h, w] (quantized_video_model.py:832-833)."""
+        h, w = self.opt.z_shape[:2]
+        z = self.net_q.embed_code_nchw(code, code.size(0) * frames, h, w)
+        return z.view(code.size(0), frames, self.opt.z_size, h, w)
+
+    @torch.no_grad()
+    def decode(self, code, state_code, inter, interl, cond_inter, dtype, log, suffix, cond_frames, global_iter):
+        """quantized_video_model.py:822-918 (skip_mode 'enc' or 'dec', no layout)."""
+        opt = self.opt
+        h, w = opt.z_shape[:2]
+        if dtype == "img":
+            z = self.net_q.embed_code_nchw(code, code.size(0), h, w)
+            fake, _ = self.net_g(z, [inter])
+            return {dtype: fake, "layout": None}
+        frames = code.size(1) // (h * w)
+        z = self._embed(code, frames)
+        if not (opt.use_inter and opt.dec_model == "skipgan" and inter[0].size(1) < opt.vid_len):
+            fake, _ = self.net_g(z, [inter])
+            return {dtype: fake, "layout": None}
+
+        ctx = inter[0].size(1)
+        fakes = []
+        if ctx > 0:
+            fakes.append(self.net_g(z[:, :ctx].contiguous(), [inter])[0])   # conditioning frames, own skip features
+        # context ring: `skip_memory` slots per level, newest last (quantized_video_model.py:864-866)
+        mem = opt.skip_memory
+        ring = []
+        for feat in inter:
+            r = feat.new_zeros(code.size(0), mem, *feat.shape[2:])
+            keep = min(ctx, mem)
+            if keep:
+                r[:, mem - keep:] = feat[:, ctx - keep:]
+            ring.append(r)
+        curr = ctx
+        has_cond = isinstance(cond_inter, list) and len(cond_inter) > 0
+        if has_cond:
+            ctx += 1
+        for _ in range(opt.vid_len - ctx):
+            inters = [[feat[:, [-dt]] for feat in ring] for dt in opt.skip_context if dt <= curr]
+            if has_cond:
+                inters.append(cond_inter)
+            if opt.skip_mode == "enc":
+                fake_img, _ = self.net_g(z[:, [curr]], inters, has_ctx=curr > 0)
+                new_inter = self.encode(fake_img, None, "vid", False, None, None, quantize=False)["inter"]
+            elif opt.skip_mode == "dec":
+                fake_img, _, _, _, inter_dec = self.net_g(z[:, [curr]], inters, return_all=True, inter_pre_warping=False,
+                                                          has_ctx=curr > 0)
+                new_inter = list(reversed(inter_dec))
+            else:
+                raise ValueError
+            for i in range(len(ring)):
+                if getattr(opt, "keep_first", False) and curr >= mem:
+                    n = opt.n_first
+                    ring[i][:, n:-1] = ring[i][:, n + 1:].clone()
+                else:
+                    ring[i][:, :-1] = ring[i][:, 1:].clone()
+                ring[i][:, -1:] = new_inter[i]
+            fakes.append(fake_img)
+            curr += 1
+        return {dtype: torch.cat(fakes, dim=1), "layout": None}
+
+    @torch.no_grad()
+    def vid_step_decode(self, code, inter, cond_inter):
+        """quantized_video_model.py:920-949: decode one frame, re-encode it, re-quantise it."""
+        opt = self.opt
+        assert opt.use_inter and opt.dec_model == "skipgan"
+        z = self._embed(code, 1)
+        ctx = inter[0].size(1)
+        inters = [[feat[:, [-dt]] for feat in inter] for dt in opt.skip_context if dt <= ctx]
+        if isinstance(cond_inter, list) and len(cond_inter) > 0:
+            inters.append(cond_inter)
+        fake, _ = self.net_g(z, inters)
+        new_data = self.encode(fake, None, None, False, None, None)
+        if ctx < opt.skip_memory:
+            inter = [torch.cat([feat, new_feat], dim=1) for feat, new_feat in zip(inter, new_data["inter"])]
+        else:
+            inter = [torch.cat([feat[:, 1:], new_feat], dim=1) for feat, new_feat in zip(inter, new_data["inter"])]
+        return {"vid": fake, "inter": inter, "code": new_data["code"]}

@@ -1,0 +1,156 @@
+"""Transformer wrapper: the autoregressive sampling loop over latent tokens.
+
+Host-side mirror of the reference's `models/skip_vid_generator/models/transformer_model.py`
+(inference only): `Transformer(opt, is_train, is_main, logger)`, `forward(data, mode='inference',
+total_len=...) -> {"code", "state_code"}`, `generate_fake`, `fill_code`, `get_icode`,
+`top_k_logits` keep their names, argument meaning and error behaviour.
+
+The loop itself is re-designed: one prefill of the known tokens, then one KV-cached decode step
+per new token (the reference re-runs the full prefix each time, transformer_model.py:343-350);
+temperature / top-k / softmax / pick run fused on the GPU and write straight into the code
+buffer.  Sampling reproduces `torch.multinomial(probs, 1)`: that op is `argmax(probs / q)` with
+`q ~ Exp(1)` drawn from the generator, so with `sample_noise='host'` the noise is drawn from the
+same CPU generator stream the reference's CPU path would consume and uploaded; with
+`sample_noise='device'` it is drawn on the GPU (throughput mode).
+"""
+import torch
+
+from .mingpt import GPT
+from ....tools.utils import to_cuda
+from ... import load_network, print_network
+from .... import ops
+
+
+class Transformer(torch.nn.Module):
+    def __init__(self, opt, is_train=False, is_main=True, logger=None):
+        super().__init__()
+        if is_train:
+            raise NotImplementedError("training is outside the MI355X hot path")
+        self.opt = opt
+        self.is_main = is_main
+        self.net_t = self.initialize_networks(is_train)
+        self.logger = logger if self.is_main else None
+        height, width = self.opt.z_shape
+        self.size = height * width
+        self.state_size = self.opt.state_size
+        self.tot_size = self.size + self.state_size
+        self.sample_noise = getattr(opt, "sample_noise", "host")  # 'host' (reference-reproducible) | 'device'
+        self.generator = None                                      # optional torch.Generator for the noise
+        self.trace = None                                          # optional list collecting per-step logits (tests)
+
+    def forward(self, data, prefix='', mode='', total_len=None, log=False, global_iter=None, show_progress=False):
+        code, state_code, cond_code, delta_length_cond, vid_lbl = self.preprocess_input(data)
+        if mode == 'inference':
+            return self.generate_fake(code, state_code, cond_code, delta_length_cond, vid_lbl, total_len, show_progress)
+        if mode in ('transformer', 'eval_transformer'):
+            raise NotImplementedError(f"mode '{mode}' (training loss) is outside the MI355X hot path")
+        raise ValueError(f"mode '{mode}' is invalid")
+
+    def preprocess_input(self, data):
+        """transformer_model.py:48-54."""
+        data["code"] = to_cuda(data, "code", flatten_empty=False)
+        data["state_code"] = to_cuda(data, "state_code", flatten_empty=False)
+        data["cond_code"] = to_cuda(data, "cond_code")
+        data["vid_lbl"] = to_cuda(data, "vid_lbl")
+        data["delta_length_cond"] = to_cuda(data, "delta_length_cond")
+        return data["code"], data["state_code"], data["cond_code"], data["delta_length_cond"], data["vid_lbl"]
+
+    def initialize_networks(self, is_train):
+        """transformer_model.py:57-73."""
+        opt = self.opt
+        if getattr(opt, "is_continuous", False):
+            raise NotImplementedError("continuous-token GPT (CGPT) is outside the hot path")
+        num_lbl = len(opt.categories) if getattr(opt, "categories", None) is not None else None
+        net_t = GPT(vocab_size=opt.z_num, block_size=opt.z_len, n_layer=opt.n_layer, n_head=opt.n_head, n_embd=opt.n_embd,
+                    emb_mode=opt.emb_mode, shape=opt.z_shape, state_vocab_size=opt.state_num, num_blocks=opt.num_blocks,
+                    state_size=opt.state_size, use_start_token=opt.use_start_token, use_lbl=opt.cat, num_lbl=num_lbl,
+                    state_front=opt.state_front).cuda()
+        if self.is_main:
+            net_t = load_network(net_t, "transformer_t", opt, head_to_n=getattr(opt, "head_to_n", 0))
+        return net_t
+
+    def top_k_logits(self, logits, k):
+        """transformer_model.py:256-260 (torch ops; the fused kernel applies the same rule)."""
+        v, _ = torch.topk(logits, k)
+        out = logits.clone()
+        out[out < v[..., [-1]]] = -float('Inf')
+        return out
+
+    @torch.no_grad()
+    def generate_fake(self, code, state_code, cond_code, delta_length_cond, vid_lbl, total_len, show_progress=False):
+        """transformer_model.py:263-328, including the sliding token window for total_len > z_len
+        (each slide restarts positions at 0, so the window is re-prefilled)."""
+        if 0 not in state_code.size():
+            raise NotImplementedError("state / stft token streams are not on the MI355X path yet (SURVEY 8f)")
+        opt = self.opt
+        n_cond = cond_code.size(1) if 0 not in cond_code.size() else 0
+        if total_len is None:
+            code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl)
+            return {"code": code, "state_code": state_code}
+        total_len = int(total_len)
+        if total_len <= opt.z_len:
+            add_len = total_len - code.size(1) - n_cond
+            code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl, add_len=add_len)
+            return {"code": code, "state_code": state_code}
+        code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl)
+        curr_len = opt.z_len
+        i = 1
+        while curr_len < total_len:
+            add_len = total_len - curr_len if total_len - curr_len < opt.z_chunk else None
+            if n_cond:
+                delta_length_cond = delta_length_cond - 1
+            tmp_code = code[:, i * self.size:]
+            pred_code, _ = self.fill_code(tmp_code, state_code, cond_code, delta_length_cond, vid_lbl, add_len=add_len)
+            delta_code = pred_code.size(1) - tmp_code.size(1)
+            code = torch.cat([code, pred_code[:, -delta_code:]], dim=1)
+            curr_len += add_len if add_len is not None else opt.z_chunk
+            i += 1
+        return {"code": code, "state_code": state_code}
+
+    def _noise(self, b, v, device):
+        if self.sample_noise == "device":
+            return torch.empty(b, v, dtype=torch.float32, device=device).exponential_(1)
+        q = torch.empty(b, v, dtype=torch.float32).exponential_(1, generator=self.generator)
+        return q.to(device, non_blocking=True)
+
+    @torch.no_grad()
+    def fill_code(self, code, state_code, cond_code, delta_length_cond, vid_lbl, add_len=None, show_progress=False):
+        """transformer_model.py:331-392 on the KV-cached engine."""
+        opt = self.opt
+        if getattr(opt, "beam_size", None) is not None:
+            raise NotImplementedError("beam search is not on the MI355X path yet (SURVEY 8f)")
+        b, t0 = code.shape
+        n_cond = cond_code.size(1) if 0 not in cond_code.size() else 0
+        if add_len is None:
+            add_len = opt.z_len - t0 - n_cond
+        if add_len <= 0:
+            return code, state_code
+        net = self.net_t
+        net.begin(b, n_cond + t0 + add_len)
+        out = torch.empty(b, t0 + add_len, dtype=torch.int64, device=code.device)
+        out[:, :t0] = code
+        logits = net.prefill(code, cond_code if n_cond else None, delta_length_cond if n_cond else None)
+        vocab = logits.shape[1]
+        for i in range(add_len):
+            if self.trace is not None:
+                self.trace.append(logits.clone())
+            noise = self._noise(b, vocab, logits.device) if opt.sample else None
+            tok = out[:, t0 + i: t0 + i + 1]
+            ops.sample_topk(logits, opt.top_k, opt.temperature, noise=noise, out=tok)
+            if i + 1 < add_len:
+                logits = net.step(tok)
+        return out, state_code
+
+    @torch.no_grad()
+    def get_icode(self, logits, temperature, top_k, sample, n=1):
+        """transformer_model.py:395-409 for n = 1: logits [B,T,V] -> (icode [B,1], log p [B,1])."""
+        if n != 1:
+            raise NotImplementedError("n > 1 proposals (beam search) is not on the MI355X path yet")
+        last = logits[:, -1].contiguous()
+        noise = self._noise(last.shape[0], last.shape[1], last.device) if sample else None
+        icode = ops.sample_topk(last, top_k, temperature, noise=noise).view(-1, 1)
+        scaled = last / temperature
+        if top_k is not None:
+            scaled = self.top_k_logits(scaled, top_k)
+        ilog_p = torch.log(torch.gather(torch.softmax(scaled, dim=-1), 1, icode))
+        return icode, ilog_p

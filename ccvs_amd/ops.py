@@ -187,15 +187,16 @@ def embed_gather(code, codebook, n, hw):
 
 
 # ------------------------------------------------------------------ transformer
-def gpt_embed(idx, pos_idx, tok_emb, pos_table):
-    _need_gpu(idx, pos_idx, tok_emb, pos_table)
-    idx = idx.contiguous().view(-1)
-    rows = idx.numel()
+def gpt_embed(idx, tok_emb, pos_table, pos0=0, pos_off=None):
+    """idx int64 [B,Tq] (row stride free) -> x [B*Tq, C]; positional row = pos_off[b] + pos0 + t."""
+    _need_gpu(idx, pos_off, tok_emb, pos_table)
+    b, tq = idx.shape
+    assert idx.stride(1) == 1 or tq == 1
     c = tok_emb.shape[1]
-    x = torch.empty(rows, c, dtype=torch.float32, device=tok_emb.device)
+    x = torch.empty(b * tq, c, dtype=torch.float32, device=tok_emb.device)
     L = _lib.load()
-    _lib.check(L.ccvs_gpt_embed(_p(idx), _p(pos_idx.contiguous()), _p(tok_emb), _p(pos_table), _p(x), rows, c, tok_emb.shape[0], _stream()),
-               "ccvs_gpt_embed")
+    _lib.check(L.ccvs_gpt_embed(_p(idx), idx.stride(0), _p(pos_off), pos0, tq, _p(tok_emb), _p(pos_table), _p(x), b, c,
+                                tok_emb.shape[0], _stream()), "ccvs_gpt_embed")
     return x
 
 

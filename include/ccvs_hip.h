@@ -126,11 +126,12 @@ int ccvs_embed_gather(const int64_t* code, const float* codebook, float* z, int3
  * and Transformer.get_icode (models/transformer_model.py:395-409), restructured around a
  * KV cache (the reference recomputes the whole prefix per token, transformer_model.py:350).
  */
-/* x[r][:] = tok_emb[idx[r]] + pos_table[pos_idx[r]]  (mingpt.py:234-236,242-244).
- * pos_table rows are the positional embeddings pre-summed by the host for the call
- * (s_emb + t_emb[+delta_length], h/w/t_emb or pos_emb: mingpt.py:186-217). */
-int ccvs_gpt_embed(const int64_t* idx, const int32_t* pos_idx, const float* tok_emb, const float* pos_table, float* x,
-                   int32_t rows, int32_t C, int32_t vocab, void* stream);
+/* x[(b,t)][:] = tok_emb[idx[b*idx_sB + t]] + pos_table[pos_off[b] + pos0 + t], t < Tq
+ * (mingpt.py:234-236,242-244).  pos_table rows are the positional embeddings pre-summed by
+ * the host for the call (s_emb + t_emb[+delta_length], h/w/t_emb or pos_emb:
+ * mingpt.py:186-217); pos_off (int32 [B], may be NULL) selects a per-sample table. */
+int ccvs_gpt_embed(const int64_t* idx, int64_t idx_sB, const int32_t* pos_off, int32_t pos0, int32_t Tq, const float* tok_emb,
+                   const float* pos_table, float* x, int32_t B, int32_t C, int32_t vocab, void* stream);
 
 /* nn.LayerNorm over the last dim (mingpt.py:103-104,168), eps 1e-5. */
 int ccvs_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t rows, int32_t C, void* stream);
@@ -143,7 +144,7 @@ int ccvs_gemm_nt(const float* x, int64_t ldx, const float* w, const float* bias,
 
 /* Causal attention against a KV cache (mingpt.py:67-77).
  * q [B,Tq,H*D] (batch stride q_sB, row stride ldq); kcache/vcache [B,H,Tmax,D]; query t
- * attends cache positions 0 .. pos0+t.  out [B,Tq,H*D] dense.  D must be 64. */
+ * attends cache positions 0 .. pos0+t.  out [B,Tq,H*D] dense.  D in {16, 32, 64}. */
 int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const float* kcache, const float* vcache, float* out, int32_t B,
                    int32_t H, int32_t Tq, int32_t pos0, int32_t Tmax, int32_t D, void* stream);
 

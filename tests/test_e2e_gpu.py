@@ -1,0 +1,198 @@
+"""-m gpu: the whole hot path through the reference-shaped API (QVidModel / Transformer /
+Generator) against the golden run of the reference (tests/golden/tiny_e2e.npz) and against
+the CPU oracle on fresh seeded inputs.  Bars: VQ indices bit-exact; pixels within 1e-3 abs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ccvs_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TINY_ARGV = [
+    "--name", "tiny", "--dataset", "bairhd", "--max_dim", "32", "--vid_len", "4",
+    "--q_z_num", "32", "--q_z_size", "16", "--q_z_shape", "8", "8",
+    "--q_use_enc", "--q_use_dec", "--q_necf", "8", "--q_necf_mult", "1", "2", "2",
+    "--q_enc_model", "skipgan", "--q_dec_model", "skipgan", "--q_use_inter", "--q_inter_p", "0.75",
+    "--q_skip_context", "1", "2", "3", "--q_skip_memory", "3",
+    "--x_z_num", "32", "--x_z_len", "256", "--x_n_layer", "2", "--x_n_head", "2", "--x_n_embd", "32",
+    "--x_z_chunk", "64", "--x_cond_len", "64", "--x_emb_mode", "temporal", "--x_num_blocks", "4",
+    "--batch_size_vid", "2",
+]
+
+PIX_TOL = 1e-3
+
+
+def _sd(gold, prefix):
+    return {k[len(prefix) + 1:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith(prefix + "/")}
+
+
+def _load(module, sd):
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith(".kernel") for k in missing), missing  # FIR buffers are recomputed
+
+
+def maxdiff(a, b):
+    return (a.detach().float().cpu() - b.detach().float().cpu()).abs().max().item()
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    assert torch.cuda.is_available()
+    from ccvs_amd.tools.options import Options
+    from ccvs_amd.models.skip_vid_generator.models.quantized_video_model import QVidModel
+    from ccvs_amd.models.skip_vid_generator.models.transformer_model import Transformer
+    gold = np.load(os.path.join(golden_dir, "tiny_e2e.npz"))
+    opt = Options().parse(load_qvid_generator=True, load_transformer=True, argv=TINY_ARGV)
+    qopt, xopt = opt["qvid_generator"], opt["transformer"]
+    qv = QVidModel(qopt, is_train=False, is_main=True).eval()
+    tr = Transformer(xopt, is_train=False, is_main=True).eval()
+    _load(qv.net_e, _sd(gold, "e"))
+    _load(qv.net_q, _sd(gold, "q"))
+    _load(qv.net_g, _sd(gold, "g"))
+    _load(tr.net_t, _sd(gold, "t"))
+    nets = {"e": _sd(gold, "e"), "q": _sd(gold, "q"), "g": _sd(gold, "g"), "t": _sd(gold, "t")}
+    return dict(gold=gold, qv=qv, tr=tr, qopt=qopt, xopt=xopt, nets=nets, opt=opt)
+
+
+def test_state_dict_layout(tiny):
+    """The MI355X modules expose exactly the reference's parameter names and shapes."""
+    for net, pre in ((tiny["qv"].net_e, "e"), (tiny["qv"].net_q, "q"), (tiny["qv"].net_g, "g"), (tiny["tr"].net_t, "t")):
+        ref = _sd(tiny["gold"], pre)
+        own = {k: v for k, v in net.state_dict().items() if not k.endswith(".kernel")}
+        assert set(own) == set(ref), (set(own) ^ set(ref))
+        assert all(tuple(own[k].shape) == tuple(ref[k].shape) for k in ref)
+
+
+def test_encode_golden(tiny):
+    g, qv = tiny["gold"], tiny["qv"]
+    enc = qv({"vid": torch.from_numpy(g["vid"])}, mode="vid_encoder")
+    assert enc["code"].dtype == torch.int64
+    assert torch.equal(enc["code"].cpu(), torch.from_numpy(g["enc_code"])), "VQ token indices must be bit-exact"
+    for i, f in enumerate(enc["inter"]):
+        assert maxdiff(f, torch.from_numpy(g[f"enc_inter{i}"])) < 1e-4
+    assert float(g["vq_min_gap"]) > 1e-4  # the fixture's argmin is well separated
+
+
+def test_decoder_cond_frame_golden(tiny):
+    g, qv = tiny["gold"], tiny["qv"]
+    enc = qv({"vid": torch.from_numpy(g["vid"])}, mode="vid_encoder")
+    rgb, _, flows, occs, _ = qv.net_g(enc["z"][:, :1].contiguous(), [[f[:, :1] for f in enc["inter"]]], return_all=True)
+    assert maxdiff(rgb, torch.from_numpy(g["dec_cond_vid"])) < PIX_TOL
+    for i in range(3):
+        assert maxdiff(flows[i], torch.from_numpy(g[f"dec_cond_flow{i}"])) < PIX_TOL
+        assert maxdiff(occs[i], torch.from_numpy(g[f"dec_cond_occ{i}"])) < PIX_TOL
+
+
+def test_gpt_logits_golden(tiny):
+    g, tr = tiny["gold"], tiny["tr"]
+    code = torch.from_numpy(g["gen_code_greedy"]).cuda()
+    logits = tr.net_t(code[:, :-1])
+    assert maxdiff(logits, torch.from_numpy(g["gpt_logits"])) < 1e-4
+
+
+def _audit_tokens(got, want, logits_at):
+    """Token streams must agree; a divergence is only acceptable at a logit near-tie."""
+    got, want = got.cpu(), want.cpu()
+    if torch.equal(got, want):
+        return
+    b, t = (got != want).nonzero()[0].tolist()
+    lg = logits_at(b, t)
+    gap = (lg[got[b, t]] - lg[want[b, t]]).abs().item()
+    assert gap < 1e-4, f"token mismatch at {(b, t)} with logit gap {gap:.3e}"
+
+
+def test_generate_greedy_golden(tiny):
+    g, tr, xopt = tiny["gold"], tiny["tr"], tiny["xopt"]
+    xopt.sample, xopt.top_k = False, 10
+    want = torch.from_numpy(g["gen_code_greedy"])
+    out = tr({"code": want[:, :64].clone()}, mode="inference", total_len=256)
+    ref_logits = torch.from_numpy(g["gpt_logits"])
+    _audit_tokens(out["code"], want, lambda b, t: ref_logits[b, t - 1])
+
+
+def test_generate_sampled_golden(tiny):
+    """torch.multinomial stream of the reference reproduced from the same CPU generator state."""
+    g, tr, xopt = tiny["gold"], tiny["tr"], tiny["xopt"]
+    xopt.sample, xopt.top_k = True, 10
+    want = torch.from_numpy(g["gen_code_sampled_seed7"])
+    torch.manual_seed(7)
+    tr.sample_noise, tr.generator = "host", None
+    out = tr({"code": want[:, :64].clone()}, mode="inference", total_len=64 + 8)
+    assert torch.equal(out["code"].cpu(), want)
+    xopt.sample = False
+
+
+def test_decode_loop_golden(tiny):
+    g, qv = tiny["gold"], tiny["qv"]
+    enc = qv({"vid": torch.from_numpy(g["vid"])}, mode="vid_encoder")
+    inter = [f[:, :1].contiguous() for f in enc["inter"]]
+    fake = qv({"code": torch.from_numpy(g["gen_code_greedy"]), "inter": inter}, mode="vid_decoder")
+    assert fake["vid"].shape == (2, 4, 3, 32, 32)
+    assert maxdiff(fake["vid"], torch.from_numpy(g["fake_vid"])) < PIX_TOL
+
+
+def test_step_decoder_golden(tiny):
+    g, qv = tiny["gold"], tiny["qv"]
+    enc = qv({"vid": torch.from_numpy(g["vid"])}, mode="vid_encoder")
+    inter = [f[:, :1].contiguous() for f in enc["inter"]]
+    step = qv({"code": torch.from_numpy(g["gen_code_greedy"])[:, 64:128].contiguous(), "inter": inter}, mode="vid_step_decoder")
+    assert maxdiff(step["vid"], torch.from_numpy(g["step_vid"])) < PIX_TOL
+    assert torch.equal(step["code"].cpu(), torch.from_numpy(g["step_code"]))
+    assert step["inter"][0].shape[1] == 2
+
+
+def test_invalid_mode_raises(tiny):
+    with pytest.raises(ValueError):
+        tiny["qv"]({}, mode="nope")
+    with pytest.raises(ValueError):
+        tiny["tr"]({"code": torch.zeros(1, 64, dtype=torch.long)}, mode="nope")
+
+
+def test_generator_vs_oracle_fresh_input(tiny):
+    """Generator.generate_vid on a NEW seeded clip == oracle.generate_vid (greedy), end to end."""
+    from ccvs_amd.helpers.generator import Generator
+    gen = Generator(tiny["opt"])
+    gen.vid_model, gen.transformer_model = tiny["qv"], tiny["tr"]
+    tiny["xopt"].sample, tiny["xopt"].top_k = False, 10
+    data = gen.synthetic_batch(2, seed=5)
+    out = gen.generate_vid({"vid": data["vid"].clone()})
+    trace = []
+    want = O.generate_vid(tiny["nets"], tiny["qopt"], tiny["xopt"], data["vid"], trace=trace)
+    assert torch.equal(out["enc_code"].cpu(), want["enc_code"])
+    _audit_tokens(out["fake"]["code"], want["code"], lambda b, t: trace[t - 64][b])
+    if torch.equal(out["fake"]["code"].cpu(), want["code"]):
+        assert maxdiff(out["fake"]["vid"], want["vid"]) < PIX_TOL
+
+
+def test_p2p_vs_oracle(tiny):
+    """Point-to-point (cond prefix with shifted t_emb, extra decoder context), SURVEY 8f row f1."""
+    from ccvs_amd.helpers.generator import Generator
+    xopt = tiny["xopt"]
+    xopt.p2p, xopt.sample = True, False
+    try:
+        gen = Generator(tiny["opt"])
+        gen.vid_model, gen.transformer_model = tiny["qv"], tiny["tr"]
+        data = gen.synthetic_batch(2, seed=9)
+        out = gen.generate_vid({"vid": data["vid"].clone()})
+        trace = []
+        want = O.generate_vid(tiny["nets"], tiny["qopt"], xopt, data["vid"], trace=trace)
+        _audit_tokens(out["fake"]["code"], want["code"], lambda b, t: trace[t - 64][b])
+        assert out["fake"]["vid"].shape == want["vid"].shape == (2, 4, 3, 32, 32)
+        if torch.equal(out["fake"]["code"].cpu(), want["code"]):
+            assert maxdiff(out["fake"]["vid"], want["vid"]) < PIX_TOL
+    finally:
+        xopt.p2p = False
+
+
+def test_determinism(tiny):
+    """Same inputs twice -> bitwise identical clip (fixed-order reductions, no float atomics)."""
+    g, qv = tiny["gold"], tiny["qv"]
+    enc = qv({"vid": torch.from_numpy(g["vid"])}, mode="vid_encoder")
+    inter = [f[:, :1].contiguous() for f in enc["inter"]]
+    a = qv({"code": torch.from_numpy(g["gen_code_greedy"]), "inter": [f.clone() for f in inter]}, mode="vid_decoder")["vid"]
+    b = qv({"code": torch.from_numpy(g["gen_code_greedy"]), "inter": [f.clone() for f in inter]}, mode="vid_decoder")["vid"]
+    assert torch.equal(a, b)

@@ -309,7 +309,11 @@ def test_sample_topk(ops, gold):
 def test_gpt_embed_pack(ops):
     torch.manual_seed(0)
     tok, pos = torch.randn(50, 32), torch.randn(20, 32)
-    idx, pidx = torch.randint(0, 50, (3, 7)), torch.randint(0, 20, (21,), dtype=torch.int32)
-    close(ops.gpt_embed(idx.cuda(), pidx.cuda(), tok.cuda(), pos.cuda()), tok[idx.view(-1)] + pos[pidx.long()], 0)
+    idx = torch.randint(0, 50, (3, 7))
+    off = torch.tensor([0, 5, 9], dtype=torch.int32)
+    prow = (off.long().view(3, 1) + 2 + torch.arange(7).view(1, 7)).view(-1)
+    close(ops.gpt_embed(idx.cuda(), tok.cuda(), pos.cuda(), 2, off.cuda()), tok[idx.view(-1)] + pos[prow], 0)
+    wide = torch.randint(0, 50, (3, 11))  # a [B,1] column view of a wider code buffer (decode step)
+    close(ops.gpt_embed(wide.cuda()[:, 4:5], tok.cuda(), pos.cuda(), 6), tok[wide[:, 4]] + pos[6], 0)
     vid = torch.randn(2, 3, 3, 9, 11) * 1.5
     assert torch.equal(ops.pack_u8(vid.cuda()).cpu(), O.pack_u8(vid))
