@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Benchmark of the CCVS synthesis hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of Generator.generate_vid over one batch per GPU (BAIR 256x256, 1
+conditioning frame -> 15 synthesized frames, batch 16 per GPU: BASELINE.json configs[1]),
+frames already resident in HBM, ending with the RCCL all-gather of the uint8-packed clips.
+Weights are random-init (the reference's initialisers), frames are seeded synthetic tensors.
+Rank 0 prints ONE JSON line; see DESIGN.md section "Measurement" for every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="clips per GPU (weak scaling)")
+    ap.add_argument("--config", type=str, default="bair", choices=["bair", "kinetics"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sample-noise", type=str, default="device", choices=["device", "host"])
+    return ap.parse_args()
+
+
+def build_generator(args):
+    from ccvs_amd.tools.options import Options, BAIR_ARGV, KINETICS_ARGV
+    from ccvs_amd.helpers.generator import Generator
+    argv = list(BAIR_ARGV if args.config == "bair" else KINETICS_ARGV)
+    argv += ["--batch_size_vid", str(args.batch), "--x_sample_noise", args.sample_noise]
+    opt = Options().parse(load_qvid_generator=True, load_transformer=True, argv=argv)
+    torch.manual_seed(0)  # reference initialisers under seed 0
+    gen = Generator(opt).build_models()
+    return gen, opt
+
+
+@torch.no_grad()
+def calibrate_codebook(gen, data):
+    """Documented synthetic codebook randn * std(z_e) (SURVEY section 7 hard part 2) and
+    non-zero positional tables, so that argmin / attention see realistic statistics."""
+    z_e, _ = gen.vid_model.net_e(data["vid"][:2, :1])
+    cb = gen.vid_model.net_q.embedding.weight
+    g = torch.Generator().manual_seed(4)
+    cb.copy_((torch.randn(cb.shape, generator=g) * float(z_e.std())).to(cb.device))
+    t = gen.transformer_model.net_t
+    g = torch.Generator().manual_seed(3)
+    t.s_emb.copy_((torch.randn(t.s_emb.shape, generator=g) * 0.02).to(cb.device))
+    t.t_emb.copy_((torch.randn(t.t_emb.shape, generator=g) * 0.02).to(cb.device))
+
+
+def cpu_baseline(gen, opt):
+    """The oracle (CPU restatement of the reference algorithm, incl. its no-KV-cache token loop)
+    timed on this host on a BOUNDED sample of config 1 (BAIR, batch 1) and extrapolated:
+    encoder on 1 frame, decoder on 1 frame with k=1 and k=2 contexts, GPT forward at
+    T = 64 / 384 / 768, integrated over the 960-token loop and the 15-frame decode loop."""
+    from oracle import ccvs_oracle as O
+    qopt, xopt = opt["qvid_generator"], opt["transformer"]
+    cpu = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    nets = {"e": cpu(gen.vid_model.net_e), "q": cpu(gen.vid_model.net_q), "g": cpu(gen.vid_model.net_g),
+            "t": cpu(gen.transformer_model.net_t)}
+    cores = torch.get_num_threads()
+    g = torch.Generator().manual_seed(1)
+    frame = torch.rand(1, 1, 3, qopt.max_dim, qopt.max_dim, generator=g) * 2 - 1
+    t_all = time.perf_counter()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        enc = O.qvid_encode(nets, qopt, frame)
+        t_enc = time.perf_counter() - t0
+        z = enc["z"]
+        ctx = [f for f in enc["inter"]]
+        t0 = time.perf_counter()
+        O.decoder_forward(nets["g"], qopt, z, [ctx])
+        t_dec1 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.decoder_forward(nets["g"], qopt, z, [ctx, ctx])
+        t_dec2 = time.perf_counter() - t0
+        ts = {}
+        for T in (64, 384, 768):
+            idx = torch.randint(0, xopt.z_num, (1, T), generator=g)
+            t0 = time.perf_counter()
+            O.gpt_forward(nets["t"], xopt, idx)
+            ts[T] = time.perf_counter() - t0
+    # decode: frame with k contexts costs a + b*k ; 1 cond frame (k=1) + 15 frames with k = 1..15
+    b = max(t_dec2 - t_dec1, 0.0)
+    a = max(t_dec1 - b, 0.0)
+    t_decode = (a + b) + sum(a + b * k for k in range(1, 16)) + 15 * t_enc          # + 15 re-encodes
+    # GPT: quadratic fit t(T) through the three samples, summed over T = 64 .. 1023
+    import numpy as np
+    coef = np.polyfit(np.array(list(ts.keys()), dtype=np.float64), np.array(list(ts.values())), 2)
+    t_gpt = float(sum(np.polyval(coef, T) for T in range(64, 1024)))
+    t_encode = 16 * t_enc
+    total = t_encode + t_gpt + t_decode
+    return {"value": 15.0 / total, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": (f"oracle on BAIR batch 1, extrapolated from {time.perf_counter() - t_all:.1f}s of CPU work: encoder 1 frame "
+                       f"{t_enc:.2f}s, decoder 1 frame k=1 {t_dec1:.2f}s / k=2 {t_dec2:.2f}s, GPT forward T=64/384/768 "
+                       f"{ts[64]:.2f}/{ts[384]:.2f}/{ts[768]:.2f}s -> clip = encode {t_encode:.0f}s + no-cache token loop "
+                       f"{t_gpt:.0f}s + decode {t_decode:.0f}s")}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    from ccvs_amd import lib, ops
+    from ccvs_amd.tools.engine import Engine
+    lib.load()
+
+    with Engine() as engine:
+        gen, opt = build_generator(args)
+        gen.engine = engine
+        lo, _ = engine.shard_batch(args.batch * world)
+        xopt = opt["transformer"]
+        predicted = xopt.vid_len - xopt.cond_len // 64
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def make_batch(step):
+            return {"vid": gen.synthetic_batch(args.batch, seed=1 + step, first_clip=lo)["vid"].to(dev)}
+
+        calibrate_codebook(gen, make_batch(0))
+
+        def one_step(step, data):
+            out = gen.generate_vid(data, step)
+            packed = ops.pack_u8(out["fake"]["vid"])
+            return engine.all_gather_clips(packed)
+
+        for w in range(args.warmup):
+            one_step(-1 - w, make_batch(1000 + w))
+        batches = [make_batch(i) for i in range(args.steps)]   # inputs resident in HBM before the clock starts
+        timer = ops.KernelTimer()
+        stage = {"encode": 0.0, "transformer": 0.0, "decode": 0.0}
+        torch.cuda.synchronize()
+        engine.barrier()
+        ops.KERNEL_TIMER = timer
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            clips = one_step(i, batches[i])
+            if engine.is_main:
+                for k, v in gen.stage_ms().items():
+                    stage[k] += v
+        torch.cuda.synchronize()
+        engine.barrier()
+        elapsed = engine.all_reduce_max(time.perf_counter() - t0)
+        ops.KERNEL_TIMER = None
+        assert clips.shape[0] == args.batch * world
+
+        if engine.is_main:
+            frames = predicted * args.batch * world * args.steps
+            n_conv, conv_flops, conv_ms = timer.summary("conv2d_mfma")
+            achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+            line = {
+                "metric": "synthesized frames/sec (BAIR 256x256, cond=1, pred=15), whole job", "value": frames / elapsed,
+                "unit": "frames/s", "per_gpu": frames / elapsed / world, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "BAIR 256x256 1->15 frames, batch 16 per GPU (BASELINE.json configs[1])" if args.config == "bair"
+                           else "Kinetics-600 64x64 5->11 frames", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                           "predicted_frames_per_clip": predicted, "sampling": f"top-k {xopt.top_k}, T={xopt.temperature}, noise={args.sample_noise}",
+                           "parallelism": f"dp{world} (batch sharded, one RCCL all-gather of uint8 clips)"},
+                "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
+                "roofline": {"kernel": "conv2d_mfma_kernel", "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                             "launches": n_conv, "avg_launch_us": 1e3 * conv_ms / max(n_conv, 1),
+                             "algorithmic_gflop_per_launch": conv_flops / max(n_conv, 1) / 1e9,
+                             "share_of_step_time": conv_ms * 1e-3 / elapsed},
+            }
+            if not args.no_cpu_baseline and args.config == "bair":
+                line["cpu_baseline"] = cpu_baseline(gen, opt)
+            print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

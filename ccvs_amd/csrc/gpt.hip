@@ -10,8 +10,10 @@
 // are pre-summed by the host into pos_table once per call).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gpt_embed_kernel(const int64_t* __restrict__ idx, long idx_sB, const int32_t* __restrict__ pos_off,
-                                                        int pos0, int Tq, const float* __restrict__ tok, const float* __restrict__ pos,
+                                                        int pos0, const int32_t* __restrict__ pos_dev, int Tq,
+                                                        const float* __restrict__ tok, const float* __restrict__ pos,
                                                         float* __restrict__ x, long total, int C, int vocab) {
+    if (pos_dev) pos0 += *pos_dev;  // device-resident position: lets a captured hipGraph replay at advancing positions
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long r = i / C;
         const int c = (int)(i - r * C);
@@ -24,13 +26,13 @@ __global__ __launch_bounds__(256) void gpt_embed_kernel(const int64_t* __restric
     }
 }
 
-extern "C" int ccvs_gpt_embed(const int64_t* idx, int64_t idx_sB, const int32_t* pos_off, int32_t pos0, int32_t Tq, const float* tok_emb,
-                              const float* pos_table, float* x, int32_t B, int32_t C, int32_t vocab, void* stream) {
+extern "C" int ccvs_gpt_embed(const int64_t* idx, int64_t idx_sB, const int32_t* pos_off, int32_t pos0, const int32_t* pos_dev, int32_t Tq,
+                              const float* tok_emb, const float* pos_table, float* x, int32_t B, int32_t C, int32_t vocab, void* stream) {
     CCVS_REQUIRE(idx && tok_emb && pos_table && x, "ccvs_gpt_embed: null pointer");
-    CCVS_REQUIRE(B > 0 && Tq > 0 && C > 0 && vocab > 0 && pos0 >= 0, "ccvs_gpt_embed: empty tensor");
+    CCVS_REQUIRE(B > 0 && Tq > 0 && C > 0 && vocab > 0 && (pos0 >= 0 || pos_dev), "ccvs_gpt_embed: empty tensor");
     const long total = (long)B * Tq * C;
     hipLaunchKernelGGL(gpt_embed_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, idx, (long)idx_sB, pos_off,
-                       pos0, Tq, tok_emb, pos_table, x, total, C, vocab);
+                       pos0, pos_dev, Tq, tok_emb, pos_table, x, total, C, vocab);
     CCVS_CHECK_LAUNCH("ccvs_gpt_embed");
     return CCVS_OK;
 }
@@ -63,116 +65,172 @@ extern "C" int ccvs_layernorm(const float* x, const float* gamma, const float* b
 }
 
 // ---------------------------------------------------------------------------------------
-// y[M,N] = epilogue(x[M,K] @ W[N,K]^T + bias) on v_mfma_f32_16x16x4_f32.
-// Workgroup = 16 rows of x (staged in LDS, K chunks of GEMM_KC) x (16*WN) columns; its 4
-// waves are WN column groups x (4/WN) K slices.  Each lane streams W straight from HBM as
-// float4 along K (row n = lane&15, k = k0 + 4*(lane>>4) + t): the 4 floats feed 4
-// consecutive MFMAs whose k-slot (lane>>4) then means "k0 + 4*slot + t" for both
-// operands.  Weights are read once per 16-row block, never staged (decode is a weight
-// stream: M = batch = 16 rows exactly fills the 16x16x4 tile).  K slices are summed
-// through LDS in a fixed order: results are bitwise reproducible run to run.
+// nn.Linear as a weight stream on v_mfma_f32_16x16x4_f32:  y[M,N] = epi(x[M,K] @ W[N,K]^T + b).
+//
+// The decode regime (M = batch = 16 rows) is a pure HBM stream of W, split over many small
+// dependent launches: what matters is bytes in flight per CU and a short critical path.
+//   * workgroup = 16 rows x 16 columns, 8 waves = 8 K slices; each lane issues ALL its float4
+//     loads of a 128-deep K batch before the first MFMA (W: row n = lane&15, k = k0+4*(lane>>4)+t;
+//     x: same k map, row = lane&15, served by L1/L2), so a wave keeps 16 KiB in flight;
+//   * no LDS staging, no barrier in the main loop; the 8 K slices are summed through LDS in a
+//     fixed order (bitwise reproducible, no float atomics);
+//   * LayerNorm is folded in algebraically: with W' = W*gamma, s[n] = sum_k W'[n][k] and
+//     b' = b + W beta (packed once by the host),
+//         LN(x) @ W^T + b = rstd * (x @ W'^T - mean * s) + b'
+//     so the GEMM runs on the raw activations and the row statistics (sum x, sum x^2, which the
+//     lanes accumulate from the very x values they feed to the MFMA) are applied in the
+//     epilogue: the separate LayerNorm launch and its round trip through HBM disappear;
+//   * the QKV projection can scatter its K and V column blocks straight into the KV cache at a
+//     host- or device-resident position (no separate append launch).
+// Larger M (prefill) runs the same kernel over ceil(M/16) row blocks, W then coming from L2.
 // ---------------------------------------------------------------------------------------
-#define GEMM_KC 512
-#define GEMM_LDX (GEMM_KC + 4)
-
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 
-template <int WN>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
-                                                      const float* __restrict__ bias, const float* __restrict__ res,
-                                                      float* __restrict__ y, long ldy, int M, int N, int K, int epi) {
-    constexpr int KS = 4 / WN;
-    __shared__ __attribute__((aligned(16))) float xs[16 * GEMM_LDX];
-    __shared__ __attribute__((aligned(16))) float red[KS > 1 ? (KS - 1) * WN * 64 * 4 : 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave % WN, wk = wave / WN;
-    const int m0 = blockIdx.y * 16;
-    const int ncol0 = (blockIdx.x * WN + wn) * 16;
-    const int li = lane & 15, g = lane >> 4;
-    const int nrow = min(ncol0 + li, N - 1);  // clamp: tail columns are computed on a valid row and dropped
-    const float* wp = w + (long)nrow * K + 4 * g;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+struct Gemm16 {
+    const float* x; long ldx;
+    const float* w; const float* bias; const float* res; float* y; long ldy;
+    int M, N, K, epi, ks;
+    const float* ln_s; float ln_eps;
+    float* kcache; float* vcache; int C, H, D, Tq, Tmax, pos0; const int32_t* pos_dev;
+};
 
-    for (int kc = 0; kc < K; kc += GEMM_KC) {
-        const int klen = min(GEMM_KC, K - kc);
-        __syncthreads();
-        for (int e = tid * 4; e < 16 * klen; e += 256 * 4) {
-            const int r = e / klen, c = e - r * klen;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < M) v = *reinterpret_cast<const float4*>(x + (long)(m0 + r) * ldx + kc + c);
-            *reinterpret_cast<float4*>(xs + r * GEMM_LDX + c) = v;
-        }
-        __syncthreads();
-        const int kper = klen / KS;  // klen is a multiple of 16*KS (checked on the host)
-        const int kb = wk * kper;
-        const float* xp = xs + li * GEMM_LDX + kb + 4 * g;
-        const float* wq = wp + kc + kb;
-#pragma unroll 4
-        for (int k0 = 0; k0 < kper; k0 += 16) {
-            const float4 wv = *reinterpret_cast<const float4*>(wq + k0);
-            const float4 xv = *reinterpret_cast<const float4*>(xp + k0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.x, wv.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.y, wv.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.z, wv.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.w, wv.w, acc, 0, 0, 0);
-        }
-    }
-    if (KS > 1) {
-        __syncthreads();
-        if (wk > 0) *reinterpret_cast<f32x4*>(red + (((wk - 1) * WN + wn) * 64 + lane) * 4) = acc;
-        __syncthreads();
-        if (wk > 0) return;
+#define GEMM_U 8  // K steps (of 16) whose loads are issued together
+
+__global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
+    __shared__ __attribute__((aligned(16))) float red[7 * 64 * 4];
+    __shared__ float stat[8 * 16 * 2];
+    __shared__ float fin[16 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * 16, ncol0 = blockIdx.x * 16;
+    const int nrow = min(ncol0 + li, p.N - 1), mrow = min(m0 + li, p.M - 1);  // tails: computed on a valid row, dropped at the store
+    const int kper = p.K / p.ks;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float sx = 0.f, sxx = 0.f;
+    if (wave < p.ks) {
+        const float* wp = p.w + (long)nrow * p.K + wave * kper + 4 * g;
+        const float* xp = p.x + (long)mrow * p.ldx + wave * kper + 4 * g;
+        for (int k0 = 0; k0 < kper; k0 += 16 * GEMM_U) {
+            float4 wv[GEMM_U], xv[GEMM_U];
 #pragma unroll
-        for (int s = 1; s < KS; ++s) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(red + (((s - 1) * WN + wn) * 64 + lane) * 4);
-            acc += o;
-        }
-    }
-    // D[row = 4*(lane>>4) + r][col = lane&15]
-    const int col = ncol0 + li;
-    if (col < N) {
-        const float bv = bias ? bias[col] : 0.f;
+            for (int u = 0; u < GEMM_U; ++u) {
+                const bool ok = k0 + 16 * u < kper;
+                wv[u] = ok ? *reinterpret_cast<const float4*>(wp + k0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xv[u] = ok ? *reinterpret_cast<const float4*>(xp + k0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + 4 * g + r;
-            if (row < M) {
-                float v = acc[r] + bv;
-                if (epi == 1) v = gelu_erf(v);
-                if (epi == 2) v += res[(long)row * ldy + col];
-                y[(long)row * ldy + col] = v;
+            for (int u = 0; u < GEMM_U; ++u) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].x, wv[u].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].y, wv[u].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].z, wv[u].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].w, wv[u].w, acc1, 0, 0, 0);
+                if (p.ln_s) {
+                    sx += (xv[u].x + xv[u].y) + (xv[u].z + xv[u].w);
+                    sxx += (xv[u].x * xv[u].x + xv[u].y * xv[u].y) + (xv[u].z * xv[u].z + xv[u].w * xv[u].w);
+                }
             }
         }
     }
+    f32x4 acc = acc0 + acc1;
+    if (p.ln_s) {  // lanes li, li+16, li+32, li+48 hold the four k-groups of row li
+        sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
+        sxx += __shfl_xor(sxx, 16, 64); sxx += __shfl_xor(sxx, 32, 64);
+        if (g == 0) { stat[(wave * 16 + li) * 2] = sx; stat[(wave * 16 + li) * 2 + 1] = sxx; }
+    }
+    if (wave > 0) *reinterpret_cast<f32x4*>(red + ((wave - 1) * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (p.ln_s && tid < 16) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < 8; ++w) { a += stat[(w * 16 + tid) * 2]; b += stat[(w * 16 + tid) * 2 + 1]; }
+        const float mean = a / p.K;
+        const float var = fmaxf(b / p.K - mean * mean, 0.f);
+        fin[tid * 2] = mean;
+        fin[tid * 2 + 1] = rsqrtf(var + p.ln_eps);
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int s = 0; s < 7; ++s) acc += *reinterpret_cast<const f32x4*>(red + (s * 64 + lane) * 4);
+
+    // D[row = 4*g + r][col = li]
+    const int col = ncol0 + li;
+    if (col >= p.N) return;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+    const float sn = p.ln_s ? p.ln_s[col] : 0.f;
+    int pos0 = p.pos0;
+    if (p.kcache && p.pos_dev) pos0 += *p.pos_dev;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 4 * g + r;
+        if (row >= p.M) continue;
+        float v = acc[r];
+        if (p.ln_s) v = fin[(4 * g + r) * 2 + 1] * (v - fin[(4 * g + r) * 2] * sn);
+        v += bv;
+        if (p.epi == 1) v = gelu_erf(v);
+        if (p.epi == 2) v += p.res[(long)row * p.ldy + col];
+        if (p.kcache && col >= p.C) {
+            const int cc = col - p.C;
+            float* cache = cc >= p.C ? p.vcache : p.kcache;
+            const int c2 = cc >= p.C ? cc - p.C : cc;
+            const int h = c2 / p.D, d = c2 - h * p.D;
+            const int b = row / p.Tq, t = row - b * p.Tq;
+            if (pos0 + t < p.Tmax) cache[(((long)b * p.H + h) * p.Tmax + pos0 + t) * p.D + d] = v;
+        } else {
+            p.y[(long)row * p.ldy + col] = v;
+        }
+    }
+}
+
+static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
+    if (!(g.x && g.w && g.y)) { ccvs_set_error("%s: null pointer", name); return CCVS_ERR_ARG; }
+    if (!(g.M > 0 && g.N > 0 && g.K > 0)) { ccvs_set_error("%s: empty tensor", name); return CCVS_ERR_ARG; }
+    if (g.K % 16 != 0 || g.ldx % 4 != 0) { ccvs_set_error("%s: K=%d must be a multiple of 16 (ldx %% 4 == 0)", name, g.K); return CCVS_ERR_ARG; }
+    if (g.epi < 0 || g.epi > 2 || (g.epi == 2 && !g.res)) { ccvs_set_error("%s: bad epilogue", name); return CCVS_ERR_ARG; }
+    g.ks = 8;
+    while (g.ks > 1 && g.K % (16 * g.ks) != 0) g.ks >>= 1;
+    hipLaunchKernelGGL(gemm16_kernel, dim3(cdiv(g.N, 16), cdiv(g.M, 16)), dim3(512), 0, st, g);
+    CCVS_CHECK_LAUNCH(name);
+    return CCVS_OK;
 }
 
 extern "C" int ccvs_gemm_nt(const float* x, int64_t ldx, const float* w, const float* bias, const float* res, float* y, int64_t ldy,
                             int32_t M, int32_t N, int32_t K, int32_t epilogue, void* stream) {
-    CCVS_REQUIRE(x && w && y, "ccvs_gemm_nt: null pointer");
-    CCVS_REQUIRE(M > 0 && N > 0 && K > 0, "ccvs_gemm_nt: empty tensor");
-    CCVS_REQUIRE(K % 16 == 0 && ldx % 4 == 0, "ccvs_gemm_nt: K=%d must be a multiple of 16 (ldx %% 4 == 0)", K);
-    CCVS_REQUIRE(epilogue >= 0 && epilogue <= 2 && (epilogue != 2 || res), "ccvs_gemm_nt: bad epilogue");
-    hipStream_t st = (hipStream_t)stream;
-    const int mblocks = cdiv(M, 16);
-    // few rows (decode): 16 columns per workgroup with a 4-way K split keeps every CU streaming;
-    // many rows (prefill): 64 columns per workgroup.
-    const bool split_ok = (K % 64 == 0) && (K <= GEMM_KC || K % GEMM_KC == 0);
-    if (mblocks <= 4 && split_ok) {
-        hipLaunchKernelGGL((gemm_nt_kernel<1>), dim3(cdiv(N, 16), mblocks), dim3(256), 0, st, x, (long)ldx, w, bias, res, y, (long)ldy, M, N,
-                           K, epilogue);
-    } else {
-        hipLaunchKernelGGL((gemm_nt_kernel<4>), dim3(cdiv(N, 64), mblocks), dim3(256), 0, st, x, (long)ldx, w, bias, res, y, (long)ldy, M, N,
-                           K, epilogue);
-    }
-    CCVS_CHECK_LAUNCH("ccvs_gemm_nt");
-    return CCVS_OK;
+    Gemm16 g = {};
+    g.x = x; g.ldx = ldx; g.w = w; g.bias = bias; g.res = res; g.y = y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.epi = epilogue;
+    return launch_gemm16(g, (hipStream_t)stream, "ccvs_gemm_nt");
+}
+
+extern "C" int ccvs_gemm_ln(const float* x, int64_t ldx, const float* w_gamma, const float* bias_beta, const float* w_rowsum, float eps,
+                            float* y, int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t epilogue, void* stream) {
+    CCVS_REQUIRE(w_rowsum, "ccvs_gemm_ln: null pointer");
+    CCVS_REQUIRE(epilogue == 0 || epilogue == 1, "ccvs_gemm_ln: bad epilogue");
+    Gemm16 g = {};
+    g.x = x; g.ldx = ldx; g.w = w_gamma; g.bias = bias_beta; g.y = y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.epi = epilogue;
+    g.ln_s = w_rowsum; g.ln_eps = eps;
+    return launch_gemm16(g, (hipStream_t)stream, "ccvs_gemm_ln");
+}
+
+extern "C" int ccvs_gemm_ln_qkv(const float* x, int64_t ldx, const float* w_gamma, const float* bias_beta, const float* w_rowsum, float eps,
+                                float* q, float* kcache, float* vcache, int32_t B, int32_t Tq, int32_t C, int32_t H, int32_t pos0,
+                                const int32_t* pos_dev, int32_t Tmax, void* stream) {
+    CCVS_REQUIRE(w_rowsum && kcache && vcache, "ccvs_gemm_ln_qkv: null pointer");
+    CCVS_REQUIRE(B > 0 && Tq > 0 && H > 0 && C % H == 0 && pos0 >= 0 && pos0 + Tq <= Tmax, "ccvs_gemm_ln_qkv: bad shape / positions");
+    Gemm16 g = {};
+    g.x = x; g.ldx = ldx; g.w = w_gamma; g.bias = bias_beta; g.y = q; g.ldy = C; g.M = B * Tq; g.N = 3 * C; g.K = C; g.epi = 0;
+    g.ln_s = w_rowsum; g.ln_eps = eps;
+    g.kcache = kcache; g.vcache = vcache; g.C = C; g.H = H; g.D = C / H; g.Tq = Tq; g.Tmax = Tmax; g.pos0 = pos0; g.pos_dev = pos_dev;
+    return launch_gemm16(g, (hipStream_t)stream, "ccvs_gemm_ln_qkv");
 }
 
 // ---------------------------------------------------------------------------------------
-// KV cache append and causal attention over the cache (head dim 64).
+// KV cache append and causal attention over the cache (head dim 16 / 32 / 64).
+// Positions may come from a device-resident int32 (`pos_dev`, added to pos0) so that a decode
+// step captured in a hipGraph replays at advancing positions without re-capture.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void kv_append_kernel(const float* __restrict__ k, const float* __restrict__ v, long sB, long ld,
                                                         float* __restrict__ kc, float* __restrict__ vc, long total, int H, int Tq,
-                                                        int pos0, int Tmax, int D) {
+                                                        int pos0, const int32_t* __restrict__ pos_dev, int Tmax, int D) {
+    if (pos_dev) pos0 += *pos_dev;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int d = (int)(i % D);
         long t = i / D;
@@ -180,6 +238,7 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const float* __restrict_
         t /= H;
         const int tq = (int)(t % Tq);
         const long b = t / Tq;
+        if (pos0 + tq >= Tmax) continue;
         const long src = b * sB + tq * ld + h * D + d;
         const long dst = ((b * H + h) * Tmax + pos0 + tq) * D + d;
         kc[dst] = k[src];
@@ -188,24 +247,24 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const float* __restrict_
 }
 
 extern "C" int ccvs_kv_append(const float* k, const float* v, int64_t sB, int64_t ld, float* kcache, float* vcache, int32_t B, int32_t H,
-                              int32_t Tq, int32_t pos0, int32_t Tmax, int32_t D, void* stream) {
+                              int32_t Tq, int32_t pos0, const int32_t* pos_dev, int32_t Tmax, int32_t D, void* stream) {
     CCVS_REQUIRE(k && v && kcache && vcache, "ccvs_kv_append: null pointer");
     CCVS_REQUIRE(B > 0 && H > 0 && Tq > 0 && D > 0 && pos0 >= 0 && pos0 + Tq <= Tmax, "ccvs_kv_append: positions %d..%d exceed cache %d",
                  pos0, pos0 + Tq, Tmax);
     const long total = (long)B * Tq * H * D;
     hipLaunchKernelGGL(kv_append_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, k, v, (long)sB, (long)ld, kcache,
-                       vcache, total, H, Tq, pos0, Tmax, D);
+                       vcache, total, H, Tq, pos0, pos_dev, Tmax, D);
     CCVS_CHECK_LAUNCH("ccvs_kv_append");
     return CCVS_OK;
 }
 
-// One workgroup per (batch, head, query).  Scores: one key per thread (row of D floats,
-// q broadcast from LDS); softmax over the L = pos0+t+1 visible keys; PV: lane = head dim
-// (coalesced V rows), 4 waves take keys round-robin and are summed through LDS.
+// Prefill form: one workgroup per (batch, head, query).  Scores: one key per thread (row of D
+// floats, q broadcast from LDS); softmax over the L = pos0+t+1 visible keys; PV: lane = head
+// dim (coalesced V rows), 4 waves take keys round-robin and are summed through LDS.
 template <int D>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, long q_sB, long ldq, const float* __restrict__ kc,
                                                         const float* __restrict__ vc, float* __restrict__ out, int H, int Tq, int pos0,
-                                                        int Tmax, float scale) {
+                                                        const int32_t* __restrict__ pos_dev, int Tmax, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* qs = smem;            // [64]
     float* red = smem + 64;      // [8]
@@ -215,7 +274,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const int t = blockIdx.x % Tq;
     const int bh = blockIdx.x / Tq;
     const int b = bh / H, h = bh - b * H;
-    const int L = pos0 + t + 1;
+    if (pos_dev) pos0 += *pos_dev;
+    const int L = min(pos0 + t + 1, Tmax);
     const float* kbase = kc + (long)bh * Tmax * D;
     const float* vbase = vc + (long)bh * Tmax * D;
     if (tid < D) qs[tid] = q[(long)b * q_sB + (long)t * ldq + h * D + tid];
@@ -260,19 +320,114 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
+// Decode form (Tq = 1): one workgroup per (batch, head) streams that head's K and V rows once.
+// A key row of D floats is read by D/4 consecutive lanes as float4 (a wave-instruction covers
+// 64/(D/4) whole rows: 1 KiB, fully coalesced); the partial dots are summed across those lanes
+// with xor shuffles.  PV uses the same lane map (lane owns 4 head dims of one key slot); the
+// key slots of a wave and the 8 waves are reduced through LDS in a fixed order.
+template <int D>
+__global__ __launch_bounds__(512) void attention_decode_kernel(const float* __restrict__ q, long q_sB, const float* __restrict__ kc,
+                                                               const float* __restrict__ vc, float* __restrict__ out, int H, int pos0,
+                                                               const int32_t* __restrict__ pos_dev, int Tmax, float scale) {
+    constexpr int LPK = D / 4;     // lanes per key row
+    constexpr int KPI = 64 / LPK;  // key rows per wave-instruction
+    constexpr int NW = 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* red = smem;                    // [16]
+    float* pv = smem + 16;                // [NW][64][4]
+    float* ps = smem + 16 + NW * 256;     // [Tmax]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x;
+    const int b = bh / H, h = bh - b * H;
+    if (pos_dev) pos0 += *pos_dev;
+    const int L = min(pos0 + 1, Tmax);
+    const int kk = lane / LPK, d4 = lane - kk * LPK;
+    const float4 qv = *reinterpret_cast<const float4*>(q + (long)b * q_sB + h * D + 4 * d4);
+    const float* kbase = kc + (long)bh * Tmax * D + 4 * d4;
+    const float* vbase = vc + (long)bh * Tmax * D + 4 * d4;
+
+    float lmax = -INFINITY;
+#pragma unroll 4
+    for (int j0 = wave * KPI; j0 < L; j0 += NW * KPI) {
+        const int j = j0 + kk;
+        float s = 0.f;
+        if (j < L) {
+            const float4 kv = *reinterpret_cast<const float4*>(kbase + (long)j * D);
+            s = kv.x * qv.x + kv.y * qv.y + kv.z * qv.z + kv.w * qv.w;
+        }
+#pragma unroll
+        for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
+        s *= scale;
+        if (j < L) {
+            if (d4 == 0) ps[j] = s;
+            lmax = fmaxf(lmax, s);
+        }
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    float gmax = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) gmax = fmaxf(gmax, red[w]);
+    float lsum = 0.f;
+    for (int j = tid; j < L; j += NW * 64) {
+        const float e = expf(ps[j] - gmax);
+        ps[j] = e;
+        lsum += e;
+    }
+    lsum = wave_sum(lsum);
+    __syncthreads();
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    float tot = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) tot += red[w];
+
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int j0 = wave * KPI; j0 < L; j0 += NW * KPI) {
+        const int j = j0 + kk;
+        if (j < L) {
+            const float p = ps[j];
+            const float4 vv = *reinterpret_cast<const float4*>(vbase + (long)j * D);
+            acc.x += p * vv.x; acc.y += p * vv.y; acc.z += p * vv.z; acc.w += p * vv.w;
+        }
+    }
+    *reinterpret_cast<float4*>(pv + (wave * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (tid < D) {
+        const int dd4 = tid >> 2, comp = tid & 3;
+        float o = 0.f;
+        for (int w = 0; w < NW; ++w)
+            for (int s2 = 0; s2 < KPI; ++s2) o += pv[(w * 64 + s2 * LPK + dd4) * 4 + comp];
+        out[(long)b * (H * D) + h * D + tid] = o / tot;
+    }
+}
+
 extern "C" int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const float* kcache, const float* vcache, float* out, int32_t B,
-                              int32_t H, int32_t Tq, int32_t pos0, int32_t Tmax, int32_t D, void* stream) {
+                              int32_t H, int32_t Tq, int32_t pos0, const int32_t* pos_dev, int32_t Tmax, int32_t D, void* stream) {
     CCVS_REQUIRE(q && kcache && vcache && out, "ccvs_attention: null pointer");
     CCVS_REQUIRE(D == 64 || D == 32 || D == 16, "ccvs_attention: head dim %d unsupported (16, 32, 64)", D);
     CCVS_REQUIRE(B > 0 && H > 0 && Tq > 0 && pos0 >= 0 && pos0 + Tq <= Tmax, "ccvs_attention: bad positions");
-    const size_t smem = (size_t)(80 + 256 + pos0 + Tq) * sizeof(float);
-    CCVS_REQUIRE(smem <= 64 * 1024, "ccvs_attention: sequence too long for the LDS score buffer");
-    const dim3 grid((unsigned)((long)B * H * Tq));
+    // with a device-side position the visible length is unknown to the host: size LDS for the whole cache
+    const int maxL = pos_dev ? Tmax : pos0 + Tq;
     const float scale = 1.0f / sqrtf((float)D);
     hipStream_t st = (hipStream_t)stream;
-    if (D == 64) hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(256), smem, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, Tmax, scale);
-    else if (D == 32) hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(256), smem, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, Tmax, scale);
-    else hipLaunchKernelGGL((attention_kernel<16>), grid, dim3(256), smem, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, Tmax, scale);
+    if (Tq == 1) {
+        const size_t smem = (size_t)(16 + 8 * 256 + maxL) * sizeof(float);
+        CCVS_REQUIRE(smem <= 64 * 1024, "ccvs_attention: sequence too long for the LDS score buffer");
+        const dim3 grid((unsigned)(B * H));
+        if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
+        else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
+        else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
+    } else {
+        const size_t smem = (size_t)(80 + 256 + maxL) * sizeof(float);
+        CCVS_REQUIRE(smem <= 64 * 1024, "ccvs_attention: sequence too long for the LDS score buffer");
+        const dim3 grid((unsigned)((long)B * H * Tq));
+        if (D == 64) hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(256), smem, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, pos_dev, Tmax, scale);
+        else if (D == 32) hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(256), smem, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, pos_dev, Tmax, scale);
+        else hipLaunchKernelGGL((attention_kernel<16>), grid, dim3(256), smem, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, pos_dev, Tmax, scale);
+    }
     CCVS_CHECK_LAUNCH("ccvs_attention");
     return CCVS_OK;
 }

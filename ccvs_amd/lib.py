@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libccvs_hip.so")
 EXPORTS = [
     "ccvs_last_error", "ccvs_abi_version", "ccvs_conv2d", "ccvs_upfirdn2d", "ccvs_dwconvT4x4s2",
     "ccvs_correlation7x7", "ccvs_backwarp", "ccvs_warp_fuse_blend", "ccvs_vq_argmin", "ccvs_embed_gather",
-    "ccvs_gpt_embed", "ccvs_layernorm", "ccvs_gemm_nt", "ccvs_attention", "ccvs_kv_append", "ccvs_sample_topk",
+    "ccvs_gpt_embed", "ccvs_layernorm", "ccvs_gemm_nt", "ccvs_gemm_ln", "ccvs_gemm_ln_qkv", "ccvs_attention", "ccvs_kv_append", "ccvs_sample_topk",
     "ccvs_pack_u8",
 ]
 
@@ -60,11 +60,13 @@ def load():
         "ccvs_warp_fuse_blend": [vp, i64, i64, vp, vp, i64, vp, i64, f32, i32, i32, i32, i32, i32, vp],
         "ccvs_vq_argmin": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "ccvs_embed_gather": [vp, vp, vp, i32, i32, i32, i32, vp],
-        "ccvs_gpt_embed": [vp, i64, vp, i32, i32, vp, vp, vp, i32, i32, i32, vp],
+        "ccvs_gpt_embed": [vp, i64, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, vp],
         "ccvs_layernorm": [vp, vp, vp, vp, i32, i32, vp],
         "ccvs_gemm_nt": [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp],
-        "ccvs_attention": [vp, i64, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
-        "ccvs_kv_append": [vp, vp, i64, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+        "ccvs_gemm_ln": [vp, i64, vp, vp, vp, f32, vp, i64, i32, i32, i32, i32, vp],
+        "ccvs_gemm_ln_qkv": [vp, i64, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp],
+        "ccvs_attention": [vp, i64, i64, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp],
+        "ccvs_kv_append": [vp, vp, i64, i64, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp],
         "ccvs_sample_topk": [vp, i64, vp, vp, i64, i32, i32, i32, f32, vp],
         "ccvs_pack_u8": [vp, vp, i64, i32, i32, f32, f32, vp],
     }

@@ -83,6 +83,20 @@ class Block(nn.Module):
             nn.Linear(4 * config.n_embd, config.n_embd),
             nn.Dropout(config.resid_pdrop),
         )
+        self._folded = None
+
+    def folded(self):
+        """(ln1 folded into the stacked QKV weight, ln2 folded into mlp[0]) -- `ops.pack_ln_linear`."""
+        src = (self.ln1.weight, self.ln1.bias, self.attn.query.weight, self.attn.key.weight, self.attn.value.weight,
+               self.attn.query.bias, self.attn.key.bias, self.attn.value.bias, self.ln2.weight, self.ln2.bias,
+               self.mlp[0].weight, self.mlp[0].bias)
+        key = tuple((t.data_ptr(), t._version) for t in src) + (src[0].device,)
+        if self._folded is None or self._folded[0] != key:
+            wqkv, bqkv = self.attn.qkv_packed()
+            qkv = ops.pack_ln_linear(wqkv, bqkv, self.ln1.weight, self.ln1.bias)
+            fc = ops.pack_ln_linear(self.mlp[0].weight, self.mlp[0].bias, self.ln2.weight, self.ln2.bias)
+            self._folded = (key, qkv, fc)
+        return self._folded[1], self._folded[2]
 
 
 class GPT(nn.Module):
@@ -165,42 +179,57 @@ class GPT(nn.Module):
     # ------------------------------------------------------------------ incremental engine
     @torch.no_grad()
     def begin(self, batch, max_len):
-        """Allocate the KV cache for `batch` sequences of at most `max_len` positions."""
+        """Allocate (or reuse) the KV cache and the device-resident decode state for `batch`
+        sequences of at most `max_len` positions."""
         cfg = self.config
         assert max_len <= self.block_size, "Cannot forward, model block size is exhausted."  # mingpt.py:299
         dev = self.tok_emb.weight.device
         d = cfg.n_embd // cfg.n_head
         c = self._cache
         if c is None or c["B"] != batch or c["T"] < max_len or c["dev"] != dev:
-            t_alloc = max_len
-            kc = [torch.empty(batch, cfg.n_head, t_alloc, d, dtype=torch.float32, device=dev) for _ in range(cfg.n_layer)]
-            vc = [torch.empty(batch, cfg.n_head, t_alloc, d, dtype=torch.float32, device=dev) for _ in range(cfg.n_layer)]
-            c = self._cache = {"B": batch, "T": t_alloc, "dev": dev, "k": kc, "v": vc}
+            kc = [torch.empty(batch, cfg.n_head, max_len, d, dtype=torch.float32, device=dev) for _ in range(cfg.n_layer)]
+            vc = [torch.empty(batch, cfg.n_head, max_len, d, dtype=torch.float32, device=dev) for _ in range(cfg.n_layer)]
+            c = self._cache = {"B": batch, "T": max_len, "dev": dev, "k": kc, "v": vc, "graphs": {},
+                               "len_dev": torch.zeros(1, dtype=torch.int32, device=dev),     # cache positions filled
+                               "tok": torch.zeros(batch, 1, dtype=torch.int64, device=dev),  # last sampled token
+                               "widx": torch.zeros(batch, 1, dtype=torch.int64, device=dev), # where the next token is stored
+                               "codes": torch.zeros(batch, max_len, dtype=torch.int64, device=dev)}
         c["len"] = 0
-        c["pos_table"] = self.get_pos_emb(min(c["T"], self.block_size))[0].contiguous()
+        table = self.get_pos_emb(min(c["T"], self.block_size))[0]
+        if "pos_table" in c:
+            c["pos_table"].copy_(table)   # same storage: captured graphs keep pointing at it
+        else:
+            c["pos_table"] = table.contiguous().clone()
         c["frame_pos0"] = 0
         return c
 
-    def _layers(self, x, b, tq):
-        """x [b*tq, C] -> x after all blocks; appends tq positions to the cache."""
+    def _layers(self, x, b, tq, pos_dev=None):
+        """x [b*tq, C] -> x after all blocks; appends tq positions to the cache (at the host-side
+        length, or at the device-resident `pos_dev` when given)."""
         c = self._cache
-        pos0 = c["len"]
+        pos0 = 0 if pos_dev is not None else c["len"]
         C = self.config.n_embd
         for i, blk in enumerate(self.blocks):
-            h = ops.layernorm(x, blk.ln1.weight, blk.ln1.bias)
-            wqkv, bqkv = blk.attn.qkv_packed()
-            qkv = ops.gemm_nt(h, wqkv, bqkv).view(b, tq, 3 * C)
-            ops.kv_append(qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], c["k"][i], c["v"][i], pos0)
-            att = ops.attention(qkv[:, :, :C], c["k"][i], c["v"][i], pos0)
+            # 5 launches per layer: [ln1 + QKV + cache scatter] [attention] [proj + residual]
+            #                       [ln2 + fc + GELU] [fc2 + residual]
+            qkv_w, fc_w = blk.folded()
+            q = ops.gemm_ln_qkv(x, *qkv_w, c["k"][i], c["v"][i], b, tq, pos0, pos_dev, eps=blk.ln1.eps).view(b, tq, C)
+            att = ops.attention(q, c["k"][i], c["v"][i], pos0, pos_dev)
             ops.gemm_nt(att.view(b * tq, C), blk.attn.proj.weight, blk.attn.proj.bias, ops.EPI_RESIDUAL, residual=x, out=x)
-            h = ops.layernorm(x, blk.ln2.weight, blk.ln2.bias, out=h)
-            h = ops.gemm_nt(h, blk.mlp[0].weight, blk.mlp[0].bias, ops.EPI_GELU)
+            h = ops.gemm_ln(x, *fc_w, eps=blk.ln2.eps, epilogue=ops.EPI_GELU)
             ops.gemm_nt(h, blk.mlp[3].weight, blk.mlp[3].bias, ops.EPI_RESIDUAL, residual=x, out=x)
-        c["len"] = pos0 + tq
+        if pos_dev is None:
+            c["len"] = pos0 + tq
         return x
 
     def _head(self, x):
-        return ops.gemm_nt(ops.layernorm(x, self.ln_f.weight, self.ln_f.bias), self.head.weight)
+        """ln_f folded into the (bias-free) head projection."""
+        src = (self.ln_f.weight, self.ln_f.bias, self.head.weight)
+        key = tuple((t.data_ptr(), t._version) for t in src) + (src[0].device,)
+        hf = getattr(self, "_head_folded", None)
+        if hf is None or hf[0] != key:
+            hf = self._head_folded = (key, ops.pack_ln_linear(self.head.weight, None, self.ln_f.weight, self.ln_f.bias))
+        return ops.gemm_ln(x, *hf[1], eps=self.ln_f.eps)
 
     @torch.no_grad()
     def prefill(self, idx, cond_idx=None, delta_length_cond=None, all_logits=False):
@@ -242,6 +271,83 @@ class GPT(nn.Module):
         x = ops.gpt_embed(tok, self.tok_emb.weight, c["pos_table"], frame_pos)
         x = self._layers(x, b, 1)
         return self._head(x)
+
+    # -- sampled generation: prefill + (add_len - 1) decode steps, all state on the device ----------
+    def _emit(self, logits, sampler, noise):
+        """Pick the next token from `logits` into c['tok'] and store it in c['codes'] at c['widx']."""
+        c = self._cache
+        ops.sample_topk(logits, sampler["top_k"], sampler["temperature"], noise=noise, out=c["tok"])
+        c["codes"].scatter_(1, c["widx"], c["tok"])
+        c["widx"].add_(1)
+
+    def _decode_body(self, sampler, noise=None, trace=None):
+        """One decode step driven entirely by device-resident state, hence hipGraph-capturable:
+        embed c['tok'] at frame position len - frame_pos0, run the layers against the cache, pick
+        and store the next token, advance the counters."""
+        c = self._cache
+        b = c["B"]
+        x = ops.gpt_embed(c["tok"], self.tok_emb.weight, c["pos_table"], -c["frame_pos0"], None, c["len_dev"])
+        x = self._layers(x, b, 1, pos_dev=c["len_dev"])
+        logits = self._head(x)
+        if trace is not None:
+            trace.append(logits.clone())
+        if noise is None and sampler["sample"] and sampler["noise"] == "device":
+            noise = torch.empty_like(logits).exponential_(1)
+        self._emit(logits, sampler, noise)
+        c["len_dev"].add_(1)
+
+    @torch.no_grad()
+    def generate(self, code, add_len, cond_idx=None, delta_length_cond=None, sample=False, top_k=None, temperature=1.0,
+                 noise="device", host_noise=None, trace=None, use_graph=True):
+        """code [B,t0] -> [B, t0+add_len]: one prefill, then KV-cached decode steps.  With device
+        (or no) noise and no trace the step is captured once in a hipGraph and replayed; with
+        host-supplied noise (`host_noise(b, v) -> [B,V]`, reference-reproducible) it runs eagerly."""
+        b, t0 = code.shape
+        use_cond = cond_idx is not None and 0 not in cond_idx.size()
+        n_cond = cond_idx.shape[1] if use_cond else 0
+        c = self.begin(b, n_cond + t0 + add_len)
+        sampler = {"sample": bool(sample), "top_k": top_k, "temperature": float(temperature), "noise": noise}
+        eager = trace is not None or (sample and noise != "device") or not use_graph or add_len < 3
+        graph = None
+        if not eager:
+            key = (bool(sample), top_k, float(temperature), n_cond)
+            graph = c["graphs"].get(key)
+            if graph is None:
+                c["frame_pos0"] = n_cond
+                c["len_dev"].fill_(n_cond)
+                c["widx"].zero_()
+                c["tok"].zero_()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._decode_body(sampler)            # warm-up: one-time attribute calls, allocator
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._decode_body(sampler)
+                c["graphs"][key] = graph
+        logits = self.prefill(code, cond_idx if use_cond else None, delta_length_cond if use_cond else None)
+        if trace is not None:
+            trace.append(logits.clone())
+        c["codes"][:, :t0] = code
+        c["widx"].fill_(t0)
+        c["len_dev"].fill_(n_cond + t0)
+
+        def draw():
+            if not sample:
+                return None
+            if noise == "device":
+                return torch.empty_like(logits).exponential_(1)
+            return host_noise(b, logits.shape[1]).to(logits.device, non_blocking=True)
+
+        self._emit(logits, sampler, draw())
+        for _ in range(add_len - 1):
+            if graph is not None:
+                graph.replay()
+            else:
+                self._decode_body(sampler, noise=draw() if sample and noise != "device" else None, trace=trace)
+        c["len"] = n_cond + t0 + add_len - 1
+        return c["codes"][:, :t0 + add_len].clone()
 
     # ------------------------------------------------------------------ reference-shaped forward
     @torch.no_grad()

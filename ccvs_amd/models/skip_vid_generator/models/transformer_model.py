@@ -125,20 +125,12 @@ class Transformer(torch.nn.Module):
             add_len = opt.z_len - t0 - n_cond
         if add_len <= 0:
             return code, state_code
-        net = self.net_t
-        net.begin(b, n_cond + t0 + add_len)
-        out = torch.empty(b, t0 + add_len, dtype=torch.int64, device=code.device)
-        out[:, :t0] = code
-        logits = net.prefill(code, cond_code if n_cond else None, delta_length_cond if n_cond else None)
-        vocab = logits.shape[1]
-        for i in range(add_len):
-            if self.trace is not None:
-                self.trace.append(logits.clone())
-            noise = self._noise(b, vocab, logits.device) if opt.sample else None
-            tok = out[:, t0 + i: t0 + i + 1]
-            ops.sample_topk(logits, opt.top_k, opt.temperature, noise=noise, out=tok)
-            if i + 1 < add_len:
-                logits = net.step(tok)
+        def host_noise(nb, nv):  # the stream torch.multinomial would consume (module docstring)
+            return torch.empty(nb, nv, dtype=torch.float32).exponential_(1, generator=self.generator)
+
+        out = self.net_t.generate(code, add_len, cond_code if n_cond else None, delta_length_cond if n_cond else None,
+                                  sample=opt.sample, top_k=opt.top_k, temperature=opt.temperature, noise=self.sample_noise,
+                                  host_noise=host_noise, trace=self.trace, use_graph=getattr(opt, "use_graph", True))
         return out, state_code
 
     @torch.no_grad()

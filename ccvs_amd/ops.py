@@ -15,6 +15,34 @@ ACT_NONE, ACT_LRELU = 0, 1
 EPI_NONE, EPI_GELU, EPI_RESIDUAL = 0, 1, 2
 
 
+class KernelTimer:
+    """HIP-event bracket around individual launches of one kernel on the current stream
+    (used by bench.py for the roofline of the dominant kernel; off by default)."""
+
+    def __init__(self):
+        self.records = []  # (name, algorithmic flops, start event, end event)
+        self._open = None
+
+    def begin(self, name, flops=0.0):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._open = (name, flops, e0)
+
+    def end(self):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        name, flops, e0 = self._open
+        self.records.append((name, flops, e0, e1))
+
+    def summary(self, name):
+        """(launches, total algorithmic flops, total milliseconds) -- call after a device sync."""
+        rec = [r for r in self.records if r[0] == name]
+        return len(rec), sum(r[1] for r in rec), sum(r[2].elapsed_time(r[3]) for r in rec)
+
+
+KERNEL_TIMER = None  # set to a KernelTimer() to time conv launches
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -78,7 +106,13 @@ def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=Fa
     d.accumulate = 1 if accumulate else 0
     d.out_scale = out_scale
     L = _lib.load()
+    prof = KERNEL_TIMER
+    if prof is not None:
+        macs = n * cout * cin * k * k * (h * w if transposed else ho * wo)
+        prof.begin("conv2d_mfma", flops=2.0 * macs)
     _lib.check(L.ccvs_conv2d(_p(x), _p(w_packed), _p(bias), _p(residual), _p(out), C.byref(d), _stream()), "ccvs_conv2d")
+    if prof is not None:
+        prof.end()
     return out
 
 
@@ -187,15 +221,15 @@ def embed_gather(code, codebook, n, hw):
 
 
 # ------------------------------------------------------------------ transformer
-def gpt_embed(idx, tok_emb, pos_table, pos0=0, pos_off=None):
-    """idx int64 [B,Tq] (row stride free) -> x [B*Tq, C]; positional row = pos_off[b] + pos0 + t."""
-    _need_gpu(idx, pos_off, tok_emb, pos_table)
+def gpt_embed(idx, tok_emb, pos_table, pos0=0, pos_off=None, pos_dev=None):
+    """idx int64 [B,Tq] (row stride free) -> x [B*Tq, C]; positional row = pos_off[b] + pos0 (+ *pos_dev) + t."""
+    _need_gpu(idx, pos_off, tok_emb, pos_table, pos_dev)
     b, tq = idx.shape
     assert idx.stride(1) == 1 or tq == 1
     c = tok_emb.shape[1]
     x = torch.empty(b * tq, c, dtype=torch.float32, device=tok_emb.device)
     L = _lib.load()
-    _lib.check(L.ccvs_gpt_embed(_p(idx), idx.stride(0), _p(pos_off), pos0, tq, _p(tok_emb), _p(pos_table), _p(x), b, c,
+    _lib.check(L.ccvs_gpt_embed(_p(idx), idx.stride(0), _p(pos_off), pos0, _p(pos_dev), tq, _p(tok_emb), _p(pos_table), _p(x), b, c,
                                 tok_emb.shape[0], _stream()), "ccvs_gpt_embed")
     return x
 
@@ -228,25 +262,63 @@ def gemm_nt(x, w, bias=None, epilogue=EPI_NONE, residual=None, out=None):
     return out
 
 
-def kv_append(k, v, kcache, vcache, pos0):
-    """k, v [B,Tq,H*D] views (row stride shared) -> caches [B,H,Tmax,D] at pos0.."""
+def pack_ln_linear(weight, bias, gamma, beta):
+    """Fold a LayerNorm (gamma, beta) into the Linear (weight [N,K], bias [N]) that follows it:
+    returns (W*gamma, bias + W@beta, rowsum(W*gamma)) -- see ccvs_gemm_ln in include/ccvs_hip.h."""
+    w = weight.detach().float()
+    wg = (w * gamma.detach().float().view(1, -1)).contiguous()
+    b = bias.detach().float() if bias is not None else torch.zeros(w.shape[0], device=w.device)
+    bb = (b + w.double().matmul(beta.detach().double()).float()).contiguous()
+    s = wg.double().sum(dim=1).float().contiguous()
+    return wg, bb, s
+
+
+def gemm_ln(x, wg, bb, s, eps=1e-5, epilogue=EPI_NONE, out=None):
+    """epilogue(LayerNorm(x) @ W.T + b) with the LayerNorm folded into (wg, bb, s) = pack_ln_linear(...)."""
+    _need_gpu(x, wg, bb, s, out)
+    m, k = x.shape
+    n = wg.shape[0]
+    assert x.stride(1) == 1 and wg.is_contiguous() and wg.shape[1] == k
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    L = _lib.load()
+    _lib.check(L.ccvs_gemm_ln(_p(x), x.stride(0), _p(wg), _p(bb), _p(s), eps, _p(out), out.stride(0), m, n, k, epilogue, _stream()),
+               "ccvs_gemm_ln")
+    return out
+
+
+def gemm_ln_qkv(x, wg, bb, s, kcache, vcache, b, tq, pos0, pos_dev=None, eps=1e-5):
+    """ln1 + fused QKV projection: returns q [b*tq, C]; K / V go straight into the caches."""
+    _need_gpu(x, wg, bb, s, kcache, vcache, pos_dev)
+    c = x.shape[1]
+    _, h, tmax, d = kcache.shape
+    assert x.shape[0] == b * tq and x.stride(1) == 1 and wg.shape == (3 * c, c) and h * d == c
+    q = torch.empty(b * tq, c, dtype=torch.float32, device=x.device)
+    L = _lib.load()
+    _lib.check(L.ccvs_gemm_ln_qkv(_p(x), x.stride(0), _p(wg), _p(bb), _p(s), eps, _p(q), _p(kcache), _p(vcache), b, tq, c, h, pos0,
+                                  _p(pos_dev), tmax, _stream()), "ccvs_gemm_ln_qkv")
+    return q
+
+
+def kv_append(k, v, kcache, vcache, pos0, pos_dev=None):
+    """k, v [B,Tq,H*D] views (row stride shared) -> caches [B,H,Tmax,D] at pos0 (+ *pos_dev).."""
     b, tq, hd = k.shape
     _, h, tmax, d = kcache.shape
     assert k.stride(2) == 1 and v.stride() == k.stride()
     L = _lib.load()
-    _lib.check(L.ccvs_kv_append(_p(k), _p(v), k.stride(0), k.stride(1), _p(kcache), _p(vcache), b, h, tq, pos0, tmax, d, _stream()),
-               "ccvs_kv_append")
+    _lib.check(L.ccvs_kv_append(_p(k), _p(v), k.stride(0), k.stride(1), _p(kcache), _p(vcache), b, h, tq, pos0, _p(pos_dev), tmax, d,
+                                _stream()), "ccvs_kv_append")
 
 
-def attention(q, kcache, vcache, pos0):
-    """q [B,Tq,H*D] view -> out [B,Tq,H*D]; query t sees cache positions 0..pos0+t."""
+def attention(q, kcache, vcache, pos0, pos_dev=None):
+    """q [B,Tq,H*D] view -> out [B,Tq,H*D]; query t sees cache positions 0..pos0(+*pos_dev)+t."""
     b, tq, hd = q.shape
     _, h, tmax, d = kcache.shape
     assert q.stride(2) == 1
     out = torch.empty(b, tq, hd, dtype=torch.float32, device=q.device)
     L = _lib.load()
-    _lib.check(L.ccvs_attention(_p(q), q.stride(0), q.stride(1), _p(kcache), _p(vcache), _p(out), b, h, tq, pos0, tmax, d, _stream()),
-               "ccvs_attention")
+    _lib.check(L.ccvs_attention(_p(q), q.stride(0), q.stride(1), _p(kcache), _p(vcache), _p(out), b, h, tq, pos0, _p(pos_dev), tmax, d,
+                                _stream()), "ccvs_attention")
     return out
 
 

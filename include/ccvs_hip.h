@@ -125,13 +125,15 @@ int ccvs_embed_gather(const int64_t* code, const float* codebook, float* z, int3
  * Together these replace GPT.forward (models/skip_vid_generator/models/mingpt.py:232-305)
  * and Transformer.get_icode (models/transformer_model.py:395-409), restructured around a
  * KV cache (the reference recomputes the whole prefix per token, transformer_model.py:350).
+ * `pos_dev` (nullable) is a device-resident int32 added to `pos0`: a decode step captured in a
+ * hipGraph then replays at advancing positions by incrementing that word on the device.
  */
 /* x[(b,t)][:] = tok_emb[idx[b*idx_sB + t]] + pos_table[pos_off[b] + pos0 + t], t < Tq
  * (mingpt.py:234-236,242-244).  pos_table rows are the positional embeddings pre-summed by
  * the host for the call (s_emb + t_emb[+delta_length], h/w/t_emb or pos_emb:
  * mingpt.py:186-217); pos_off (int32 [B], may be NULL) selects a per-sample table. */
-int ccvs_gpt_embed(const int64_t* idx, int64_t idx_sB, const int32_t* pos_off, int32_t pos0, int32_t Tq, const float* tok_emb,
-                   const float* pos_table, float* x, int32_t B, int32_t C, int32_t vocab, void* stream);
+int ccvs_gpt_embed(const int64_t* idx, int64_t idx_sB, const int32_t* pos_off, int32_t pos0, const int32_t* pos_dev, int32_t Tq,
+                   const float* tok_emb, const float* pos_table, float* x, int32_t B, int32_t C, int32_t vocab, void* stream);
 
 /* nn.LayerNorm over the last dim (mingpt.py:103-104,168), eps 1e-5. */
 int ccvs_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t rows, int32_t C, void* stream);
@@ -142,15 +144,28 @@ int ccvs_layernorm(const float* x, const float* gamma, const float* beta, float*
 int ccvs_gemm_nt(const float* x, int64_t ldx, const float* w, const float* bias, const float* res, float* y, int64_t ldy,
                  int32_t M, int32_t N, int32_t K, int32_t epilogue, void* stream);
 
+/* LayerNorm folded into the following Linear (mingpt.py:115-116: x + attn(ln1(x)), mlp(ln2(x))):
+ *   LN(x) @ W^T + b = rstd * (x @ W'^T - mean * s) + b',  W' = W*gamma, s = rowsum(W'), b' = b + W beta
+ * (w_gamma / bias_beta / w_rowsum are packed once by the host).  epilogue 0 none, 1 GELU. */
+int ccvs_gemm_ln(const float* x, int64_t ldx, const float* w_gamma, const float* bias_beta, const float* w_rowsum, float eps,
+                 float* y, int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t epilogue, void* stream);
+
+/* ln1 + fused [query; key; value] projection (mingpt.py:67-69): q [B*Tq, C] is written dense,
+ * the key / value column blocks go straight into kcache / vcache [B,H,Tmax,C/H] at positions
+ * pos0 (+ *pos_dev) + t. */
+int ccvs_gemm_ln_qkv(const float* x, int64_t ldx, const float* w_gamma, const float* bias_beta, const float* w_rowsum, float eps,
+                     float* q, float* kcache, float* vcache, int32_t B, int32_t Tq, int32_t C, int32_t H, int32_t pos0,
+                     const int32_t* pos_dev, int32_t Tmax, void* stream);
+
 /* Causal attention against a KV cache (mingpt.py:67-77).
  * q [B,Tq,H*D] (batch stride q_sB, row stride ldq); kcache/vcache [B,H,Tmax,D]; query t
  * attends cache positions 0 .. pos0+t.  out [B,Tq,H*D] dense.  D in {16, 32, 64}. */
 int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const float* kcache, const float* vcache, float* out, int32_t B,
-                   int32_t H, int32_t Tq, int32_t pos0, int32_t Tmax, int32_t D, void* stream);
+                   int32_t H, int32_t Tq, int32_t pos0, const int32_t* pos_dev, int32_t Tmax, int32_t D, void* stream);
 
 /* Scatter new K/V rows [B,Tq,H*D] (batch stride sB, row stride ld) into the caches at pos0.. */
 int ccvs_kv_append(const float* k, const float* v, int64_t sB, int64_t ld, float* kcache, float* vcache, int32_t B, int32_t H,
-                   int32_t Tq, int32_t pos0, int32_t Tmax, int32_t D, void* stream);
+                   int32_t Tq, int32_t pos0, const int32_t* pos_dev, int32_t Tmax, int32_t D, void* stream);
 
 /* get_icode: logits/temperature -> top-k mask (ties kept) -> softmax -> pick.
  * noise == NULL: greedy argmax (sample=False, topk k=1).  noise [B,V] ~ Exp(1):

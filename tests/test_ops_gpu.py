@@ -265,6 +265,33 @@ def test_layernorm_gemm(ops):
         close(ops.gemm_nt(x.cuda(), w.cuda(), None, epilogue=ops.EPI_RESIDUAL, residual=res.cuda()), x @ w.t() + res, 1e-4)
 
 
+def test_gemm_ln_fold(ops):
+    """LayerNorm folded into the following Linear (and the QKV variant scattering K/V into the cache)."""
+    torch.manual_seed(1)
+    F = torch.nn.functional
+    for m, n, k in [(16, 4096, 1024), (16, 1024, 1024), (37, 96, 64), (5, 50, 32)]:
+        x = torch.randn(m, k) * 0.7 + 0.3          # non-zero row means
+        gam, bet = torch.randn(k) * 0.3 + 1.0, torch.randn(k) * 0.2
+        w, b = torch.randn(n, k) * 0.05, torch.randn(n)
+        packed = [t.cuda() for t in ops.pack_ln_linear(w, b, gam, bet)]
+        want = F.layer_norm(x, (k,), gam, bet) @ w.t() + b
+        close(ops.gemm_ln(x.cuda(), *packed), want, 2e-4)
+        close(ops.gemm_ln(x.cuda(), *packed, epilogue=ops.EPI_GELU), F.gelu(want), 2e-4)
+    B, Tq, C, H, Tmax, pos0 = 3, 5, 128, 2, 16, 4
+    x = torch.randn(B * Tq, C) + 0.1
+    gam, bet = torch.randn(C) * 0.3 + 1.0, torch.randn(C) * 0.2
+    w, b = torch.randn(3 * C, C) * 0.05, torch.randn(3 * C)
+    packed = [t.cuda() for t in ops.pack_ln_linear(w, b, gam, bet)]
+    want = (F.layer_norm(x, (C,), gam, bet) @ w.t() + b).view(B, Tq, 3, H, C // H)
+    kc, vc = torch.zeros(B, H, Tmax, C // H).cuda(), torch.zeros(B, H, Tmax, C // H).cuda()
+    pos_dev = torch.tensor([3], dtype=torch.int32).cuda()   # effective position = pos0 + 3
+    q = ops.gemm_ln_qkv(x.cuda(), *packed, kc, vc, B, Tq, pos0, pos_dev)
+    close(q.view(B, Tq, H, C // H), want[:, :, 0], 2e-4)
+    close(kc[:, :, 7:12], want[:, :, 1].transpose(1, 2), 2e-4)
+    close(vc[:, :, 7:12], want[:, :, 2].transpose(1, 2), 2e-4)
+    assert kc[:, :, :7].abs().max().item() == 0 and kc[:, :, 12:].abs().max().item() == 0
+
+
 def test_attention_cache(ops):
     torch.manual_seed(0)
     B, H, D, T = 3, 4, 64, 37
