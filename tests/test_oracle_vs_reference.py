@@ -1,0 +1,50 @@
+"""not gpu, build container only: the oracle against the REAL reference imported through
+tests/golden/ref_harness.py (skipped where /root/reference does not exist, e.g. the GPU box)."""
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import ref_harness as rh  # noqa: E402
+from oracle import ccvs_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not rh.reference_available(), reason="upstream reference tree not present")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return rh.load_reference()
+
+
+def test_encoder_decoder_fresh_weights(ref):
+    """New seed, new input: reference modules vs the oracle driven by their state dicts."""
+    opt = rh.parse_reference_options(rh.TINY_ARGV)["qvid_generator"]
+    torch.manual_seed(123)
+    enc, dec = ref.sae.SkipGANEncoder(opt), ref.sae.SkipGANDecoder(opt)
+    vid = torch.rand(1, 2, 3, 32, 32) * 2 - 1
+    with torch.no_grad():
+        z, inter = enc(vid)
+        oz, ointer = O.encoder_forward(enc.state_dict(), opt, vid)
+        assert torch.equal(z, oz) and all(torch.equal(a, b) for a, b in zip(inter, ointer))
+        ctx = [[f[:, :1] for f in inter], [f[:, 1:] for f in inter]]
+        rgb, _, flows, occs, _ = dec(z[:, :1].contiguous(), ctx, return_all=True, inter_pre_warping=False)
+        orgb, oflows, ooccs = O.decoder_forward(dec.state_dict(), opt, z[:, :1].contiguous(), ctx, return_all=True)
+        assert (rgb - orgb).abs().max() < 1e-6
+        for a, b in zip(flows + occs, oflows + ooccs):
+            assert (a - b).abs().max() < 1e-6
+
+
+def test_gpt_spatio_temporal_and_flat_positions(ref):
+    torch.manual_seed(5)
+    for mode in ("spatio-temporal", None):
+        gpt = ref.mingpt.GPT(vocab_size=30, block_size=48, num_blocks=3, n_layer=1, n_head=2, n_embd=32, emb_mode=mode, shape=[4, 4])
+        with torch.no_grad():
+            for n, p in gpt.named_parameters():
+                if n.endswith("_emb"):
+                    p.normal_(0, 0.1)
+            idx = torch.randint(0, 30, (2, 21))
+            cfg = O.namespace(z_shape=[4, 4], emb_mode=mode, n_layer=1, n_head=2, z_len=48)
+            assert (gpt(idx) - O.gpt_forward(gpt.state_dict(), cfg, idx)).abs().max() < 1e-6
