@@ -21,7 +21,8 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense)
 
 
 def parse_args():
@@ -33,6 +34,7 @@ def parse_args():
     ap.add_argument("--config", type=str, default="bair", choices=["bair", "kinetics"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-noise", type=str, default="device", choices=["device", "host"])
+    ap.add_argument("--conv-precision", type=str, default=None, choices=["bf16x3", "f32"])
     return ap.parse_args()
 
 
@@ -118,6 +120,8 @@ def main():
     from ccvs_amd import lib, ops
     from ccvs_amd.tools.engine import Engine
     lib.load()
+    if args.conv_precision:
+        ops.CONV_PRECISION = args.conv_precision
 
     with Engine() as engine:
         gen, opt = build_generator(args)
@@ -159,20 +163,27 @@ def main():
 
         if engine.is_main:
             frames = predicted * args.batch * world * args.steps
-            n_conv, conv_flops, conv_ms = timer.summary("conv2d_mfma")
+            kind = ops.CONV_PRECISION
+            n_conv, conv_flops, conv_ms = timer.summary("conv2d_" + kind)
             achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+            # bf16x3: three bf16 MFMA products per algorithmic fp32 product; peak = dense bf16 MFMA
+            peak = BF16_MFMA_PEAK_TFLOPS if kind == "bf16x3" else FP32_MFMA_PEAK_TFLOPS
+            products = 3 if kind == "bf16x3" else 1
             line = {
                 "metric": "synthesized frames/sec (BAIR 256x256, cond=1, pred=15), whole job", "value": frames / elapsed,
                 "unit": "frames/s", "per_gpu": frames / elapsed / world, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
+                "dtype": "f32 (convolutions as split-bf16 x3 on bf16 MFMA, fp32 accumulate)" if kind == "bf16x3" else "f32",
+                "data": "synthetic",
                 "config": {"workload": "BAIR 256x256 1->15 frames, batch 16 per GPU (BASELINE.json configs[1])" if args.config == "bair"
                            else "Kinetics-600 64x64 5->11 frames", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                            "predicted_frames_per_clip": predicted, "sampling": f"top-k {xopt.top_k}, T={xopt.temperature}, noise={args.sample_noise}",
                            "parallelism": f"dp{world} (batch sharded, one RCCL all-gather of uint8 clips)"},
                 "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
-                "roofline": {"kernel": "conv2d_mfma_kernel", "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                             "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "roofline": {"kernel": "conv2d_bf16x3_kernel" if kind == "bf16x3" else "conv2d_mfma_kernel", "bound": "mfma",
+                             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                             "mfma_products_per_flop": products, "mfma_issue_frac": products * achieved / peak,
+                             "vs_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                              "launches": n_conv, "avg_launch_us": 1e3 * conv_ms / max(n_conv, 1),
                              "algorithmic_gflop_per_launch": conv_flops / max(n_conv, 1) / 1e9,
                              "share_of_step_time": conv_ms * 1e-3 / elapsed},

@@ -16,51 +16,10 @@
 // convolution (four output-parity classes, each a small dense conv on the input grid)
 // all reduce to the same tap-table loop.
 #include "common.h"
+#include "conv_common.h"
 
 #define CONV_CC 8     // input channels per LDS chunk (even: the MFMA consumes k in pairs)
 #define CONV_MAX_E 5  // max halo-tile elements per thread per channel (256*5 >= 17*65)
-
-struct ConvK {
-    const float* x;
-    const float* w;
-    const float* bias;
-    const float* res;
-    float* y;
-    int N, Cin, Hin, Win;
-    long in_sN, in_sC;
-    int Cout, CoutPad, Hout, Wout;
-    long out_sN, out_sC, res_sN, res_sC;
-    int kh, kw, stride, pad, transposed;
-    int act, accumulate;
-    float out_scale;
-    int tiles_x, tiles_y;
-};
-
-struct AxisTaps {
-    int nt;       // number of taps along this axis
-    int d0, dd;   // input offset of tap a: d0 + a*dd
-    int w0, dw;   // weight index of tap a along this axis: w0 + a*dw
-    int s;        // virtual -> input stride
-    int os, oo;   // virtual -> output: o = v*os + oo
-    int V;        // virtual extent
-    int lo, ext;  // min offset, halo extent (hi - lo)
-};
-
-__device__ __forceinline__ AxisTaps axis_taps(int k, int stride, int pad, int transposed, int parity, int out_extent) {
-    AxisTaps t;
-    if (transposed) {
-        // conv_transpose2d stride 2 pad 0:  o = 2*i + kk.  Output parity class `parity`
-        // uses taps kk = parity, parity+2, ... reading input i = v - a.
-        t.nt = (k - parity + 1) / 2;
-        t.d0 = 0; t.dd = -1; t.w0 = parity; t.dw = 2; t.s = 1; t.os = 2; t.oo = parity;
-        t.V = (out_extent - parity + 1) / 2;
-        t.lo = -(t.nt - 1); t.ext = t.nt - 1;
-    } else {
-        t.nt = k; t.d0 = -pad; t.dd = 1; t.w0 = 0; t.dw = 1; t.s = stride; t.os = 1; t.oo = 0;
-        t.V = out_extent; t.lo = -pad; t.ext = k - 1;
-    }
-    return t;
-}
 
 template <int TW, int MB>
 __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvK p) {
@@ -124,11 +83,14 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvK p) {
         for (int j = 0; j < CONV_MAX_E; ++j) {
             if (off[j] != -2) {
                 const int e = tid + 256 * j;
+                // unconditional loads from a clamped address, zeroed afterwards (a predicated load in an
+                // unrolled loop makes hipcc branch + wait per element)
+                const bool inside = off[j] >= 0;
+                const int o = inside ? off[j] : 0;
 #pragma unroll
                 for (int c = 0; c < CONV_CC; ++c) {
-                    float v = 0.f;
-                    if (off[j] >= 0 && c0 + c < p.Cin) v = xn[(long)(c0 + c) * p.in_sC + off[j]];
-                    in_tile[c * plane + e] = v;
+                    const float t = xn[(long)min(c0 + c, p.Cin - 1) * p.in_sC + o];
+                    in_tile[c * plane + e] = (inside && c0 + c < p.Cin) ? t : 0.f;
                 }
             }
         }
@@ -140,8 +102,8 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvK p) {
                 const int b = idx / (CONV_CC * NT), rem = idx - b * (CONV_CC * NT);
                 const int c = rem / NT, nn = rem - c * NT;
                 const int tap = wy * p.kw + (ax.w0 + b * ax.dw);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c0 + c < p.Cin) v = *reinterpret_cast<const float4*>(p.w + ((long)tap * p.Cin + (c0 + c)) * p.CoutPad + n0 + nn);
+                float4 v = *reinterpret_cast<const float4*>(p.w + ((long)tap * p.Cin + min(c0 + c, p.Cin - 1)) * p.CoutPad + n0 + nn);
+                if (c0 + c >= p.Cin) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(w_tile + idx) = v;
             }
             __syncthreads();

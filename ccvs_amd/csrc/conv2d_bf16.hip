@@ -1,0 +1,531 @@
+// Convolution on the bf16 matrix cores with fp32-class accuracy ("split-bf16", 3 products).
+//
+// Same implicit GEMM, tiling, tap table and epilogue as conv2d.hip, but each fp32 operand is
+// split into two bf16 halves  v = hi + lo  (hi = RNE_bf16(v), lo = RNE_bf16(v - hi), residual
+// <= 2^-17 |v|) and the product is evaluated as  hi*hi + hi*lo + lo*hi  on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The dropped lo*lo term is <= 2^-16 relative,
+// i.e. the per-product error is ~1e-5 -- two orders below the 1e-3 pixel tolerance of the path --
+// while the matrix pipe runs 16x the fp32-MFMA rate, so three products are still 5.3x faster than
+// v_mfma_f32_32x32x2_f32 (157 TF -> 833 TF effective ceiling).
+//
+// Operand layout: a 32x32x16 MFMA takes 8 consecutive k per lane (lanes 0-31: k 0..7, lanes
+// 32-63: k 8..15).  k = input channel, so both LDS images are "8 channels innermost":
+//   input   [half][hi|lo][halo pixel][8 bf16]   -- converted from NCHW fp32 while staging
+//   weights [tap][half][hi|lo][cout][8 bf16]    -- pre-split and pre-laid-out once by the host
+// Every operand fetch is one ds_read_b128 with 16-B lane stride (conflict-free).
+#include "common.h"
+#include "conv_common.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define CB_CC 16      // input channels per chunk = one MFMA K step
+#define CB_MAX_E 5
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// two floats -> two bf16 (round to nearest even) in one v_cvt_pk_bf16_f32; element 0 in the low half
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// 8 floats -> 8 bf16 hi (uint4) + 8 bf16 lo (uint4),  v = hi + lo + O(2^-17 |v|)
+__device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = pk_bf16(v[2 * i], v[2 * i + 1]);
+        l[i] = pk_bf16(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// Stage `n_iter`-strided elements of one 16-channel chunk of the input halo tile: NCHW fp32 ->
+// [half][hi|lo][pixel][8 bf16].  Loads are unconditional from clamped addresses (a predicated load
+// in an unrolled loop makes hipcc branch and wait per element) and zeroed afterwards.
+__device__ __forceinline__ void stage_pixel(const float* __restrict__ xn, long in_sC, int Cin, int c0, int off, uint4* in_tile, int plane,
+                                            int e) {
+    const bool inside = off >= 0;
+    const float* src = xn + (inside ? off : 0);
+    const bool full = (c0 + CB_CC <= Cin);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float v[8];
+        if (full) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = src[(long)(c0 + 8 * h + i) * in_sC];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = c0 + 8 * h + i;
+                const float t = src[(long)min(c, Cin - 1) * in_sC];
+                v[i] = c < Cin ? t : 0.f;
+            }
+        }
+        if (!inside) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        }
+        uint4 hi, lo;
+        split8(v, hi, lo);
+        in_tile[(h * 2 + 0) * plane + e] = hi;
+        in_tile[(h * 2 + 1) * plane + e] = lo;
+    }
+}
+
+template <int TW, int MB>
+__global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG) {
+    constexpr int TH = 256 / TW;
+    constexpr int NT = 32 * MB;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
+    const int n0 = blockIdx.y * NT;
+    int n = blockIdx.z, cls = 0;
+    if (p.transposed) { cls = n & 3; n >>= 2; }
+    const AxisTaps ay = axis_taps(p.kh, p.stride, p.pad, p.transposed, cls >> 1, p.Hout);
+    const AxisTaps ax = axis_taps(p.kw, p.stride, p.pad, p.transposed, cls & 1, p.Wout);
+    if (ty * TH >= ay.V || tx * TW >= ax.V) return;
+
+    const int IH = (TH - 1) * ay.s + ay.ext + 1;
+    const int IW = (TW - 1) * ax.s + ax.ext + 1;
+    const int plane = IH * IW;
+    const int iy0 = ty * TH * ay.s + ay.lo, ix0 = tx * TW * ax.s + ax.lo;
+    uint4* in_tile = smem4;              // [half 2][part 2][plane]
+    uint4* w_tile = smem4 + 4 * plane;   // [ntx][half 2][part 2][NT]
+
+    int off[CB_MAX_E];
+#pragma unroll
+    for (int j = 0; j < CB_MAX_E; ++j) {
+        const int e = tid + 256 * j;
+        off[j] = -2;
+        if (e < plane) {
+            const int r = e / IW, c = e - r * IW;
+            const int gy = iy0 + r, gx = ix0 + c;
+            off[j] = (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) ? gy * p.Win + gx : -1;
+        }
+    }
+    int bofs[2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const int pj = (wave * 2 + pp) * 32 + (lane & 31);
+        const int prow = pj / TW, pcol = pj - prow * TW;
+        bofs[pp] = prow * ay.s * IW + pcol * ax.s;
+    }
+    const int khalf = lane >> 5;
+
+    f32x16 acc[MB][2];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][pp][r] = 0.f;
+
+    const float* xn = p.x + (long)n * p.in_sN;
+    const int wunits = ax.nt * 4 * NT;  // 16-B units of one tap row
+
+    for (int c0 = 0; c0 < p.Cin; c0 += CB_CC) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CB_MAX_E; ++j) {
+            if (off[j] != -2) stage_pixel(xn, p.in_sC, p.Cin, c0, off[j], in_tile, plane, tid + 256 * j);
+        }
+        const int cg0 = c0 >> 3;
+        for (int a = 0; a < ay.nt; ++a) {
+            if (a > 0) __syncthreads();
+            const int wy = ay.w0 + a * ay.dw;
+            for (int i = tid; i < wunits; i += 256) {
+                const int b = i / (4 * NT), rem = i - b * (4 * NT);
+                const int hp = rem / NT, co = rem - hp * NT;   // hp = half*2 + part
+                const int tap = wy * p.kw + (ax.w0 + b * ax.dw);
+                const int cg = cg0 + (hp >> 1);  // < CinG: the host pads Cin to a multiple of 16
+                w_tile[i] = wsplit[(((long)tap * CinG + cg) * 2 + (hp & 1)) * p.CoutPad + n0 + co];
+            }
+            __syncthreads();
+            const int dyl = (ay.d0 + a * ay.dd - ay.lo) * IW;
+            for (int b = 0; b < ax.nt; ++b) {
+                const int dl = dyl + (ax.d0 + b * ax.dd - ax.lo);
+                const uint4* wt = w_tile + (b * 4 + khalf * 2) * NT + (lane & 31);
+                const uint4* it = in_tile + (khalf * 2) * plane + dl;
+                bf16x8 bh[2], bl[2];
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    bh[pp] = __builtin_bit_cast(bf16x8, it[bofs[pp]]);
+                    bl[pp] = __builtin_bit_cast(bf16x8, it[plane + bofs[pp]]);
+                }
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, wt[m * 32]);
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, wt[NT + m * 32]);
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[pp], acc[m][pp], 0, 0, 0);
+                        acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[pp], acc[m][pp], 0, 0, 0);
+                        acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[pp], acc[m][pp], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const int pj = (wave * 2 + pp) * 32 + (lane & 31);
+        const int prow = pj / TW, pcol = pj - prow * TW;
+        const int vy = ty * TH + prow, vx = tx * TW + pcol;
+        if (vy >= ay.V || vx >= ax.V) continue;
+        const int oy = vy * ay.os + ay.oo, ox = vx * ax.os + ax.oo;
+        const long opix = (long)oy * p.Wout + ox;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = n0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (co < p.Cout) {
+                    float v = acc[m][pp][r];
+                    if (p.bias) v += p.bias[co];
+                    if (p.act == CCVS_ACT_LRELU) v = lrelu01(v);
+                    if (p.res) v += p.res[(long)n * p.res_sN + (long)co * p.res_sC + opix];
+                    v *= p.out_scale;
+                    float* dst = p.y + (long)n * p.out_sN + (long)co * p.out_sC + opix;
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Producer / consumer form (used whenever its LDS and register staging fit): a 512-thread
+// workgroup whose waves 0-3 only issue MFMAs and whose waves 4-7 only stage -- the matrix pipe and
+// the VALU / memory pipes of a SIMD run concurrently, so the fp32 -> split-bf16 conversion hides
+// under the MFMAs.  A step is one tap row of one 16-channel chunk; the halo tile and the tap-row
+// weights are double-buffered in LDS and handed over with ONE workgroup barrier per step.
+// The producers are software-pipelined one step deep in REGISTERS: during step s they first
+// convert + store what they loaded during step s-1 (needed at step s+1), then issue the global
+// loads for step s+2 -- so every load has a whole step of MFMA time to land before it is touched.
+//   bundle of step t:  W_row(t)   and, for chunk c, the halo-tile parts j (pixel pass j of the 256
+//   producer threads) with j % nt == a, which are stored during step (c-1, a) and loaded one
+//   step before that.
+// ---------------------------------------------------------------------------------------
+#define CB_WR 6  // uint4 of tap-row weights per producer thread (ntx*4*NT <= 256*CB_WR)
+#define CB_XQ 2  // halo-tile pixel passes per producer thread per step (passes <= CB_XQ * nt)
+
+template <int TW, int MB>
+__global__ __launch_bounds__(512, 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
+    constexpr int TH = 256 / TW;
+    constexpr int NT = 32 * MB;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+    const int rt = tid & 255, rw = wave & 3;  // thread / wave index inside the role
+    const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
+    const int n0 = blockIdx.y * NT;
+    int n = blockIdx.z, cls = 0;
+    if (p.transposed) { cls = n & 3; n >>= 2; }
+    const AxisTaps ay = axis_taps(p.kh, p.stride, p.pad, p.transposed, cls >> 1, p.Hout);
+    const AxisTaps ax = axis_taps(p.kw, p.stride, p.pad, p.transposed, cls & 1, p.Wout);
+    if (ty * TH >= ay.V || tx * TW >= ax.V) return;
+
+    const int IH = (TH - 1) * ay.s + ay.ext + 1;
+    const int IW = (TW - 1) * ax.s + ax.ext + 1;
+    const int plane = IH * IW;
+    const int iy0 = ty * TH * ay.s + ay.lo, ix0 = tx * TW * ax.s + ax.lo;
+    const int in_sz = 4 * plane, w_sz = ntx_max * 4 * NT;
+    uint4* in_buf = smem4;               // [2][half 2][part 2][plane]
+    uint4* w_buf = smem4 + 2 * in_sz;    // [2][ntx][half 2][part 2][NT]
+
+    const float* xn = p.x + (long)n * p.in_sN;
+    const int nt = ay.nt;
+    const int nchunks = (p.Cin + CB_CC - 1) / CB_CC;
+    const int nsteps = nchunks * nt;
+    const int wunits = ax.nt * 4 * NT;
+
+    // ---- producer helpers -------------------------------------------------------------------
+    // All per-lane address parts are computed ONCE; per step only wave-uniform (scalar) bases change,
+    // so a load is `uniform base + 32-bit lane offset` with no vector address arithmetic.
+    int offs[CB_MAX_E];  // halo element -> plane offset; -2: no such element, -1: outside the image
+#pragma unroll
+    for (int j = 0; j < CB_MAX_E; ++j) {
+        const int e = rt + 256 * j;
+        offs[j] = -2;
+        if (producer && e < plane) {
+            const int r = e / IW, c = e - r * IW;
+            const int gy = iy0 + r, gx = ix0 + c;
+            offs[j] = (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) ? gy * p.Win + gx : -1;
+        }
+    }
+    auto pix_offset = [&](int j) -> int {  // register-array select without dynamic indexing
+        int o = -2;
+#pragma unroll
+        for (int jj = 0; jj < CB_MAX_E; ++jj) o = (j == jj) ? offs[jj] : o;
+        return o;
+    };
+    int wofs[CB_WR];  // lane part of the weight address (uint4 units): tap column, half, hi|lo, cout
+#pragma unroll
+    for (int i = 0; i < CB_WR; ++i) {
+        const int ic = min(rt + 256 * i, wunits - 1);
+        const int b = ic / (4 * NT), rem = ic - b * (4 * NT);
+        const int hp = rem / NT, co = rem - hp * NT;
+        wofs[i] = ((b * ax.dw * CinG + (hp >> 1)) * 2 + (hp & 1)) * p.CoutPad + co;
+    }
+    u32x4 wraw[CB_WR];  // native vector type: HIP's uint4 struct array does not stay in registers across the loop
+    float xraw[CB_XQ][16];
+    int xoff[CB_XQ], xc0 = 0;
+#pragma unroll
+    for (int q = 0; q < CB_XQ; ++q) xoff[q] = -2;
+
+    const int ay_w0 = ay.w0, ay_dw = ay.dw, ax_w0 = ax.w0, kw_ = p.kw, cout_pad = p.CoutPad, cin_ = p.Cin;
+    const long in_sC = p.in_sC;
+    auto load_w = [&](int ci_, int a_) {
+        const uint4* base = wsplit + ((((long)(ay_w0 + a_ * ay_dw) * kw_ + ax_w0) * CinG + ci_ * 2) * 2) * cout_pad + n0;  // uniform
+#pragma unroll
+        for (int i = 0; i < CB_WR; ++i) wraw[i] = *reinterpret_cast<const u32x4*>(base + wofs[i]);
+    };
+    auto store_w = [&](uint4* dst) {
+#pragma unroll
+        for (int i = 0; i < CB_WR; ++i)
+            if (rt + 256 * i < wunits) *reinterpret_cast<u32x4*>(dst + rt + 256 * i) = wraw[i];
+    };
+    auto load_x = [&](int c_, int slot) {
+        xc0 = c_ * CB_CC;
+        const bool full = (xc0 + CB_CC <= cin_);
+#pragma unroll
+        for (int q = 0; q < CB_XQ; ++q) {
+            xoff[q] = pix_offset(slot + q * nt);
+            if (xoff[q] != -2) {
+                const int o = max(xoff[q], 0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float* cb = xn + (long)(full ? xc0 + i : min(xc0 + i, cin_ - 1)) * in_sC;  // uniform
+                    xraw[q][i] = cb[o];
+                }
+            }
+        }
+    };
+    auto store_x = [&](int slot, uint4* dst) {
+#pragma unroll
+        for (int q = 0; q < CB_XQ; ++q) {
+            if (xoff[q] == -2) continue;
+            const int e = rt + 256 * (slot + q * nt);
+            const bool plain = (xoff[q] >= 0) && (xc0 + CB_CC <= cin_);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = xraw[q][8 * h + i];
+                if (!plain) {  // border pixel or channel tail: zero what lies outside
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (xoff[q] >= 0 && xc0 + 8 * h + i < cin_) ? v[i] : 0.f;
+                }
+                uint4 hi, lo;
+                split8(v, hi, lo);
+                dst[(h * 2 + 0) * plane + e] = hi;
+                dst[(h * 2 + 1) * plane + e] = lo;
+            }
+        }
+    };
+
+    // ---- consumer state ---------------------------------------------------------------------
+    int bofs[2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const int pj = (rw * 2 + pp) * 32 + (lane & 31);
+        const int prow = pj / TW, pcol = pj - prow * TW;
+        bofs[pp] = prow * ay.s * IW + pcol * ax.s;
+    }
+    const int khalf = lane >> 5;
+    f32x16 acc[MB][2];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][pp][r] = 0.f;
+
+    if (producer) {
+        // prologue: chunk 0's halo tile and step 0's weights, synchronously and straight into LDS
+        for (int j = 0; j < CB_MAX_E; ++j) {
+            const int o = pix_offset(j);
+            if (o != -2) stage_pixel(xn, p.in_sC, p.Cin, 0, o, in_buf, plane, rt + 256 * j);
+        }
+        const uint4* base = wsplit + ((((long)ay_w0 * kw_ + ax_w0) * CinG) * 2) * cout_pad + n0;
+#pragma unroll
+        for (int i = 0; i < CB_WR; ++i)
+            if (rt + 256 * i < wunits) w_buf[rt + 256 * i] = base[wofs[i]];
+    }
+
+    // Step -1 only lets the producers fetch the first register bundle (everyone meets at the barrier);
+    // steps 0 .. nsteps-1 are the real ones.  (ci, a) = (chunk, tap row) of step s.
+    int ci = -1, a = nt - 1;
+    for (int s = -1; s < nsteps; ++s) {
+        if (producer && !(ablate & 1)) {
+            if (s >= 0) {  // (1) convert + store the bundle loaded during the previous step
+                if (s + 1 < nsteps) store_w(w_buf + ((s + 1) & 1) * w_sz);
+                if (ci + 1 < nchunks) store_x(a, in_buf + ((ci + 1) & 1) * in_sz);
+            }
+            // (2) issue the loads of the following bundle: W_row(s+2), halo parts of slot a+1
+            int a1 = a + 1, c1 = ci;
+            if (a1 == nt) { a1 = 0; ++c1; }
+            int a2 = a1 + 1, c2 = c1;
+            if (a2 == nt) { a2 = 0; ++c2; }
+            if (s + 2 < nsteps) load_w(c2, a2);
+            const int cx = (a1 == 0) ? ci + 2 : ci + 1;  // chunk whose parts of slot a1 are stored next step
+            if (cx < nchunks) {
+                load_x(cx, a1);
+            } else {
+#pragma unroll
+                for (int q = 0; q < CB_XQ; ++q) xoff[q] = -2;
+            }
+        } else if (!producer && s >= 0 && !(ablate & 2)) {
+            const uint4* it0 = in_buf + (ci & 1) * in_sz + (khalf * 2) * plane + (ay.d0 + a * ay.dd - ay.lo) * IW;
+            const uint4* wt0 = w_buf + (s & 1) * w_sz + (khalf * 2) * NT + (lane & 31);
+            for (int b = 0; b < ax.nt; ++b) {
+                const uint4* it = it0 + (ax.d0 + b * ax.dd - ax.lo);
+                const uint4* wt = wt0 + b * 4 * NT;
+                bf16x8 bh[2], bl[2];
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    bh[pp] = __builtin_bit_cast(bf16x8, it[bofs[pp]]);
+                    bl[pp] = __builtin_bit_cast(bf16x8, it[plane + bofs[pp]]);
+                }
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, wt[m * 32]);
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, wt[NT + m * 32]);
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[pp], acc[m][pp], 0, 0, 0);
+                        acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[pp], acc[m][pp], 0, 0, 0);
+                        acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[pp], acc[m][pp], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (++a == nt) { a = 0; ++ci; }
+    }
+    if (producer) return;
+
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const int pj = (rw * 2 + pp) * 32 + (lane & 31);
+        const int prow = pj / TW, pcol = pj - prow * TW;
+        const int vy = ty * TH + prow, vx = tx * TW + pcol;
+        if (vy >= ay.V || vx >= ax.V) continue;
+        const int oy = vy * ay.os + ay.oo, ox = vx * ax.os + ax.oo;
+        const long opix = (long)oy * p.Wout + ox;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = n0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (co < p.Cout) {
+                    float v = acc[m][pp][r];
+                    if (p.bias) v += p.bias[co];
+                    if (p.act == CCVS_ACT_LRELU) v = lrelu01(v);
+                    if (p.res) v += p.res[(long)n * p.res_sN + (long)co * p.res_sC + opix];
+                    v *= p.out_scale;
+                    float* dst = p.y + (long)n * p.out_sN + (long)co * p.out_sC + opix;
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+template <int TW, int MB>
+static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int halo_h, int halo_w, int ntx_max, int gz, hipStream_t st) {
+    constexpr int NT = 32 * MB;
+    const int plane = halo_h * halo_w;
+    if (plane > 256 * CB_MAX_E) {
+        ccvs_set_error("ccvs_conv2d_bf16x3: halo tile %dx%d too large", halo_h, halo_w);
+        return CCVS_ERR_ARG;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_kernel<TW, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const size_t smem_pc = (size_t)(2 * 4 * plane + 2 * ntx_max * 4 * NT) * 16;
+    const int nt_min = (k.transposed ? 1 : k.kh);               // fewest tap rows of any parity class
+    const int passes = (plane + 255) / 256;
+    const bool regs_ok = (ntx_max * 4 * NT <= 256 * CB_WR) && (passes <= CB_XQ * nt_min);
+    if (smem_pc <= 156 * 1024 && regs_ok) {  // double-buffered producer / consumer form
+        dim3 grid(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
+        static const int ablate = getenv("CCVS_CONV_ABLATE") ? atoi(getenv("CCVS_CONV_ABLATE")) : 0;  // timing experiments only (1: no staging, 2: no MFMA)
+        hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB>), grid, dim3(512), smem_pc, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
+        CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
+        return CCVS_OK;
+    }
+    const size_t smem = (size_t)(4 * plane + ntx_max * 4 * NT) * 16;
+    if (smem > 160 * 1024) {
+        ccvs_set_error("ccvs_conv2d_bf16x3: %zu bytes of LDS needed", smem);
+        return CCVS_ERR_ARG;
+    }
+    dim3 grid(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
+    hipLaunchKernelGGL((conv2d_bf16x3_kernel<TW, MB>), grid, dim3(256), smem, st, k, (const uint4*)wsplit, CinG);
+    CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
+    return CCVS_OK;
+}
+
+extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const float* bias, const float* residual, float* y,
+                                  const ccvs_conv_desc* d, void* stream) {
+    CCVS_REQUIRE(x && w_split && y && d, "ccvs_conv2d_bf16x3: null pointer");
+    CCVS_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->Hin > 0 && d->Win > 0, "ccvs_conv2d_bf16x3: empty tensor");
+    CCVS_REQUIRE(d->kh == d->kw && d->kh >= 1 && d->kh <= 9, "ccvs_conv2d_bf16x3: kernel %dx%d unsupported", d->kh, d->kw);
+    CCVS_REQUIRE(d->CoutPad % 32 == 0 && d->CoutPad >= d->Cout, "ccvs_conv2d_bf16x3: CoutPad %d invalid for Cout %d", d->CoutPad, d->Cout);
+    int Hout, Wout;
+    if (d->transposed) {
+        CCVS_REQUIRE(d->kh == 3 && d->stride == 2 && d->pad == 0, "ccvs_conv2d_bf16x3: transposed supports k3 s2 p0 only");
+        Hout = 2 * d->Hin + d->kh - 2;
+        Wout = 2 * d->Win + d->kw - 2;
+    } else {
+        CCVS_REQUIRE(d->stride == 1 || d->stride == 2, "ccvs_conv2d_bf16x3: stride %d unsupported", d->stride);
+        Hout = (d->Hin + 2 * d->pad - d->kh) / d->stride + 1;
+        Wout = (d->Win + 2 * d->pad - d->kw) / d->stride + 1;
+    }
+    CCVS_REQUIRE(Hout == d->Hout && Wout == d->Wout, "ccvs_conv2d_bf16x3: output %dx%d expected, got %dx%d", Hout, Wout, d->Hout, d->Wout);
+
+    ConvK k;
+    k.x = x; k.w = nullptr; k.bias = bias; k.res = residual; k.y = y;
+    k.N = d->N; k.Cin = d->Cin; k.Hin = d->Hin; k.Win = d->Win; k.in_sN = d->in_sN; k.in_sC = d->in_sC;
+    k.Cout = d->Cout; k.CoutPad = d->CoutPad; k.Hout = d->Hout; k.Wout = d->Wout;
+    k.out_sN = d->out_sN; k.out_sC = d->out_sC; k.res_sN = d->res_sN; k.res_sC = d->res_sC;
+    k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad; k.transposed = d->transposed ? 1 : 0;
+    k.act = d->act; k.accumulate = d->accumulate; k.out_scale = d->out_scale;
+    const int CinG = 2 * ((d->Cin + 15) / 16);  // 8-channel groups, Cin padded to 16
+
+    const int VH = d->transposed ? (Hout + 1) / 2 : Hout;
+    const int VW = d->transposed ? (Wout + 1) / 2 : Wout;
+    const int TW = VW > 16 ? 32 : (VW > 8 ? 16 : 8);
+    const int TH = 256 / TW;
+    k.tiles_x = cdiv(VW, TW);
+    k.tiles_y = cdiv(VH, TH);
+    const int s = d->transposed ? 1 : d->stride;
+    const int ext = d->transposed ? 1 : d->kh - 1;
+    const int ntx_max = d->transposed ? 2 : d->kw;
+    const int halo_h = (TH - 1) * s + ext + 1, halo_w = (TW - 1) * s + ext + 1;
+    const int gz = d->N * (d->transposed ? 4 : 1);
+    CCVS_REQUIRE(gz <= 65535, "ccvs_conv2d_bf16x3: batch %d too large for one launch", d->N);
+    hipStream_t st = (hipStream_t)stream;
+    const int mb = (d->CoutPad % 128 == 0) ? 4 : ((d->CoutPad % 64 == 0) ? 2 : 1);
+#define CB_DISPATCH(TWv)                                                                                        \
+    if (mb == 4) return launch_conv_bf16<TWv, 4>(k, w_split, CinG, halo_h, halo_w, ntx_max, gz, st);           \
+    if (mb == 2) return launch_conv_bf16<TWv, 2>(k, w_split, CinG, halo_h, halo_w, ntx_max, gz, st);           \
+    return launch_conv_bf16<TWv, 1>(k, w_split, CinG, halo_h, halo_w, ntx_max, gz, st);
+    if (TW == 32) { CB_DISPATCH(32) }
+    if (TW == 16) { CB_DISPATCH(16) }
+    CB_DISPATCH(8)
+#undef CB_DISPATCH
+}

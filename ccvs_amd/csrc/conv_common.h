@@ -1,0 +1,47 @@
+// Shared by the fp32-MFMA and the split-bf16 convolution kernels: the kernel argument block and the
+// per-axis tap table that turns padding, stride and the stride-2 transposed form into one loop.
+#pragma once
+#include "common.h"
+
+struct ConvK {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* res;
+    float* y;
+    int N, Cin, Hin, Win;
+    long in_sN, in_sC;
+    int Cout, CoutPad, Hout, Wout;
+    long out_sN, out_sC, res_sN, res_sC;
+    int kh, kw, stride, pad, transposed;
+    int act, accumulate;
+    float out_scale;
+    int tiles_x, tiles_y;
+};
+
+struct AxisTaps {
+    int nt;       // number of taps along this axis
+    int d0, dd;   // input offset of tap a: d0 + a*dd
+    int w0, dw;   // weight index of tap a along this axis: w0 + a*dw
+    int s;        // virtual -> input stride
+    int os, oo;   // virtual -> output: o = v*os + oo
+    int V;        // virtual extent
+    int lo, ext;  // min offset, halo extent (hi - lo)
+};
+
+__device__ __forceinline__ AxisTaps axis_taps(int k, int stride, int pad, int transposed, int parity, int out_extent) {
+    AxisTaps t;
+    if (transposed) {
+        // conv_transpose2d stride 2 pad 0:  o = 2*i + kk.  Output parity class `parity`
+        // uses taps kk = parity, parity+2, ... reading input i = v - a.
+        t.nt = (k - parity + 1) / 2;
+        t.d0 = 0; t.dd = -1; t.w0 = parity; t.dw = 2; t.s = 1; t.os = 2; t.oo = parity;
+        t.V = (out_extent - parity + 1) / 2;
+        t.lo = -(t.nt - 1); t.ext = t.nt - 1;
+    } else {
+        t.nt = k; t.d0 = -pad; t.dd = 1; t.w0 = 0; t.dw = 1; t.s = stride; t.os = 1; t.oo = 0;
+        t.V = out_extent; t.lo = -pad; t.ext = k - 1;
+    }
+    return t;
+}
+

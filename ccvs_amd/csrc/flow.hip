@@ -39,14 +39,18 @@ __global__ __launch_bounds__(256) void correlation7x7_kernel(const float* __rest
             const int r = e / IW, c = e - r * IW;
             const int gy = iy0 + r, gx = ix0 + c;
             const bool ok = (gy >= 0 && gy < H && gx >= 0 && gx < W);
+            const long o = ok ? (long)gy * W + gx : 0;  // unconditional loads from a clamped address
 #pragma unroll
-            for (int cc = 0; cc < CORR_CC; ++cc)
-                bt[cc][e] = (ok && c0 + cc < C) ? B[(long)(c0 + cc) * H * W + (long)gy * W + gx] : 0.f;
+            for (int cc = 0; cc < CORR_CC; ++cc) {
+                const float t = B[(long)min(c0 + cc, C - 1) * H * W + o];
+                bt[cc][e] = (ok && c0 + cc < C) ? t : 0.f;
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int cc = 0; cc < CORR_CC; ++cc) {
-            const float a = (live && c0 + cc < C) ? A[(long)(c0 + cc) * H * W + (long)(oy * S) * W + ox * S] : 0.f;
+            const float ta = A[(long)min(c0 + cc, C - 1) * H * W + (live ? (long)(oy * S) * W + ox * S : 0)];
+            const float a = (live && c0 + cc < C) ? ta : 0.f;
             const float* bp = &bt[cc][(py * S) * IW + px * S];
 #pragma unroll
             for (int dy = 0; dy < 7; ++dy)
@@ -90,7 +94,7 @@ extern "C" int ccvs_correlation7x7(const float* first, const float* second, floa
 // reference's arithmetic: g = (2x+1)/W - 1 + f / ((W-1)/2);  ix = ((g+1)*W - 1)/2.
 // ---------------------------------------------------------------------------------------
 struct Bilin {
-    int o00, o01, o10, o11;  // plane offsets, -1 when outside
+    int o00, o01, o10, o11;  // plane offsets (clamped to 0 when outside, weight then 0)
     float w00, w01, w10, w11;
 };
 
@@ -107,20 +111,17 @@ __device__ __forceinline__ Bilin bilin_setup(int x, int y, float fx, float fy, i
     const float xc = fminf(fmaxf(x0f, -2.f), (float)W + 1.f), yc = fminf(fmaxf(y0f, -2.f), (float)H + 1.f);
     const int x0 = (int)xc, y0 = (int)yc, x1 = x0 + 1, y1 = y0 + 1;
     const bool vx0 = (x0 >= 0 && x0 < W), vx1 = (x1 >= 0 && x1 < W), vy0 = (y0 >= 0 && y0 < H), vy1 = (y1 >= 0 && y1 < H);
-    b.o00 = (vx0 && vy0) ? y0 * W + x0 : -1;
-    b.o01 = (vx1 && vy0) ? y0 * W + x1 : -1;
-    b.o10 = (vx0 && vy1) ? y1 * W + x0 : -1;
-    b.o11 = (vx1 && vy1) ? y1 * W + x1 : -1;
+    // corners outside the image: weight 0 and a clamped (valid) offset, so that the four loads of a
+    // sample are unconditional (predicated loads in the channel loop would serialise)
+    b.o00 = (vx0 && vy0) ? y0 * W + x0 : 0;  if (!(vx0 && vy0)) b.w00 = 0.f;
+    b.o01 = (vx1 && vy0) ? y0 * W + x1 : 0;  if (!(vx1 && vy0)) b.w01 = 0.f;
+    b.o10 = (vx0 && vy1) ? y1 * W + x0 : 0;  if (!(vx0 && vy1)) b.w10 = 0.f;
+    b.o11 = (vx1 && vy1) ? y1 * W + x1 : 0;  if (!(vx1 && vy1)) b.w11 = 0.f;
     return b;
 }
 
 __device__ __forceinline__ float bilin_sample(const float* __restrict__ plane, const Bilin& b) {
-    float v = 0.f;
-    if (b.o00 >= 0) v += plane[b.o00] * b.w00;
-    if (b.o01 >= 0) v += plane[b.o01] * b.w01;
-    if (b.o10 >= 0) v += plane[b.o10] * b.w10;
-    if (b.o11 >= 0) v += plane[b.o11] * b.w11;
-    return v;
+    return ((plane[b.o00] * b.w00 + plane[b.o01] * b.w01) + plane[b.o10] * b.w10) + plane[b.o11] * b.w11;
 }
 
 #define WARP_CCH 16  // channels per thread

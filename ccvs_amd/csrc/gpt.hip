@@ -110,13 +110,15 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
     if (wave < p.ks) {
         const float* wp = p.w + (long)nrow * p.K + wave * kper + 4 * g;
         const float* xp = p.x + (long)mrow * p.ldx + wave * kper + 4 * g;
-        for (int k0 = 0; k0 < kper; k0 += 16 * GEMM_U) {
+        // full batches: GEMM_U unconditional float4 loads of W and of x in flight per lane (no
+        // predicated loads -- hipcc would serialise them), then the MFMAs
+        int k0 = 0;
+        for (; k0 + 16 * GEMM_U <= kper; k0 += 16 * GEMM_U) {
             float4 wv[GEMM_U], xv[GEMM_U];
 #pragma unroll
             for (int u = 0; u < GEMM_U; ++u) {
-                const bool ok = k0 + 16 * u < kper;
-                wv[u] = ok ? *reinterpret_cast<const float4*>(wp + k0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
-                xv[u] = ok ? *reinterpret_cast<const float4*>(xp + k0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+                wv[u] = *reinterpret_cast<const float4*>(wp + k0 + 16 * u);
+                xv[u] = *reinterpret_cast<const float4*>(xp + k0 + 16 * u);
             }
 #pragma unroll
             for (int u = 0; u < GEMM_U; ++u) {
@@ -128,6 +130,18 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
                     sx += (xv[u].x + xv[u].y) + (xv[u].z + xv[u].w);
                     sxx += (xv[u].x * xv[u].x + xv[u].y * xv[u].y) + (xv[u].z * xv[u].z + xv[u].w * xv[u].w);
                 }
+            }
+        }
+        for (; k0 < kper; k0 += 16) {  // remainder (small K only)
+            const float4 wv = *reinterpret_cast<const float4*>(wp + k0);
+            const float4 xv = *reinterpret_cast<const float4*>(xp + k0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.x, wv.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.y, wv.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.z, wv.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.w, wv.w, acc1, 0, 0, 0);
+            if (p.ln_s) {
+                sx += (xv.x + xv.y) + (xv.z + xv.w);
+                sxx += (xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w);
             }
         }
     }
@@ -350,11 +364,9 @@ __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __re
 #pragma unroll 4
     for (int j0 = wave * KPI; j0 < L; j0 += NW * KPI) {
         const int j = j0 + kk;
-        float s = 0.f;
-        if (j < L) {
-            const float4 kv = *reinterpret_cast<const float4*>(kbase + (long)j * D);
-            s = kv.x * qv.x + kv.y * qv.y + kv.z * qv.z + kv.w * qv.w;
-        }
+        // unconditional load from a clamped row (predicated loads in an unrolled loop serialise)
+        const float4 kv = *reinterpret_cast<const float4*>(kbase + (long)min(j, L - 1) * D);
+        float s = kv.x * qv.x + kv.y * qv.y + kv.z * qv.z + kv.w * qv.w;
 #pragma unroll
         for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
         s *= scale;
@@ -387,11 +399,10 @@ __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __re
 #pragma unroll 4
     for (int j0 = wave * KPI; j0 < L; j0 += NW * KPI) {
         const int j = j0 + kk;
-        if (j < L) {
-            const float p = ps[j];
-            const float4 vv = *reinterpret_cast<const float4*>(vbase + (long)j * D);
-            acc.x += p * vv.x; acc.y += p * vv.y; acc.z += p * vv.z; acc.w += p * vv.w;
-        }
+        const int jc = min(j, L - 1);
+        const float p = (j < L) ? ps[jc] : 0.f;
+        const float4 vv = *reinterpret_cast<const float4*>(vbase + (long)jc * D);
+        acc.x += p * vv.x; acc.y += p * vv.y; acc.z += p * vv.z; acc.w += p * vv.w;
     }
     *reinterpret_cast<float4*>(pv + (wave * 64 + lane) * 4) = acc;
     __syncthreads();

@@ -68,10 +68,12 @@ __global__ __launch_bounds__(256) void blur4x4_kernel(FirK p) {
             const int iy = oy + ky - p.pad0;
             float r[7];
             const bool rowok = (iy >= 0 && iy < p.H);
+            const long rowoff = (long)min(max(iy, 0), p.H - 1) * p.W;
 #pragma unroll
-            for (int c = 0; c < 7; ++c) {
+            for (int c = 0; c < 7; ++c) {  // unconditional loads from clamped addresses, zeroed afterwards
                 const int ix = ox0 + c - p.pad0;
-                r[c] = (rowok && ix >= 0 && ix < p.W) ? xp[(long)iy * p.W + ix] : 0.f;
+                const float t = xp[rowoff + min(max(ix, 0), p.W - 1)];
+                r[c] = (rowok && ix >= 0 && ix < p.W) ? t : 0.f;
             }
 #pragma unroll
             for (int o = 0; o < 4; ++o) h[ky][o] = (r[o] + r[o + 3]) + 3.f * (r[o + 1] + r[o + 2]);

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libccvs_hip.so")
 
 # every symbol include/ccvs_hip.h declares
 EXPORTS = [
-    "ccvs_last_error", "ccvs_abi_version", "ccvs_conv2d", "ccvs_upfirdn2d", "ccvs_dwconvT4x4s2",
+    "ccvs_last_error", "ccvs_abi_version", "ccvs_conv2d", "ccvs_conv2d_bf16x3", "ccvs_upfirdn2d", "ccvs_dwconvT4x4s2",
     "ccvs_correlation7x7", "ccvs_backwarp", "ccvs_warp_fuse_blend", "ccvs_vq_argmin", "ccvs_embed_gather",
     "ccvs_gpt_embed", "ccvs_layernorm", "ccvs_gemm_nt", "ccvs_gemm_ln", "ccvs_gemm_ln_qkv", "ccvs_attention", "ccvs_kv_append", "ccvs_sample_topk",
     "ccvs_pack_u8",
@@ -53,6 +53,7 @@ def load():
     lib.ccvs_abi_version.restype = C.c_int
     sigs = {
         "ccvs_conv2d": [vp, vp, vp, vp, vp, C.POINTER(ConvDesc), vp],
+        "ccvs_conv2d_bf16x3": [vp, vp, vp, vp, vp, C.POINTER(ConvDesc), vp],
         "ccvs_upfirdn2d": [vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, i32, f32, vp],
         "ccvs_dwconvT4x4s2": [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp],
         "ccvs_correlation7x7": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],

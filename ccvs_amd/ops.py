@@ -66,24 +66,53 @@ def _as_rows_dense(t):
 
 
 # ------------------------------------------------------------------ convolution
-def pack_conv_weight(weight):
-    """[Cout,Cin,k,k] parameter -> [k*k][Cin][CoutPad] with the EqualConv2d scale
-    1/sqrt(Cin*k*k) multiplied in (skip_autoencoder.py:44,55,58)."""
+# Arithmetic of the convolution kernels:
+#   "bf16x3": split-bf16, 3 products per fp32 product on v_mfma_f32_32x32x16_bf16 (default)
+#   "f32"   : exact fp32 on v_mfma_f32_32x32x2_f32
+CONV_PRECISION = "bf16x3"
+
+
+class PackedConv:
+    """Kernel-ready weights of one convolution (built once per parameter version)."""
+    __slots__ = ("kind", "data", "cin", "cout", "cout_pad", "k")
+
+    def __init__(self, kind, data, cin, cout, cout_pad, k):
+        self.kind, self.data, self.cin, self.cout, self.cout_pad, self.k = kind, data, cin, cout, cout_pad, k
+
+
+def pack_conv_weight(weight, precision=None):
+    """[Cout,Cin,k,k] parameter -> PackedConv, with the EqualConv2d scale 1/sqrt(Cin*k*k) multiplied in
+    first (the same fp32 product as `weight * scale`, skip_autoencoder.py:44,55,58).
+      f32   : [k*k][Cin][CoutPad] fp32
+      bf16x3: [k*k][CinPad/8][hi|lo][CoutPad][8] bf16, w = hi + lo (both round-to-nearest-even)"""
+    precision = precision or CONV_PRECISION
     cout, cin, kh, kw = weight.shape
     scale = 1 / math.sqrt(cin * kh * kw)
-    cpad = -(-cout // 64) * 64 if cout >= 64 else 32 * (-(-cout // 32))
     w = (weight.detach().float() * scale).permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
-    out = torch.zeros(kh * kw, cin, cpad, dtype=torch.float32, device=weight.device)
-    out[:, :, :cout] = w
-    return out.contiguous()
+    if precision == "f32":
+        cpad = -(-cout // 64) * 64 if cout >= 64 else 32 * (-(-cout // 32))
+        out = torch.zeros(kh * kw, cin, cpad, dtype=torch.float32, device=weight.device)
+        out[:, :, :cout] = w
+        return PackedConv("f32", out.contiguous(), cin, cout, cpad, kh)
+    if precision != "bf16x3":
+        raise ValueError(f"unknown conv precision {precision!r}")
+    cpad = 32 * (-(-cout // 32))
+    cinp = 16 * (-(-cin // 16))
+    full = torch.zeros(kh * kw, cinp, cpad, dtype=torch.float32, device=weight.device)
+    full[:, :cin, :cout] = w
+    hi = full.to(torch.bfloat16)
+    lo = (full - hi.float()).to(torch.bfloat16)
+    lay = lambda t: t.view(kh * kw, cinp // 8, 8, cpad).permute(0, 1, 3, 2)
+    out = torch.stack([lay(hi), lay(lo)], dim=2).contiguous()  # [tap][cg][2][cpad][8]
+    return PackedConv("bf16x3", out, cin, cout, cpad, kh)
 
 
 def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=False, residual=None,
            out_scale=1.0, out=None, accumulate=False):
-    _need_gpu(x, w_packed, bias, residual, out)
+    _need_gpu(x, w_packed.data, bias, residual, out)
     x = _as_rows_dense(x)
     n, cin, h, w = x.shape
-    assert w_packed.shape[0] == k * k and w_packed.shape[1] == cin, (w_packed.shape, k, cin)
+    assert w_packed.k == k and w_packed.cin == cin and w_packed.cout == cout, (w_packed.k, w_packed.cin, w_packed.cout, k, cin, cout)
     if transposed:
         ho, wo = 2 * h + k - 2, 2 * w + k - 2
     else:
@@ -94,7 +123,7 @@ def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=Fa
     d = _lib.ConvDesc()
     d.N, d.Cin, d.Hin, d.Win = n, cin, h, w
     d.in_sN, d.in_sC = x.stride(0), x.stride(1)
-    d.Cout, d.CoutPad, d.Hout, d.Wout = cout, w_packed.shape[2], ho, wo
+    d.Cout, d.CoutPad, d.Hout, d.Wout = cout, w_packed.cout_pad, ho, wo
     d.out_sN, d.out_sC = out.stride(0), out.stride(1)
     if residual is not None:
         residual = _as_rows_dense(residual)
@@ -109,8 +138,9 @@ def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=Fa
     prof = KERNEL_TIMER
     if prof is not None:
         macs = n * cout * cin * k * k * (h * w if transposed else ho * wo)
-        prof.begin("conv2d_mfma", flops=2.0 * macs)
-    _lib.check(L.ccvs_conv2d(_p(x), _p(w_packed), _p(bias), _p(residual), _p(out), C.byref(d), _stream()), "ccvs_conv2d")
+        prof.begin("conv2d_" + w_packed.kind, flops=2.0 * macs)
+    fn = L.ccvs_conv2d if w_packed.kind == "f32" else L.ccvs_conv2d_bf16x3
+    _lib.check(fn(_p(x), _p(w_packed.data), _p(bias), _p(residual), _p(out), C.byref(d), _stream()), "ccvs_conv2d[" + w_packed.kind + "]")
     if prof is not None:
         prof.end()
     return out

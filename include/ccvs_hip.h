@@ -64,6 +64,14 @@ typedef struct ccvs_conv_desc {
 int ccvs_conv2d(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
                 const ccvs_conv_desc* d, void* stream);
 
+/* Same contract as ccvs_conv2d on the bf16 matrix cores with fp32-class accuracy: every fp32
+ * operand is split v = hi + lo (bf16, round-to-nearest-even) and a product is evaluated as
+ * hi*hi + hi*lo + lo*hi with fp32 accumulation (per-product error ~2^-16 relative).
+ * w_split: [kh*kw][CinPad/8][2 = hi,lo][CoutPad][8] bf16, scale multiplied in before the split,
+ *          CinPad = Cin rounded up to 16, CoutPad = Cout rounded up to 32, padding zero. */
+int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const float* bias, const float* residual, float* y,
+                       const ccvs_conv_desc* d, void* stream);
+
 /* ---- FIR resampling ------------------------------------------------------------------
  * Replaces upfirdn2d(input, kernel, up, down, pad) (modules/upfirdn2d.py:145-159, CUDA
  * upfirdn2d_kernel.cu:107-207, pybind upfirdn2d.cpp:21-23) for the 4-tap separable

@@ -121,6 +121,22 @@ def test_conv_oracle_shapes(ops, cin, cout, k, stride, hw):
     close(got, want)
 
 
+def test_conv_fp32_mfma_variant(ops):
+    """The exact-fp32 kernel (v_mfma_f32_32x32x2_f32) stays available next to the split-bf16 default."""
+    torch.manual_seed(11)
+    for cin, cout, k, stride, tr, hw in [(49, 128, 3, 1, False, (40, 72)), (32, 3, 9, 1, False, (20, 33)), (16, 70, 3, 2, False, (35, 37)),
+                                         (7, 70, 3, 2, True, (17, 33))]:
+        x, w, b = torch.randn(2, cin, *hw), torch.randn(cout, cin, k, k), torch.randn(cout)
+        pad = 0 if (tr or stride == 2) else k // 2
+        want = O.equal_conv2d(x, w, b, stride=stride, padding=pad, transpose=tr)
+        got = ops.conv2d(x.cuda(), ops.pack_conv_weight(w.cuda(), "f32"), b.cuda(), cout, k, stride=stride, pad=pad, transposed=tr)
+        close(got, want, 1e-4)
+        got3 = ops.conv2d(x.cuda(), ops.pack_conv_weight(w.cuda(), "bf16x3"), b.cuda(), cout, k, stride=stride, pad=pad, transposed=tr)
+        close(got3, want, 1e-4)
+        # the split-bf16 result sits within ~1e-5 relative of the exact-fp32 kernel
+        assert (got3 - got).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
 def test_conv_transposed_oracle(ops):
     torch.manual_seed(5)
     for cin, cout, hw in [(16, 24, (8, 8)), (7, 70, (17, 33)), (32, 32, (1, 1))]:
