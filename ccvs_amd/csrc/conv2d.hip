@@ -177,7 +177,7 @@ extern "C" int ccvs_conv2d(const float* x, const float* w_packed, const float* b
                            const ccvs_conv_desc* d, void* stream) {
     CCVS_REQUIRE(x && w_packed && y && d, "ccvs_conv2d: null pointer");
     CCVS_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->Hin > 0 && d->Win > 0, "ccvs_conv2d: empty tensor");
-    CCVS_REQUIRE(d->kh == d->kw && d->kh >= 1 && d->kh <= 9, "ccvs_conv2d: kernel %dx%d unsupported", d->kh, d->kw);
+    CCVS_REQUIRE((d->kh == d->kw || d->kw == 1) && d->kh >= 1 && d->kh <= 9, "ccvs_conv2d: kernel %dx%d unsupported", d->kh, d->kw);
     CCVS_REQUIRE(d->CoutPad % 32 == 0 && d->CoutPad >= d->Cout, "ccvs_conv2d: CoutPad %d invalid for Cout %d", d->CoutPad, d->Cout);
     int Hout, Wout;
     if (d->transposed) {
@@ -207,9 +207,9 @@ extern "C" int ccvs_conv2d(const float* x, const float* w_packed, const float* b
     k.tiles_x = cdiv(VW, TW);
     k.tiles_y = cdiv(VH, TH);
     const int s = d->transposed ? 1 : d->stride;
-    const int ext = d->transposed ? 1 : d->kh - 1;
+    const int ext_y = d->transposed ? 1 : d->kh - 1, ext_x = d->transposed ? 1 : d->kw - 1;
     const int ntx_max = d->transposed ? 2 : d->kw;
-    const int halo_h = (TH - 1) * s + ext + 1, halo_w = (TW - 1) * s + ext + 1;
+    const int halo_h = (TH - 1) * s + ext_y + 1, halo_w = (TW - 1) * s + ext_x + 1;
     const int gz = d->N * (d->transposed ? 4 : 1);
     CCVS_REQUIRE(gz <= 65535, "ccvs_conv2d: batch %d too large for one launch", d->N);
     hipStream_t st = (hipStream_t)stream;

@@ -413,6 +413,68 @@ __global__ __launch_bounds__(512, 2) void conv2d_bf16x3_pc_kernel(ConvK p, const
         __syncthreads();
         if (++a == nt) { a = 0; ++ci; }
     }
+    // ---- epilogue ------------------------------------------------------------------------------
+    // Dense convolutions: the accumulators (one pixel column per lane, 16 couts in registers) go
+    // through LDS so that ALL 8 waves write 16-byte pieces along x (a lane then owns 4 consecutive
+    // pixels of one channel) instead of 128 scalar stores per consumer lane: the store tail was
+    // issue-bound.  32 couts x 256 pixels per pass, MB passes.
+    if (!p.transposed) {
+        float* stage = reinterpret_cast<float*>(smem4);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (!producer) {
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * 256 + (rw * 2 + pp) * 32 + (lane & 31)] = acc[m][pp][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx4 = tid + 512 * i;
+                const int col = idx4 >> 6, px = (idx4 & 63) * 4;
+                const int co = n0 + m * 32 + col;
+                const int prow = px / TW, pcol = px - prow * TW;
+                const int vy = ty * TH + prow, vx = tx * TW + pcol;
+                if (co < p.Cout && vy < ay.V && vx < ax.V) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(stage + col * 256 + px);
+                    float v[4] = {a4.x, a4.y, a4.z, a4.w};
+                    const float bv = p.bias ? p.bias[co] : 0.f;
+                    const long opix = (long)vy * p.Wout + vx;
+                    float* dst = p.y + (long)n * p.out_sN + (long)co * p.out_sC + opix;
+                    const float* rsrc = p.res ? p.res + (long)n * p.res_sN + (long)co * p.res_sC + opix : nullptr;
+                    const int nv = min(4, ax.V - vx);
+                    const bool vec = (nv == 4) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) &&
+                                     (!rsrc || (reinterpret_cast<uintptr_t>(rsrc) & 15) == 0);
+                    float rv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (vec) {
+                        if (rsrc) { const float4 t = *reinterpret_cast<const float4*>(rsrc); rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
+                        if (p.accumulate) { const float4 t = *reinterpret_cast<const float4*>(dst); ov[0] = t.x; ov[1] = t.y; ov[2] = t.z; ov[3] = t.w; }
+                    } else {
+                        for (int j = 0; j < nv; ++j) {
+                            if (rsrc) rv[j] = rsrc[j];
+                            if (p.accumulate) ov[j] = dst[j];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = v[j] + bv;
+                        if (p.act == CCVS_ACT_LRELU) t = lrelu01(t);
+                        t = (t + rv[j]) * p.out_scale;
+                        v[j] = t + ov[j];
+                    }
+                    if (vec) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        for (int j = 0; j < nv; ++j) dst[j] = v[j];
+                    }
+                }
+            }
+            if (m + 1 < MB) __syncthreads();
+        }
+        return;
+    }
     if (producer) return;
 
 #pragma unroll
@@ -483,7 +545,7 @@ extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const flo
                                   const ccvs_conv_desc* d, void* stream) {
     CCVS_REQUIRE(x && w_split && y && d, "ccvs_conv2d_bf16x3: null pointer");
     CCVS_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->Hin > 0 && d->Win > 0, "ccvs_conv2d_bf16x3: empty tensor");
-    CCVS_REQUIRE(d->kh == d->kw && d->kh >= 1 && d->kh <= 9, "ccvs_conv2d_bf16x3: kernel %dx%d unsupported", d->kh, d->kw);
+    CCVS_REQUIRE((d->kh == d->kw || d->kw == 1) && d->kh >= 1 && d->kh <= 9, "ccvs_conv2d_bf16x3: kernel %dx%d unsupported", d->kh, d->kw);
     CCVS_REQUIRE(d->CoutPad % 32 == 0 && d->CoutPad >= d->Cout, "ccvs_conv2d_bf16x3: CoutPad %d invalid for Cout %d", d->CoutPad, d->Cout);
     int Hout, Wout;
     if (d->transposed) {
@@ -513,9 +575,9 @@ extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const flo
     k.tiles_x = cdiv(VW, TW);
     k.tiles_y = cdiv(VH, TH);
     const int s = d->transposed ? 1 : d->stride;
-    const int ext = d->transposed ? 1 : d->kh - 1;
+    const int ext_y = d->transposed ? 1 : d->kh - 1, ext_x = d->transposed ? 1 : d->kw - 1;
     const int ntx_max = d->transposed ? 2 : d->kw;
-    const int halo_h = (TH - 1) * s + ext + 1, halo_w = (TW - 1) * s + ext + 1;
+    const int halo_h = (TH - 1) * s + ext_y + 1, halo_w = (TW - 1) * s + ext_x + 1;
     const int gz = d->N * (d->transposed ? 4 : 1);
     CCVS_REQUIRE(gz <= 65535, "ccvs_conv2d_bf16x3: batch %d too large for one launch", d->N);
     hipStream_t st = (hipStream_t)stream;

@@ -210,3 +210,42 @@ extern "C" int ccvs_warp_fuse_blend(float* dec, int64_t dec_sN, int64_t dec_sC, 
     CCVS_CHECK_LAUNCH("ccvs_warp_fuse_blend");
     return CCVS_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------
+// Second half of the flow / occlusion heads (skip_autoencoder.py:176-177,204-205,225-226).
+// A k x k convolution with only 3 outputs would use 3 of the 32 rows of an MFMA tile.  The heads
+// are therefore run as a k x 1 convolution with 3k outputs, T[kx*3+co] = sum_{c,ky} W[co][c][ky][kx] * X
+// on a map widened by the horizontal padding (one MFMA row per (kx, co): 27 of 32 rows busy for the
+// 9x9 heads), and this kernel applies the horizontal taps:
+//   y[n][co][yy][x] (+)= bias[co] + sum_kx T[n][kx*3+co][yy][x + kx]          (T width = W + k - 1)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tap_shift_add_kernel(const float* __restrict__ t, const float* __restrict__ bias,
+                                                            float* __restrict__ y, long y_sN, long total, int k, int H, int W,
+                                                            int accumulate) {
+    const int Wt = W + k - 1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % W);
+        long r = i / W;
+        const int yy = (int)(r % H);
+        r /= H;
+        const int co = (int)(r % 3);
+        const long n = r / 3;
+        const float* tp = t + ((n * 3 * k + co) * H + yy) * (long)Wt + x;
+        float acc = bias ? bias[co] : 0.f;
+        for (int kx = 0; kx < k; ++kx) acc += tp[(long)kx * 3 * H * Wt + kx];
+        float* dst = y + n * y_sN + ((long)co * H + yy) * W + x;
+        *dst = accumulate ? *dst + acc : acc;
+    }
+}
+
+extern "C" int ccvs_tap_shift_add(const float* t, const float* bias, float* y, int64_t y_sN, int32_t N, int32_t k, int32_t H, int32_t W,
+                                  int32_t accumulate, void* stream) {
+    CCVS_REQUIRE(t && y, "ccvs_tap_shift_add: null pointer");
+    CCVS_REQUIRE(N > 0 && k >= 1 && k <= 9 && H > 0 && W > 0, "ccvs_tap_shift_add: bad shape");
+    const long total = (long)N * 3 * H * W;
+    const int blocks = (int)(cdiv64(total, 256) < 65536 * 16 ? cdiv64(total, 256) : 65536 * 16);
+    hipLaunchKernelGGL(tap_shift_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, bias, y, (long)y_sN, total, k, H, W, accumulate);
+    CCVS_CHECK_LAUNCH("ccvs_tap_shift_add");
+    return CCVS_OK;
+}

@@ -92,9 +92,13 @@ struct Gemm16 {
     int M, N, K, epi, ks;
     const float* ln_s; float ln_eps;
     float* kcache; float* vcache; int C, H, D, Tq, Tmax, pos0; const int32_t* pos_dev;
+    int kz;            // K slices across workgroups (gridDim.z); > 1 only with a workspace
+    float* ws_slabs;   // [tile][kz][64 lanes][4] partial accumulators
+    int* ws_count;     // [tile] arrival counters, zero between launches
 };
 
 #define GEMM_U 8  // K steps (of 16) whose loads are issued together
+#define GEMM_WS_TILES 128  // output tiles a workspace covers (split-K is only used when tiles <= this)
 
 __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
     __shared__ __attribute__((aligned(16))) float red[7 * 64 * 4];
@@ -104,12 +108,13 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
     const int li = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.y * 16, ncol0 = blockIdx.x * 16;
     const int nrow = min(ncol0 + li, p.N - 1), mrow = min(m0 + li, p.M - 1);  // tails: computed on a valid row, dropped at the store
-    const int kper = p.K / p.ks;
+    const int kper = p.K / (p.ks * p.kz);
+    const int kbase = blockIdx.z * (p.K / p.kz);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float sx = 0.f, sxx = 0.f;
     if (wave < p.ks) {
-        const float* wp = p.w + (long)nrow * p.K + wave * kper + 4 * g;
-        const float* xp = p.x + (long)mrow * p.ldx + wave * kper + 4 * g;
+        const float* wp = p.w + (long)nrow * p.K + kbase + wave * kper + 4 * g;
+        const float* xp = p.x + (long)mrow * p.ldx + kbase + wave * kper + 4 * g;
         // full batches: GEMM_U unconditional float4 loads of W and of x in flight per lane (no
         // predicated loads -- hipcc would serialise them), then the MFMAs
         int k0 = 0;
@@ -166,6 +171,29 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
 #pragma unroll
     for (int s = 0; s < 7; ++s) acc += *reinterpret_cast<const f32x4*>(red + (s * 64 + lane) * 4);
 
+    if (p.kz > 1) {
+        // K is also split over gridDim.z workgroups (few output columns: keeps all 256 CUs streaming W).
+        // Each publishes its 16x16 partial, the LAST arriver sums the slabs in slice order (bitwise
+        // reproducible) and runs the epilogue.  One wave does all of it: slab stores -> vmcnt(0) ->
+        // agent release -> ticket; the reducer: agent acquire -> plain loads (cdna_hip_programming.md
+        // section 6 Guideline 16, counter form).  The reducer re-zeroes the counter for the next launch.
+        const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+        float* slabs = p.ws_slabs + (long)tile * p.kz * 256;
+        *reinterpret_cast<f32x4*>(slabs + (blockIdx.z * 64 + lane) * 4) = acc;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(p.ws_count + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != p.kz - 1) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        acc = *reinterpret_cast<const f32x4*>(slabs + lane * 4);
+        for (int z = 1; z < p.kz; ++z) acc += *reinterpret_cast<const f32x4*>(slabs + (z * 64 + lane) * 4);
+        if (lane == 0) __hip_atomic_store(p.ws_count + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
     // D[row = 4*g + r][col = li]
     const int col = ncol0 + li;
     if (col >= p.N) return;
@@ -200,17 +228,29 @@ static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
     if (!(g.M > 0 && g.N > 0 && g.K > 0)) { ccvs_set_error("%s: empty tensor", name); return CCVS_ERR_ARG; }
     if (g.K % 16 != 0 || g.ldx % 4 != 0) { ccvs_set_error("%s: K=%d must be a multiple of 16 (ldx %% 4 == 0)", name, g.K); return CCVS_ERR_ARG; }
     if (g.epi < 0 || g.epi > 2 || (g.epi == 2 && !g.res)) { ccvs_set_error("%s: bad epilogue", name); return CCVS_ERR_ARG; }
+    const int tiles = cdiv(g.N, 16) * cdiv(g.M, 16);
+    g.kz = 1;
+    if (g.ws_slabs && !g.ln_s) {  // spread small-N GEMMs over the chip: K slices across workgroups
+        // (pays only for deep K: the release/acquire hand-off costs ~3 us, measured)
+        while (g.K >= 2048 && g.kz < 4 && tiles * g.kz * 2 <= 256 && g.K % (16 * 8 * g.kz * 2) == 0 && tiles <= GEMM_WS_TILES) g.kz *= 2;
+    }
     g.ks = 8;
-    while (g.ks > 1 && g.K % (16 * g.ks) != 0) g.ks >>= 1;
-    hipLaunchKernelGGL(gemm16_kernel, dim3(cdiv(g.N, 16), cdiv(g.M, 16)), dim3(512), 0, st, g);
+    while (g.ks > 1 && g.K % (16 * g.ks * g.kz) != 0) g.ks >>= 1;
+    hipLaunchKernelGGL(gemm16_kernel, dim3(cdiv(g.N, 16), cdiv(g.M, 16), g.kz), dim3(512), 0, st, g);
     CCVS_CHECK_LAUNCH(name);
     return CCVS_OK;
 }
 
+extern "C" int64_t ccvs_gemm_workspace_bytes(void) { return (int64_t)GEMM_WS_TILES * (4 * 256 * sizeof(float) + sizeof(int)); }
+
 extern "C" int ccvs_gemm_nt(const float* x, int64_t ldx, const float* w, const float* bias, const float* res, float* y, int64_t ldy,
-                            int32_t M, int32_t N, int32_t K, int32_t epilogue, void* stream) {
+                            int32_t M, int32_t N, int32_t K, int32_t epilogue, void* workspace, void* stream) {
     Gemm16 g = {};
     g.x = x; g.ldx = ldx; g.w = w; g.bias = bias; g.res = res; g.y = y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.epi = epilogue;
+    if (workspace) {
+        g.ws_slabs = (float*)workspace;
+        g.ws_count = (int*)((char*)workspace + (size_t)GEMM_WS_TILES * 4 * 256 * sizeof(float));
+    }
     return launch_gemm16(g, (hipStream_t)stream, "ccvs_gemm_nt");
 }
 

@@ -13,8 +13,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libccvs_hip.so")
 # every symbol include/ccvs_hip.h declares
 EXPORTS = [
     "ccvs_last_error", "ccvs_abi_version", "ccvs_conv2d", "ccvs_conv2d_bf16x3", "ccvs_upfirdn2d", "ccvs_dwconvT4x4s2",
-    "ccvs_correlation7x7", "ccvs_backwarp", "ccvs_warp_fuse_blend", "ccvs_vq_argmin", "ccvs_embed_gather",
-    "ccvs_gpt_embed", "ccvs_layernorm", "ccvs_gemm_nt", "ccvs_gemm_ln", "ccvs_gemm_ln_qkv", "ccvs_attention", "ccvs_kv_append", "ccvs_sample_topk",
+    "ccvs_correlation7x7", "ccvs_backwarp", "ccvs_warp_fuse_blend", "ccvs_tap_shift_add", "ccvs_vq_argmin", "ccvs_embed_gather",
+    "ccvs_gpt_embed", "ccvs_layernorm", "ccvs_gemm_workspace_bytes", "ccvs_gemm_nt", "ccvs_gemm_ln", "ccvs_gemm_ln_qkv", "ccvs_attention", "ccvs_kv_append", "ccvs_sample_topk",
     "ccvs_pack_u8",
 ]
 
@@ -51,6 +51,8 @@ def load():
     lib.ccvs_last_error.restype = C.c_char_p
     lib.ccvs_last_error.argtypes = []
     lib.ccvs_abi_version.restype = C.c_int
+    lib.ccvs_gemm_workspace_bytes.restype = C.c_int64
+    lib.ccvs_gemm_workspace_bytes.argtypes = []
     sigs = {
         "ccvs_conv2d": [vp, vp, vp, vp, vp, C.POINTER(ConvDesc), vp],
         "ccvs_conv2d_bf16x3": [vp, vp, vp, vp, vp, C.POINTER(ConvDesc), vp],
@@ -59,11 +61,12 @@ def load():
         "ccvs_correlation7x7": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
         "ccvs_backwarp": [vp, i64, i64, vp, i64, f32, vp, i64, i64, i32, i32, i32, i32, vp],
         "ccvs_warp_fuse_blend": [vp, i64, i64, vp, vp, i64, vp, i64, f32, i32, i32, i32, i32, i32, vp],
+        "ccvs_tap_shift_add": [vp, vp, vp, i64, i32, i32, i32, i32, i32, vp],
         "ccvs_vq_argmin": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "ccvs_embed_gather": [vp, vp, vp, i32, i32, i32, i32, vp],
         "ccvs_gpt_embed": [vp, i64, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, vp],
         "ccvs_layernorm": [vp, vp, vp, vp, i32, i32, vp],
-        "ccvs_gemm_nt": [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp],
+        "ccvs_gemm_nt": [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp],
         "ccvs_gemm_ln": [vp, i64, vp, vp, vp, f32, vp, i64, i32, i32, i32, i32, vp],
         "ccvs_gemm_ln_qkv": [vp, i64, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp],
         "ccvs_attention": [vp, i64, i64, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp],

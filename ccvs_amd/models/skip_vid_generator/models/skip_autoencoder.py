@@ -216,13 +216,11 @@ class _FusedHeads:
 
     def __call__(self, feat, out, accumulate):
         fw, ow = self.fh.weight, self.oh.weight
-        key = (fw.data_ptr(), fw._version, ow.data_ptr(), ow._version, fw.device)
+        key = (fw.data_ptr(), fw._version, ow.data_ptr(), ow._version, fw.device, ops.CONV_PRECISION)
         if self._cache is None or self._cache[0] != key:
-            w = torch.cat([fw.detach(), ow.detach()], dim=0)
             b = torch.cat([self.fh.bias.detach(), self.oh.bias.detach()], dim=0).contiguous()
-            self._cache = (key, ops.pack_conv_weight(w), b)
-        k = self.fh.kernel_size
-        return ops.conv2d(feat, self._cache[1], self._cache[2], 3, k, pad=k // 2, out=out, accumulate=accumulate)
+            self._cache = (key, ops.pack_head_weights(fw, ow), b)
+        return ops.conv_heads(feat, self._cache[1], self._cache[2], out, accumulate)
 
 
 class InterBlock(nn.Module):

@@ -74,26 +74,28 @@ CONV_PRECISION = "bf16x3"
 
 class PackedConv:
     """Kernel-ready weights of one convolution (built once per parameter version)."""
-    __slots__ = ("kind", "data", "cin", "cout", "cout_pad", "k")
+    __slots__ = ("kind", "data", "cin", "cout", "cout_pad", "k", "kw")
 
-    def __init__(self, kind, data, cin, cout, cout_pad, k):
+    def __init__(self, kind, data, cin, cout, cout_pad, k, kw=None):
         self.kind, self.data, self.cin, self.cout, self.cout_pad, self.k = kind, data, cin, cout, cout_pad, k
+        self.kw = k if kw is None else kw
 
 
-def pack_conv_weight(weight, precision=None):
+def pack_conv_weight(weight, precision=None, scale=None):
     """[Cout,Cin,k,k] parameter -> PackedConv, with the EqualConv2d scale 1/sqrt(Cin*k*k) multiplied in
     first (the same fp32 product as `weight * scale`, skip_autoencoder.py:44,55,58).
       f32   : [k*k][Cin][CoutPad] fp32
       bf16x3: [k*k][CinPad/8][hi|lo][CoutPad][8] bf16, w = hi + lo (both round-to-nearest-even)"""
     precision = precision or CONV_PRECISION
     cout, cin, kh, kw = weight.shape
-    scale = 1 / math.sqrt(cin * kh * kw)
+    if scale is None:
+        scale = 1 / math.sqrt(cin * kh * kw)
     w = (weight.detach().float() * scale).permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
     if precision == "f32":
         cpad = -(-cout // 64) * 64 if cout >= 64 else 32 * (-(-cout // 32))
         out = torch.zeros(kh * kw, cin, cpad, dtype=torch.float32, device=weight.device)
         out[:, :, :cout] = w
-        return PackedConv("f32", out.contiguous(), cin, cout, cpad, kh)
+        return PackedConv("f32", out.contiguous(), cin, cout, cpad, kh, kw)
     if precision != "bf16x3":
         raise ValueError(f"unknown conv precision {precision!r}")
     cpad = 32 * (-(-cout // 32))
@@ -104,7 +106,7 @@ def pack_conv_weight(weight, precision=None):
     lo = (full - hi.float()).to(torch.bfloat16)
     lay = lambda t: t.view(kh * kw, cinp // 8, 8, cpad).permute(0, 1, 3, 2)
     out = torch.stack([lay(hi), lay(lo)], dim=2).contiguous()  # [tap][cg][2][cpad][8]
-    return PackedConv("bf16x3", out, cin, cout, cpad, kh)
+    return PackedConv("bf16x3", out, cin, cout, cpad, kh, kw)
 
 
 def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=False, residual=None,
@@ -113,10 +115,11 @@ def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=Fa
     x = _as_rows_dense(x)
     n, cin, h, w = x.shape
     assert w_packed.k == k and w_packed.cin == cin and w_packed.cout == cout, (w_packed.k, w_packed.cin, w_packed.cout, k, cin, cout)
+    kw = w_packed.kw
     if transposed:
         ho, wo = 2 * h + k - 2, 2 * w + k - 2
     else:
-        ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+        ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - kw) // stride + 1
     if out is None:
         out = torch.empty(n, cout, ho, wo, dtype=torch.float32, device=x.device)
     assert out.shape == (n, cout, ho, wo) and _rows_dense(out), (out.shape, (n, cout, ho, wo))
@@ -129,7 +132,7 @@ def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=Fa
         residual = _as_rows_dense(residual)
         assert residual.shape == out.shape
         d.res_sN, d.res_sC = residual.stride(0), residual.stride(1)
-    d.kh = d.kw = k
+    d.kh, d.kw = k, kw
     d.stride, d.pad, d.transposed = stride, pad, 1 if transposed else 0
     d.act = ACT_LRELU if act else ACT_NONE
     d.accumulate = 1 if accumulate else 0
@@ -137,12 +140,34 @@ def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=Fa
     L = _lib.load()
     prof = KERNEL_TIMER
     if prof is not None:
-        macs = n * cout * cin * k * k * (h * w if transposed else ho * wo)
+        macs = n * cout * cin * k * kw * (h * w if transposed else ho * wo)
         prof.begin("conv2d_" + w_packed.kind, flops=2.0 * macs)
     fn = L.ccvs_conv2d if w_packed.kind == "f32" else L.ccvs_conv2d_bf16x3
     _lib.check(fn(_p(x), _p(w_packed.data), _p(bias), _p(residual), _p(out), C.byref(d), _stream()), "ccvs_conv2d[" + w_packed.kind + "]")
     if prof is not None:
         prof.end()
+    return out
+
+
+def pack_head_weights(flow_w, occ_w, precision=None):
+    """flow_head [2,C,k,k] + occ_head [1,C,k,k] -> PackedConv of the equivalent k x 1 convolution with 3k
+    outputs (row kx*3+co = tap column kx of output co); see ccvs_tap_shift_add."""
+    w = torch.cat([flow_w.detach(), occ_w.detach()], dim=0).float()          # [3, C, k, k]
+    _, cin, k, _ = w.shape
+    wt = w.permute(3, 0, 1, 2).reshape(3 * k, cin, k, 1).contiguous()          # [(kx,co), C, ky, 1]
+    return pack_conv_weight(wt, precision, scale=1 / math.sqrt(cin * k * k))
+
+
+def conv_heads(feat, w_packed, bias3, out, accumulate, flops_cb=None):
+    """The fused flow/occ heads: k x 1 MFMA convolution to 3k maps, then the horizontal tap sum into
+    `out` ([N,3,H,W] view, batch stride free)."""
+    k = w_packed.k
+    n, _, h, w = feat.shape
+    t = conv2d(feat, w_packed, None, 3 * k, k, pad=k // 2)                      # [N, 3k, H, W+k-1]
+    assert out.shape == (n, 3, h, w) and _planes_dense(out)
+    L = _lib.load()
+    _lib.check(L.ccvs_tap_shift_add(_p(t), _p(bias3), _p(out), out.stride(0), n, k, h, w, 1 if accumulate else 0, _stream()),
+               "ccvs_tap_shift_add")
     return out
 
 
@@ -287,9 +312,21 @@ def gemm_nt(x, w, bias=None, epilogue=EPI_NONE, residual=None, out=None):
     if residual is not None:
         assert residual.stride(1) == 1 and residual.stride(0) == out.stride(0)
     L = _lib.load()
-    _lib.check(L.ccvs_gemm_nt(_p(x), x.stride(0), _p(w), _p(bias), _p(residual), _p(out), out.stride(0), m, n, k, epilogue, _stream()),
-               "ccvs_gemm_nt")
+    _lib.check(L.ccvs_gemm_nt(_p(x), x.stride(0), _p(w), _p(bias), _p(residual), _p(out), out.stride(0), m, n, k, epilogue,
+                              _p(_gemm_workspace(x.device)), _stream()), "ccvs_gemm_nt")
     return out
+
+
+_GEMM_WS = {}
+
+
+def _gemm_workspace(device):
+    """Zero-initialised split-K workspace (slabs + arrival counters), one per device, reused by every
+    call on the stream (calls are stream-ordered; the reducer leaves the counters at zero)."""
+    ws = _GEMM_WS.get(device)
+    if ws is None:
+        ws = _GEMM_WS[device] = torch.zeros(int(_lib.load().ccvs_gemm_workspace_bytes()), dtype=torch.uint8, device=device)
+    return ws
 
 
 def pack_ln_linear(weight, bias, gamma, beta):

@@ -115,6 +115,14 @@ int ccvs_warp_fuse_blend(float* dec, int64_t dec_sN, int64_t dec_sC, const float
                          const float* occs, int64_t occs_sN, float flow_mult, int32_t N, int32_t k, int32_t C, int32_t H,
                          int32_t W, void* stream);
 
+/* Horizontal half of the 3-output flow / occlusion heads (skip_autoencoder.py:176-177,204-205,225-226).
+ * The k x k, 3-output convolution is run as ccvs_conv2d[_bf16x3] with a k x 1 kernel, 3k outputs
+ * (row kx*3+co holds tap column kx of output co) and padding k/2 on both axes, giving
+ * t [N,3k,H,W+k-1]; this call sums the k shifted rows:
+ *   y[n][co][yy][x] (+)= bias[co] + sum_kx t[n][kx*3+co][yy][x+kx].   y batch stride y_sN, planes dense. */
+int ccvs_tap_shift_add(const float* t, const float* bias, float* y, int64_t y_sN, int32_t N, int32_t k, int32_t H, int32_t W,
+                       int32_t accumulate, void* stream);
+
 /* ---- vector quantiser ----------------------------------------------------------------
  * ccvs_vq_argmin replaces VectorQuantizer.forward's distance + argmin
  * (modules/quantize.py:40-50): idx[n*HW + p] = argmin_j (|z|^2 + |e_j|^2) - 2 z.e_j,
@@ -148,9 +156,13 @@ int ccvs_layernorm(const float* x, const float* gamma, const float* beta, float*
 
 /* y = epilogue(x @ W^T + bias): nn.Linear (mingpt.py:44-51,107-110,169).
  * x [M,K] row stride ldx, W [N,K] (torch Linear layout), y [M,N] row stride ldy.
- * epilogue: 0 none, 1 GELU(erf) (mingpt.py:109), 2 add residual (res [M,N], stride ldy). */
+ * epilogue: 0 none, 1 GELU(erf) (mingpt.py:109), 2 add residual (res [M,N], stride ldy).
+ * workspace (may be NULL): ccvs_gemm_workspace_bytes() bytes of device memory, ZEROED once by the caller and
+ * then owned by this call chain; with it, GEMMs with few output columns also split K across workgroups
+ * (deterministic last-arriver reduction) so that every CU streams weights. */
+int64_t ccvs_gemm_workspace_bytes(void);
 int ccvs_gemm_nt(const float* x, int64_t ldx, const float* w, const float* bias, const float* res, float* y, int64_t ldy,
-                 int32_t M, int32_t N, int32_t K, int32_t epilogue, void* stream);
+                 int32_t M, int32_t N, int32_t K, int32_t epilogue, void* workspace, void* stream);
 
 /* LayerNorm folded into the following Linear (mingpt.py:115-116: x + attn(ln1(x)), mlp(ln2(x))):
  *   LN(x) @ W^T + b = rstd * (x @ W'^T - mean * s) + b',  W' = W*gamma, s = rowsum(W'), b' = b + W beta
