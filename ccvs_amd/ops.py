@@ -313,7 +313,7 @@ def gemm_nt(x, w, bias=None, epilogue=EPI_NONE, residual=None, out=None):
         assert residual.stride(1) == 1 and residual.stride(0) == out.stride(0)
     L = _lib.load()
     _lib.check(L.ccvs_gemm_nt(_p(x), x.stride(0), _p(w), _p(bias), _p(residual), _p(out), out.stride(0), m, n, k, epilogue,
-                              _p(_gemm_workspace(x.device)), _stream()), "ccvs_gemm_nt")
+                              _p(_gemm_workspace(x.device)), _stream()), "ccvs_gemm_nt")  # workspace is per (device, stream)
     return out
 
 
@@ -321,11 +321,13 @@ _GEMM_WS = {}
 
 
 def _gemm_workspace(device):
-    """Zero-initialised split-K workspace (slabs + arrival counters), one per device, reused by every
-    call on the stream (calls are stream-ordered; the reducer leaves the counters at zero)."""
-    ws = _GEMM_WS.get(device)
+    """Zero-initialised split-K workspace (slabs + arrival counters), one per (device, stream): calls on
+    one stream are ordered and the reducer leaves the counters at zero, but two streams (the parallel
+    decode lanes of GPT.generate) may run the same GEMM concurrently and must not share slabs."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _GEMM_WS.get(key)
     if ws is None:
-        ws = _GEMM_WS[device] = torch.zeros(int(_lib.load().ccvs_gemm_workspace_bytes()), dtype=torch.uint8, device=device)
+        ws = _GEMM_WS[key] = torch.zeros(int(_lib.load().ccvs_gemm_workspace_bytes()), dtype=torch.uint8, device=device)
     return ws
 
 
