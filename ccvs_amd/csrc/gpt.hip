@@ -400,19 +400,24 @@ __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __re
     const float* kbase = kc + (long)bh * Tmax * D + 4 * d4;
     const float* vbase = vc + (long)bh * Tmax * D + 4 * d4;
 
+    constexpr int AU = 8;  // key rows per lane whose loads are issued together (64 KiB in flight per workgroup)
     float lmax = -INFINITY;
-#pragma unroll 4
-    for (int j0 = wave * KPI; j0 < L; j0 += NW * KPI) {
-        const int j = j0 + kk;
-        // unconditional load from a clamped row (predicated loads in an unrolled loop serialise)
-        const float4 kv = *reinterpret_cast<const float4*>(kbase + (long)min(j, L - 1) * D);
-        float s = kv.x * qv.x + kv.y * qv.y + kv.z * qv.z + kv.w * qv.w;
+    for (int j0 = wave * KPI; j0 < L; j0 += NW * KPI * AU) {
+        float4 kv[AU];
 #pragma unroll
-        for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
-        s *= scale;
-        if (j < L) {
-            if (d4 == 0) ps[j] = s;
-            lmax = fmaxf(lmax, s);
+        for (int u = 0; u < AU; ++u)  // unconditional loads from clamped rows (predicated loads would serialise)
+            kv[u] = *reinterpret_cast<const float4*>(kbase + (long)min(j0 + u * NW * KPI + kk, L - 1) * D);
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            const int j = j0 + u * NW * KPI + kk;
+            float s = kv[u].x * qv.x + kv[u].y * qv.y + kv[u].z * qv.z + kv[u].w * qv.w;
+#pragma unroll
+            for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
+            s *= scale;
+            if (j < L) {
+                if (d4 == 0) ps[j] = s;
+                lmax = fmaxf(lmax, s);
+            }
         }
     }
     lmax = wave_max(lmax);
@@ -436,13 +441,17 @@ __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __re
     for (int w = 1; w < NW; ++w) tot += red[w];
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-    for (int j0 = wave * KPI; j0 < L; j0 += NW * KPI) {
-        const int j = j0 + kk;
-        const int jc = min(j, L - 1);
-        const float p = (j < L) ? ps[jc] : 0.f;
-        const float4 vv = *reinterpret_cast<const float4*>(vbase + (long)jc * D);
-        acc.x += p * vv.x; acc.y += p * vv.y; acc.z += p * vv.z; acc.w += p * vv.w;
+    for (int j0 = wave * KPI; j0 < L; j0 += NW * KPI * AU) {
+        float4 vv[AU];
+#pragma unroll
+        for (int u = 0; u < AU; ++u)
+            vv[u] = *reinterpret_cast<const float4*>(vbase + (long)min(j0 + u * NW * KPI + kk, L - 1) * D);
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            const int j = j0 + u * NW * KPI + kk;
+            const float p = (j < L) ? ps[min(j, L - 1)] : 0.f;
+            acc.x += p * vv[u].x; acc.y += p * vv[u].y; acc.z += p * vv[u].z; acc.w += p * vv[u].w;
+        }
     }
     *reinterpret_cast<float4*>(pv + (wave * 64 + lane) * 4) = acc;
     __syncthreads();

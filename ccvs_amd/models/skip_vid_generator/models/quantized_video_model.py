@@ -6,8 +6,8 @@ Host-side mirror of the inference half of the reference's
 same constructor, same modes, same dict keys in and out, `ValueError` on an unknown mode.
 
 Differences that do not change results:
-  * the context ring of skip features is shifted with an explicit copy (the reference's
-    overlapping in-place slice assignment, :898-900/:946, is rejected by torch >= 1.8);
+  * the context ring of skip features is a circular buffer (slot permutation instead of the
+    reference's overlapping in-place shift, :898-900/:946, which torch >= 1.8 rejects anyway);
   * re-encoding a synthesized frame inside the decode loop (:875-878) skips the vector
     quantiser, whose output that loop discards;
   * `embed_code` + two transposes (:832-833) is one gather kernel writing NCHW.
@@ -130,12 +130,16 @@ class QVidModel(torch.nn.Module):
             if keep:
                 r[:, mem - keep:] = feat[:, ctx - keep:]
             ring.append(r)
+        # The ring is circular: `order[p]` is the physical slot of logical position p (oldest .. newest), so
+        # the per-frame "shift left by one" (quantized_video_model.py:895-901) moves no data, and contexts
+        # are slot VIEWS (the reference's `feat[:, [-dt]]` list-index makes a copy per context and level).
+        order = list(range(mem))
         curr = ctx
         has_cond = isinstance(cond_inter, list) and len(cond_inter) > 0
         if has_cond:
             ctx += 1
         for _ in range(opt.vid_len - ctx):
-            inters = [[feat[:, [-dt]] for feat in ring] for dt in opt.skip_context if dt <= curr]
+            inters = [[feat[:, order[mem - dt]: order[mem - dt] + 1] for feat in ring] for dt in opt.skip_context if dt <= curr]
             if has_cond:
                 inters.append(cond_inter)
             if opt.skip_mode == "enc":
@@ -147,13 +151,10 @@ class QVidModel(torch.nn.Module):
                 new_inter = list(reversed(inter_dec))
             else:
                 raise ValueError
+            drop = opt.n_first if (getattr(opt, "keep_first", False) and curr >= mem) else 0   # logical slot that leaves
+            order = order[:drop] + order[drop + 1:] + [order[drop]]
             for i in range(len(ring)):
-                if getattr(opt, "keep_first", False) and curr >= mem:
-                    n = opt.n_first
-                    ring[i][:, n:-1] = ring[i][:, n + 1:].clone()
-                else:
-                    ring[i][:, :-1] = ring[i][:, 1:].clone()
-                ring[i][:, -1:] = new_inter[i]
+                ring[i][:, order[-1]: order[-1] + 1] = new_inter[i]
             fakes.append(fake_img)
             curr += 1
         return {dtype: torch.cat(fakes, dim=1), "layout": None}
