@@ -225,6 +225,8 @@ __global__ __launch_bounds__(512, 2) void conv2d_bf16x3_pc_kernel(ConvK p, const
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (measured: making the role provably wave-uniform with readfirstlane, or s_setprio(1) on the MFMA
+    //  waves, both cost ~25 % on the 195->128 3x3 shape with hipcc / ROCm 7.2 -- left as plain predication)
     const bool producer = wave >= 4;
     const int rt = tid & 255, rw = wave & 3;  // thread / wave index inside the role
     const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;

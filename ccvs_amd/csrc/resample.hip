@@ -49,46 +49,95 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(FirK p) {
     }
 }
 
-// up = down = 1 fast path: a thread produces 4 consecutive outputs of one row from a
-// 4 x 7 input window held in registers (7 loads per output row instead of 16 per pixel),
-// separable 1-3-3-1 passes.
-__global__ __launch_bounds__(256) void blur4x4_kernel(FirK p) {
-    const int Wq = (p.Wo + 3) >> 2;
-    const long total = p.NC * p.Ho * Wq;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % Wq);
-        const long t = i / Wq;
-        const int oy = (int)(t % p.Ho);
-        const long nc = t / p.Ho;
-        const int ox0 = q * 4;
-        const float* xp = p.x + nc * (long)p.H * p.W;
-        float h[4][4];  // horizontal pass results for the 4 rows x 4 outputs
+// up = down = 1: a 256-thread workgroup owns a 16 x 64 output tile of one channel plane; the
+// (16+3) x (64+3) input tile is staged once in LDS with coalesced loads (every input element is read
+// from HBM once, unconditionally from a clamped address), then each thread produces 4 consecutive
+// outputs of one row with the separable 1-3-3-1 passes and writes them as one 16-byte store.
+#define BLUR_TH 16
+#define BLUR_TW 64
+__global__ __launch_bounds__(256) void blur4x4_tile_kernel(FirK p, int tiles_x) {
+    __shared__ float tile[(BLUR_TH + 3) * (BLUR_TW + 4)];
+    constexpr int IWp = BLUR_TW + 4, IH = BLUR_TH + 3, IW = BLUR_TW + 3;
+    const int tid = threadIdx.x;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const long nc = blockIdx.y;
+    const float* xp = p.x + nc * (long)p.H * p.W;
+    const int iy0 = ty * BLUR_TH - p.pad0, ix0 = tx * BLUR_TW - p.pad0;
+    for (int e = tid; e < IH * IW; e += 256) {
+        const int r = e / IW, c = e - r * IW;
+        const int iy = iy0 + r, ix = ix0 + c;
+        const float t = xp[(long)min(max(iy, 0), p.H - 1) * p.W + min(max(ix, 0), p.W - 1)];
+        tile[r * IWp + c] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? t : 0.f;
+    }
+    __syncthreads();
+    const int row = tid >> 4, col = (tid & 15) * 4;
+    const int oy = ty * BLUR_TH + row, ox0 = tx * BLUR_TW + col;
+    if (oy >= p.Ho || ox0 >= p.Wo) return;
+    float h[4][4];
 #pragma unroll
-        for (int ky = 0; ky < 4; ++ky) {
-            const int iy = oy + ky - p.pad0;
-            float r[7];
-            const bool rowok = (iy >= 0 && iy < p.H);
-            const long rowoff = (long)min(max(iy, 0), p.H - 1) * p.W;
+    for (int ky = 0; ky < 4; ++ky) {
+        float r[7];
 #pragma unroll
-            for (int c = 0; c < 7; ++c) {  // unconditional loads from clamped addresses, zeroed afterwards
-                const int ix = ox0 + c - p.pad0;
-                const float t = xp[rowoff + min(max(ix, 0), p.W - 1)];
-                r[c] = (rowok && ix >= 0 && ix < p.W) ? t : 0.f;
-            }
+        for (int c = 0; c < 7; ++c) r[c] = tile[(row + ky) * IWp + col + c];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) h[ky][o] = (r[o] + r[o + 3]) + 3.f * (r[o + 1] + r[o + 2]);
+        for (int o = 0; o < 4; ++o) h[ky][o] = (r[o] + r[o + 3]) + 3.f * (r[o + 1] + r[o + 2]);
+    }
+    const float g = p.gain * (1.f / 64.f);
+    float v[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        v[o] = ((h[0][o] + h[3][o]) + 3.f * (h[1][o] + h[2][o])) * g;
+        if (p.act == CCVS_ACT_LRELU) v[o] = lrelu01(v[o]);
+    }
+    const long oi = (nc * p.Ho + oy) * (long)p.Wo + ox0;
+    const int nv = min(4, p.Wo - ox0);
+    if (nv == 4 && (oi & 3) == 0) {
+        if (p.res) {
+            const float4 r4 = *reinterpret_cast<const float4*>(p.res + oi);
+            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
         }
+        *reinterpret_cast<float4*>(p.y + oi) = make_float4(v[0] * p.out_scale, v[1] * p.out_scale, v[2] * p.out_scale, v[3] * p.out_scale);
+    } else {
+        for (int o = 0; o < nv; ++o) p.y[oi + o] = (v[o] + (p.res ? p.res[oi + o] : 0.f)) * p.out_scale;
+    }
+}
+
+// up = 2, down = 1, pad (2,1): the decoder's skip up-sampling.  On the zero-inserted grid only every
+// other tap hits a sample, so an output quad (2i..2i+1, 2j..2j+1) is a 1-3 / 3-1 blend of the 3 x 3
+// input neighbourhood: even rows 1*x[i-1] + 3*x[i], odd rows 3*x[i] + 1*x[i+1] (same along x).
+__global__ __launch_bounds__(256) void upsample2_kernel(FirK p) {
+    const long total = p.NC * p.H * p.W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int jx = (int)(i % p.W);
+        const long t = i / p.W;
+        const int iy = (int)(t % p.H);
+        const long nc = t / p.H;
+        const float* xp = p.x + nc * (long)p.H * p.W;
+        float v[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int yy = iy + a - 1, xx = jx + b - 1;
+                const float tv = xp[(long)min(max(yy, 0), p.H - 1) * p.W + min(max(xx, 0), p.W - 1)];
+                v[a][b] = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? tv : 0.f;
+            }
+        float hr[3][2];  // horizontal pass: even column 1*left + 3*mid, odd column 3*mid + 1*right
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { hr[a][0] = v[a][0] + 3.f * v[a][1]; hr[a][1] = 3.f * v[a][1] + v[a][2]; }
         const float g = p.gain * (1.f / 64.f);
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const int ox = ox0 + o;
-            if (ox < p.Wo) {
-                float v = ((h[0][o] + h[3][o]) + 3.f * (h[1][o] + h[2][o])) * g;
-                if (p.act == CCVS_ACT_LRELU) v = lrelu01(v);
-                const long oi = (nc * p.Ho + oy) * (long)p.Wo + ox;
-                if (p.res) v += p.res[oi];
-                p.y[oi] = v * p.out_scale;
+        for (int a = 0; a < 2; ++a) {
+            float o2[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float r = (a == 0 ? hr[0][b] + 3.f * hr[1][b] : 3.f * hr[1][b] + hr[2][b]) * g;
+                if (p.act == CCVS_ACT_LRELU) r = lrelu01(r);
+                o2[b] = r;
             }
+            const long oi = (nc * p.Ho + 2 * iy + a) * (long)p.Wo + 2 * jx;
+            if (p.res) { o2[0] += p.res[oi]; o2[1] += p.res[oi + 1]; }
+            *reinterpret_cast<float2*>(p.y + oi) = make_float2(o2[0] * p.out_scale, o2[1] * p.out_scale);
         }
     }
 }
@@ -105,10 +154,13 @@ extern "C" int ccvs_upfirdn2d(const float* x, float* y, const float* residual, i
     CCVS_REQUIRE(k.Ho > 0 && k.Wo > 0, "ccvs_upfirdn2d: empty output");
     k.gain = gain; k.act = act; k.out_scale = out_scale;
     hipStream_t st = (hipStream_t)stream;
-    if (up == 1 && down == 1) {
-        const long work = NC * k.Ho * ((k.Wo + 3) / 4);
+    if (up == 1 && down == 1 && NC <= 65535) {
+        const int tiles_x = cdiv(k.Wo, BLUR_TW), tiles_y = cdiv(k.Ho, BLUR_TH);
+        hipLaunchKernelGGL(blur4x4_tile_kernel, dim3(tiles_x * tiles_y, (unsigned)NC), dim3(256), 0, st, k, tiles_x);
+    } else if (up == 2 && down == 1 && pad0 == 2 && pad1 == 1) {
+        const long work = NC * (long)H * W;
         const int blocks = (int)(cdiv64(work, 256) < 65536 * 16 ? cdiv64(work, 256) : 65536 * 16);
-        hipLaunchKernelGGL(blur4x4_kernel, dim3(blocks), dim3(256), 0, st, k);
+        hipLaunchKernelGGL(upsample2_kernel, dim3(blocks), dim3(256), 0, st, k);
     } else {
         const long work = NC * k.Ho * k.Wo;
         const int blocks = (int)(cdiv64(work, 256) < 65536 * 16 ? cdiv64(work, 256) : 65536 * 16);
@@ -118,36 +170,47 @@ extern "C" int ccvs_upfirdn2d(const float* x, float* y, const float* residual, i
     return CCVS_OK;
 }
 
-// out[c][y][x] = sum over the (<=2 x 2) taps with y + 1 = 2*iy + ky, x + 1 = 2*ix + kx.
+// Transposed 4x4 stride-2 pad-1 depthwise filter, gather form: y + 1 = 2*iy + ky.  One thread per INPUT
+// pixel (i, j) produces the output quad (2i..2i+1, 2j..2j+1) from the 3 x 3 input neighbourhood:
+// row 2i takes (ky=1, iy=i), (ky=3, iy=i-1); row 2i+1 takes (ky=0, iy=i+1), (ky=2, iy=i); same along x.
 __global__ __launch_bounds__(256) void dwconvT4x4s2_kernel(const float* __restrict__ x, long x_sN, const float* __restrict__ w,
                                                            float* __restrict__ y, long y_sN, long N, int C, int H, int W) {
     const int Ho = 2 * H, Wo = 2 * W;
-    const long total = N * C * (long)Ho * Wo;
+    const long total = N * C * (long)H * W;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int ox = (int)(i % Wo);
-        const long t = i / Wo;
-        const int oy = (int)(t % Ho);
-        const long nc = t / Ho;
+        const int jx = (int)(i % W);
+        const long t = i / W;
+        const int iy = (int)(t % H);
+        const long nc = t / H;
         const int c = (int)(nc % C);
         const long n = nc / C;
         const float* xp = x + n * x_sN + (long)c * H * W;
         const float* wp = w + c * 16;
-        float acc = 0.f;
-        const int ky0 = (oy + 1) & 1, kx0 = (ox + 1) & 1;
+        float v[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int yy = iy + a - 1, xx = jx + b - 1;
+                const float tv = xp[(long)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];
+                v[a][b] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? tv : 0.f;
+            }
+        // (output parity, tap) -> neighbourhood index: parity 0: ky {1,3} -> rows {1,0}; parity 1: ky {0,2} -> rows {2,1}
+        const int kyt[2][2] = {{1, 3}, {0, 2}}, nyt[2][2] = {{1, 0}, {2, 1}};
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const int ky = ky0 + 2 * a;
-            const int iy = (oy + 1 - ky) >> 1;
-            if (iy < 0 || iy >= H) continue;
+            float o2[2];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const int kx = kx0 + 2 * b;
-                const int ix = (ox + 1 - kx) >> 1;
-                if (ix < 0 || ix >= W) continue;
-                acc += xp[(long)iy * W + ix] * wp[ky * 4 + kx];
+                float acc = 0.f;
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < 2; ++tb) acc += v[nyt[a][ta]][nyt[b][tb]] * wp[kyt[a][ta] * 4 + kyt[b][tb]];
+                o2[b] = acc;
             }
+            *reinterpret_cast<float2*>(y + n * y_sN + ((long)c * Ho + 2 * iy + a) * Wo + 2 * jx) = make_float2(o2[0], o2[1]);
         }
-        y[n * y_sN + ((long)c * Ho + oy) * Wo + ox] = acc;
     }
 }
 
@@ -155,7 +218,7 @@ extern "C" int ccvs_dwconvT4x4s2(const float* x, int64_t x_sN, const float* w, f
                                  int32_t W, void* stream) {
     CCVS_REQUIRE(x && w && y, "ccvs_dwconvT4x4s2: null pointer");
     CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "ccvs_dwconvT4x4s2: empty tensor");
-    const long work = (long)N * C * 4 * H * W;
+    const long work = (long)N * C * H * W;
     const int blocks = (int)(cdiv64(work, 256) < 65536 * 16 ? cdiv64(work, 256) : 65536 * 16);
     hipLaunchKernelGGL(dwconvT4x4s2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)x_sN, w, y, (long)y_sN, (long)N, C, H, W);
     CCVS_CHECK_LAUNCH("ccvs_dwconvT4x4s2");
