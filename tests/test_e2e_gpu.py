@@ -196,3 +196,35 @@ def test_determinism(tiny):
     a = qv({"code": torch.from_numpy(g["gen_code_greedy"]), "inter": [f.clone() for f in inter]}, mode="vid_decoder")["vid"]
     b = qv({"code": torch.from_numpy(g["gen_code_greedy"]), "inter": [f.clone() for f in inter]}, mode="vid_decoder")["vid"]
     assert torch.equal(a, b)
+
+
+def test_bair_scale_encode_decode_frame_vs_oracle():
+    """Full BAIR geometry (256x256, 6 levels, 128..512 channels, 9x9 heads, stride-2 cost volumes, k = 2
+    contexts): one encode + one flow-guided decoder frame through the split-bf16 convolutions against the
+    fp32 CPU oracle.  VQ indices exact, pixels within the 1e-3 bar of the north star."""
+    from ccvs_amd.tools.options import Options, BAIR_ARGV
+    from ccvs_amd.models.skip_vid_generator.models.quantized_video_model import QVidModel
+    opt = Options().parse(load_qvid_generator=True, load_transformer=True, argv=BAIR_ARGV)
+    qopt = opt["qvid_generator"]
+    torch.manual_seed(0)
+    qv = QVidModel(qopt, is_train=False, is_main=True).eval()
+    g = torch.Generator().manual_seed(1)
+    vid = torch.rand(1, 2, 3, 256, 256, generator=g) * 2 - 1
+    with torch.no_grad():
+        z_e, _ = qv.net_e(vid.cuda())
+        cb = qv.net_q.embedding.weight
+        cb.copy_((torch.randn(cb.shape, generator=torch.Generator().manual_seed(4)) * float(z_e.std())).cuda())
+        enc = qv({"vid": vid.clone()}, mode="vid_encoder")
+        ctx = [[f[:, :1] for f in enc["inter"]], [f[:, 1:] for f in enc["inter"]]]
+        rgb, _, flows, occs, _ = qv.net_g(enc["z"][:, :1].contiguous(), ctx, return_all=True, inter_pre_warping=False)
+    cpu = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    nets = {"e": cpu(qv.net_e), "q": cpu(qv.net_q), "g": cpu(qv.net_g)}
+    with torch.no_grad():
+        want = O.qvid_encode(nets, qopt, vid)
+        assert torch.equal(enc["code"].cpu(), want["code"]), "VQ indices must be bit-exact at BAIR scale"
+        for a, b in zip(enc["inter"], want["inter"]):
+            assert maxdiff(a, b) < 1e-4
+        octx = [[f[:, :1] for f in want["inter"]], [f[:, 1:] for f in want["inter"]]]
+        orgb, oflows, ooccs = O.decoder_forward(nets["g"], qopt, want["z"][:, :1].contiguous(), octx, return_all=True)
+    assert maxdiff(rgb, orgb) < PIX_TOL, maxdiff(rgb, orgb)
+    assert maxdiff(flows[-1], oflows[-1]) < PIX_TOL and maxdiff(occs[-1], ooccs[-1]) < PIX_TOL
