@@ -78,6 +78,7 @@ def cpu_baseline(gen, opt):
     frame = torch.rand(1, 1, 3, qopt.max_dim, qopt.max_dim, generator=g) * 2 - 1
     t_all = time.perf_counter()
     with torch.no_grad():
+        O.encoder_forward(nets["e"], qopt, frame[:, :, :, :64, :64])  # untimed warm-up (thread pool, allocator)
         t0 = time.perf_counter()
         enc = O.qvid_encode(nets, qopt, frame)
         t_enc = time.perf_counter() - t0
@@ -87,8 +88,9 @@ def cpu_baseline(gen, opt):
         O.decoder_forward(nets["g"], qopt, z, [ctx])
         t_dec1 = time.perf_counter() - t0
         t0 = time.perf_counter()
-        O.decoder_forward(nets["g"], qopt, z, [ctx, ctx])
-        t_dec2 = time.perf_counter() - t0
+        O.decoder_forward(nets["g"], qopt, z, [ctx, ctx, ctx])
+        t_dec3 = time.perf_counter() - t0
+        t_dec2 = 0.5 * (t_dec1 + t_dec3)   # linear in the number of contexts
         ts = {}
         for T in (64, 384, 768):
             idx = torch.randint(0, xopt.z_num, (1, T), generator=g)
@@ -107,9 +109,24 @@ def cpu_baseline(gen, opt):
     total = t_encode + t_gpt + t_decode
     return {"value": 15.0 / total, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": (f"oracle on BAIR batch 1, extrapolated from {time.perf_counter() - t_all:.1f}s of CPU work: encoder 1 frame "
-                       f"{t_enc:.2f}s, decoder 1 frame k=1 {t_dec1:.2f}s / k=2 {t_dec2:.2f}s, GPT forward T=64/384/768 "
+                       f"{t_enc:.2f}s, decoder 1 frame k=1 {t_dec1:.2f}s / k=3 {t_dec3:.2f}s, GPT forward T=64/384/768 "
                        f"{ts[64]:.2f}/{ts[384]:.2f}/{ts[768]:.2f}s -> clip = encode {t_encode:.0f}s + no-cache token loop "
                        f"{t_gpt:.0f}s + decode {t_decode:.0f}s")}
+
+
+def conv_traffic(args, kind, launches):
+    """HBM bytes per launch of the convolution kernel, from the rocprofv3 PMC passes of this same command
+    (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units; profiles/r01_conv_traffic.json says how it was
+    collected).  None when no matching profile is committed: PMC counters cannot be read from inside bench.py."""
+    path = os.path.join(ROOT, "profiles", "conv_traffic.json")
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    key = f"{args.config}-b{args.batch}-{kind}"
+    if key not in rec:
+        return None
+    r = rec[key]
+    return r
 
 
 def main():
@@ -170,7 +187,8 @@ def main():
             peak = BF16_MFMA_PEAK_TFLOPS if kind == "bf16x3" else FP32_MFMA_PEAK_TFLOPS
             products = 3 if kind == "bf16x3" else 1
             line = {
-                "metric": "synthesized frames/sec (BAIR 256x256, cond=1, pred=15), whole job", "value": frames / elapsed,
+                "metric": ("synthesized frames/sec (BAIR 256x256, cond=1, pred=15), whole job" if args.config == "bair" else
+                           "synthesized frames/sec (Kinetics-600 64x64, cond=5, pred=11), whole job"), "value": frames / elapsed,
                 "unit": "frames/s", "per_gpu": frames / elapsed / world, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32 (convolutions as split-bf16 x3 on bf16 MFMA, fp32 accumulate)" if kind == "bf16x3" else "f32",
@@ -181,7 +199,9 @@ def main():
                            "parallelism": f"dp{world} (batch sharded, one RCCL all-gather of uint8 clips)"},
                 "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
                 "roofline": {"kernel": "conv2d_bf16x3_kernel" if kind == "bf16x3" else "conv2d_mfma_kernel", "bound": "mfma",
-                             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                             "traffic": (conv_traffic(args, kind, n_conv) or {}).get("bytes_per_launch"),
+                             "traffic_detail": conv_traffic(args, kind, n_conv),
                              "mfma_products_per_flop": products, "mfma_issue_frac": products * achieved / peak,
                              "vs_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                              "launches": n_conv, "avg_launch_us": 1e3 * conv_ms / max(n_conv, 1),

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvK p) {
                 const int co = n0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 if (co < p.Cout) {
                     float v = acc[m][pp][r];
+                    if (p.pre) v += p.pre[(long)(n / p.pre_div) * p.pre_sN + (long)co * p.pre_sC + opix];
                     if (p.bias) v += p.bias[co];
                     if (p.act == CCVS_ACT_LRELU) v = lrelu01(v);
                     if (p.res) v += p.res[(long)n * p.res_sN + (long)co * p.res_sC + opix];
@@ -198,6 +199,7 @@ extern "C" int ccvs_conv2d(const float* x, const float* w_packed, const float* b
     k.out_sN = d->out_sN; k.out_sC = d->out_sC; k.res_sN = d->res_sN; k.res_sC = d->res_sC;
     k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad; k.transposed = d->transposed ? 1 : 0;
     k.act = d->act; k.accumulate = d->accumulate; k.out_scale = d->out_scale;
+    k.pre = d->pre; k.pre_sN = d->pre_sN; k.pre_sC = d->pre_sC; k.pre_div = d->pre_div > 0 ? d->pre_div : 1;
 
     // virtual grid (largest parity class for the transposed form)
     const int VH = d->transposed ? (Hout + 1) / 2 : Hout;

@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4
                 const int co = n0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 if (co < p.Cout) {
                     float v = acc[m][pp][r];
+                    if (p.pre) v += p.pre[(long)(n / p.pre_div) * p.pre_sN + (long)co * p.pre_sC + opix];
                     if (p.bias) v += p.bias[co];
                     if (p.act == CCVS_ACT_LRELU) v = lrelu01(v);
                     if (p.res) v += p.res[(long)n * p.res_sN + (long)co * p.res_sC + opix];
@@ -446,22 +447,26 @@ __global__ __launch_bounds__(512, 2) void conv2d_bf16x3_pc_kernel(ConvK p, const
                     const long opix = (long)vy * p.Wout + vx;
                     float* dst = p.y + (long)n * p.out_sN + (long)co * p.out_sC + opix;
                     const float* rsrc = p.res ? p.res + (long)n * p.res_sN + (long)co * p.res_sC + opix : nullptr;
+                    const float* psrc = p.pre ? p.pre + (long)(n / p.pre_div) * p.pre_sN + (long)co * p.pre_sC + opix : nullptr;
                     const int nv = min(4, ax.V - vx);
                     const bool vec = (nv == 4) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) &&
-                                     (!rsrc || (reinterpret_cast<uintptr_t>(rsrc) & 15) == 0);
-                    float rv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
+                                     (!rsrc || (reinterpret_cast<uintptr_t>(rsrc) & 15) == 0) &&
+                                     (!psrc || (reinterpret_cast<uintptr_t>(psrc) & 15) == 0);
+                    float rv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f};
                     if (vec) {
+                        if (psrc) { const float4 t = *reinterpret_cast<const float4*>(psrc); pv[0] = t.x; pv[1] = t.y; pv[2] = t.z; pv[3] = t.w; }
                         if (rsrc) { const float4 t = *reinterpret_cast<const float4*>(rsrc); rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
                         if (p.accumulate) { const float4 t = *reinterpret_cast<const float4*>(dst); ov[0] = t.x; ov[1] = t.y; ov[2] = t.z; ov[3] = t.w; }
                     } else {
                         for (int j = 0; j < nv; ++j) {
+                            if (psrc) pv[j] = psrc[j];
                             if (rsrc) rv[j] = rsrc[j];
                             if (p.accumulate) ov[j] = dst[j];
                         }
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float t = v[j] + bv;
+                        float t = (v[j] + pv[j]) + bv;
                         if (p.act == CCVS_ACT_LRELU) t = lrelu01(t);
                         t = (t + rv[j]) * p.out_scale;
                         v[j] = t + ov[j];
@@ -494,6 +499,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_bf16x3_pc_kernel(ConvK p, const
                 const int co = n0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 if (co < p.Cout) {
                     float v = acc[m][pp][r];
+                    if (p.pre) v += p.pre[(long)(n / p.pre_div) * p.pre_sN + (long)co * p.pre_sC + opix];
                     if (p.bias) v += p.bias[co];
                     if (p.act == CCVS_ACT_LRELU) v = lrelu01(v);
                     if (p.res) v += p.res[(long)n * p.res_sN + (long)co * p.res_sC + opix];
@@ -568,6 +574,7 @@ extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const flo
     k.out_sN = d->out_sN; k.out_sC = d->out_sC; k.res_sN = d->res_sN; k.res_sC = d->res_sC;
     k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad; k.transposed = d->transposed ? 1 : 0;
     k.act = d->act; k.accumulate = d->accumulate; k.out_scale = d->out_scale;
+    k.pre = d->pre; k.pre_sN = d->pre_sN; k.pre_sC = d->pre_sC; k.pre_div = d->pre_div > 0 ? d->pre_div : 1;
     const int CinG = 2 * ((d->Cin + 15) / 16);  // 8-channel groups, Cin padded to 16
 
     const int VH = d->transposed ? (Hout + 1) / 2 : Hout;

@@ -16,6 +16,9 @@ struct ConvK {
     int kh, kw, stride, pad, transposed;
     int act, accumulate;
     float out_scale;
+    const float* pre;
+    long pre_sN, pre_sC;
+    int pre_div;
     int tiles_x, tiles_y;
 };
 

@@ -256,8 +256,11 @@ class InterBlock(nn.Module):
         k = len(inters)
         m = self.matching
         stacked = torch.stack([t.reshape(n, s, h, w) for t in inters], dim=1).view(n * k, s, h, w)
-        sp_in = torch.empty(n * k, 2 * s + 3, h, w, dtype=torch.float32, device=dec.device)
-        fo = sp_in[:, 2 * s:]
+        # Subpixel input [dec | warped ctx | flow | occ] (skip_autoencoder.py:224): the `dec` block is the same
+        # for the k contexts of a frame, so its share of the first Subpixel conv is computed ONCE per frame
+        # (`pre`) and broadcast inside the conv epilogue; only [warped | flow | occ] is materialised per pair.
+        sp_in = torch.empty(n * k, s + 3, h, w, dtype=torch.float32, device=dec.device)
+        fo = sp_in[:, s:]
         if fo_prev is not None:
             ops.dwconvT4x4s2(fo_prev, self._upsample_fo_weight(), out=fo)       # learned x2 of flow and occ
             inter_w = ops.backwarp(stacked, fo[:, :2], self.flow_mult)
@@ -273,15 +276,28 @@ class InterBlock(nn.Module):
         feat = m.convs[2](m.convs[1](m.convs[0](corr)))
         self._m_heads(feat, fo, accumulate=fo_prev is not None)
         del corr, feat, pa, pb, inter_w
-        # Subpixel: its input [dec | warped ctx | flow | occ] is assembled in place in sp_in
-        sp_in.view(n, k, 2 * s + 3, h, w)[:, :, :s].copy_(dec.unsqueeze(1))
-        ops.backwarp(stacked, fo[:, :2], self.flow_mult, out=sp_in[:, s:2 * s])
         sp = self.subpixel
-        feat = sp.convs[2](sp.convs[1](sp.convs[0](sp_in)))
+        w_dec, w_rest = self._sub0_split()
+        conv0 = sp.convs[0].conv
+        pre = ops.conv2d(dec, w_dec, None, conv0.out_channel, 3, pad=1)          # [N,128,H,W], before dec is blended
+        ops.backwarp(stacked, fo[:, :2], self.flow_mult, out=sp_in[:, :s])
+        feat = ops.conv2d(sp_in, w_rest, conv0.bias, conv0.out_channel, 3, pad=1, act=True, pre=pre, pre_div=k)
+        feat = sp.convs[2](sp.convs[1](feat))
         self._s_heads(feat, fo, accumulate=True)
-        del feat
+        del feat, pre
         ops.warp_fuse_blend(dec, stacked, fo[:, :2], fo[:, 2:3], self.flow_mult, k)
         return fo
+
+    def _sub0_split(self):
+        """First Subpixel conv split along its input channels: (dec block, [warped | flow | occ] block), both
+        with the FULL fan-in scale 1/sqrt((2s+3)*9) of the unsplit layer."""
+        conv = self.subpixel.convs[0].conv
+        w = conv.weight
+        key = (w.data_ptr(), w._version, w.device, ops.CONV_PRECISION)
+        if getattr(self, "_sub0", None) is None or self._sub0[0] != key:
+            s = self.feat_size
+            self._sub0 = (key, ops.pack_conv_weight(w[:, :s], scale=conv.scale), ops.pack_conv_weight(w[:, s:], scale=conv.scale))
+        return self._sub0[1], self._sub0[2]
 
     def forward(self, input, inters, flows=None, occs=None, toffs=None, eps=1e-6):
         """Reference signature (skip_autoencoder.py:246): returns (fused input, flows, occs, toffs)."""

@@ -110,8 +110,9 @@ def pack_conv_weight(weight, precision=None, scale=None):
 
 
 def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=False, residual=None,
-           out_scale=1.0, out=None, accumulate=False):
-    _need_gpu(x, w_packed.data, bias, residual, out)
+           out_scale=1.0, out=None, accumulate=False, pre=None, pre_div=1):
+    """y = [y +] (act(conv(x) [+ pre[n // pre_div]] + bias) [+ residual]) * out_scale."""
+    _need_gpu(x, w_packed.data, bias, residual, out, pre)
     x = _as_rows_dense(x)
     n, cin, h, w = x.shape
     assert w_packed.k == k and w_packed.cin == cin and w_packed.cout == cout, (w_packed.k, w_packed.cin, w_packed.cout, k, cin, cout)
@@ -132,6 +133,10 @@ def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=Fa
         residual = _as_rows_dense(residual)
         assert residual.shape == out.shape
         d.res_sN, d.res_sC = residual.stride(0), residual.stride(1)
+    if pre is not None:
+        pre = _as_rows_dense(pre)
+        assert pre.shape == (n // pre_div, cout, ho, wo) and n % pre_div == 0, (pre.shape, out.shape, pre_div)
+        d.pre, d.pre_sN, d.pre_sC, d.pre_div = pre.data_ptr(), pre.stride(0), pre.stride(1), pre_div
     d.kh, d.kw = k, kw
     d.stride, d.pad, d.transposed = stride, pad, 1 if transposed else 0
     d.act = ACT_LRELU if act else ACT_NONE

@@ -47,7 +47,7 @@ int ccvs_abi_version(void);
  *           (tap-major, then input channel, then output channel, CoutPad = Cout rounded up
  *           to 32, or to 64 when Cout >= 64; padding is zero).
  * transposed != 0: conv_transpose2d(stride 2, padding 0); Hout = 2*Hin + kh - 2.
- * y = [ y + ] ( act(conv + bias) [+ residual] ) * out_scale
+ * y = [ y + ] ( act(conv [+ pre] + bias) [+ residual] ) * out_scale
  *     the leading `y +` only when accumulate != 0.  bias / residual may be NULL.
  */
 typedef struct ccvs_conv_desc {
@@ -59,6 +59,12 @@ typedef struct ccvs_conv_desc {
     int32_t kh, kw, stride, pad, transposed;
     int32_t act, accumulate;
     float out_scale;
+    /* optional pre-activation addend: act(conv + pre[n / pre_div] + bias).  Lets the part of a convolution
+     * whose input is shared by pre_div consecutive batch items (the decoder feature that
+     * skip_autoencoder.py:251 repeats k times) be computed once and broadcast. */
+    const float* pre;
+    int64_t pre_sN, pre_sC;
+    int32_t pre_div;
 } ccvs_conv_desc;
 
 int ccvs_conv2d(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
