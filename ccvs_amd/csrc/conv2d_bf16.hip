@@ -216,20 +216,22 @@ __global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4
 //   producer threads) with j % nt == a, which are stored during step (c-1, a) and loaded one
 //   step before that.
 // ---------------------------------------------------------------------------------------
-#define CB_WR 6  // uint4 of tap-row weights per producer thread (ntx*4*NT <= 256*CB_WR)
-#define CB_XQ 2  // halo-tile pixel passes per producer thread per step (passes <= CB_XQ * nt)
+#define CB_XQ 1  // halo-tile pixel passes per producer thread per step (passes <= CB_XQ * nt)
 
-template <int TW, int MB>
-__global__ __launch_bounds__(512, 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
+// NPW = staging waves (4, or 8 when the MFMA work per staged byte is low: few output channels)
+template <int TW, int MB, int NPW>
+__global__ __launch_bounds__(256 + 64 * NPW, (MB == 1 && NPW == 4) ? 4 : 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
     constexpr int TH = 256 / TW;
     constexpr int NT = 32 * MB;
+    constexpr int NP = 64 * NPW;  // staging threads
+    constexpr int CB_WR = (3 * 4 * NT + NP - 1) / NP;  // uint4 of tap-row weights per staging thread (3 taps per row)
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (measured: making the role provably wave-uniform with readfirstlane, or s_setprio(1) on the MFMA
     //  waves, both cost ~25 % on the 195->128 3x3 shape with hipcc / ROCm 7.2 -- left as plain predication)
     const bool producer = wave >= 4;
-    const int rt = tid & 255, rw = wave & 3;  // thread / wave index inside the role
+    const int rt = producer ? tid - 256 : tid, rw = wave & 3;  // thread / wave index inside the role
     const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
     const int n0 = blockIdx.y * NT;
     int n = blockIdx.z, cls = 0;
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_bf16x3_pc_kernel(ConvK p, const
     int offs[CB_MAX_E];  // halo element -> plane offset; -2: no such element, -1: outside the image
 #pragma unroll
     for (int j = 0; j < CB_MAX_E; ++j) {
-        const int e = rt + 256 * j;
+        const int e = rt + NP * j;
         offs[j] = -2;
         if (producer && e < plane) {
             const int r = e / IW, c = e - r * IW;
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_bf16x3_pc_kernel(ConvK p, const
     int wofs[CB_WR];  // lane part of the weight address (uint4 units): tap column, half, hi|lo, cout
 #pragma unroll
     for (int i = 0; i < CB_WR; ++i) {
-        const int ic = min(rt + 256 * i, wunits - 1);
+        const int ic = min(rt + NP * i, wunits - 1);
         const int b = ic / (4 * NT), rem = ic - b * (4 * NT);
         const int hp = rem / NT, co = rem - hp * NT;
         wofs[i] = ((b * ax.dw * CinG + (hp >> 1)) * 2 + (hp & 1)) * p.CoutPad + co;
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_bf16x3_pc_kernel(ConvK p, const
     auto store_w = [&](uint4* dst) {
 #pragma unroll
         for (int i = 0; i < CB_WR; ++i)
-            if (rt + 256 * i < wunits) *reinterpret_cast<u32x4*>(dst + rt + 256 * i) = wraw[i];
+            if (rt + NP * i < wunits) *reinterpret_cast<u32x4*>(dst + rt + NP * i) = wraw[i];
     };
     auto load_x = [&](int c_, int slot) {
         xc0 = c_ * CB_CC;
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_bf16x3_pc_kernel(ConvK p, const
 #pragma unroll
         for (int q = 0; q < CB_XQ; ++q) {
             if (xoff[q] == -2) continue;
-            const int e = rt + 256 * (slot + q * nt);
+            const int e = rt + NP * (slot + q * nt);
             const bool plain = (xoff[q] >= 0) && (xc0 + CB_CC <= cin_);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -358,12 +360,12 @@ __global__ __launch_bounds__(512, 2) void conv2d_bf16x3_pc_kernel(ConvK p, const
         // prologue: chunk 0's halo tile and step 0's weights, synchronously and straight into LDS
         for (int j = 0; j < CB_MAX_E; ++j) {
             const int o = pix_offset(j);
-            if (o != -2) stage_pixel(xn, p.in_sC, p.Cin, 0, o, in_buf, plane, rt + 256 * j);
+            if (o != -2) stage_pixel(xn, p.in_sC, p.Cin, 0, o, in_buf, plane, rt + NP * j);
         }
         const uint4* base = wsplit + ((((long)ay_w0 * kw_ + ax_w0) * CinG) * 2) * cout_pad + n0;
 #pragma unroll
         for (int i = 0; i < CB_WR; ++i)
-            if (rt + 256 * i < wunits) w_buf[rt + 256 * i] = base[wofs[i]];
+            if (rt + NP * i < wunits) w_buf[rt + NP * i] = base[wofs[i]];
     }
 
     // Step -1 only lets the producers fetch the first register bundle (everyone meets at the barrier);
@@ -434,8 +436,9 @@ __global__ __launch_bounds__(512, 2) void conv2d_bf16x3_pc_kernel(ConvK p, const
             }
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx4 = tid + 512 * i;
+            for (int i = 0; i < (2048 + 255 + NP) / (256 + NP); ++i) {
+                const int idx4 = tid + (256 + NP) * i;
+                if (idx4 >= 2048) break;
                 const int col = idx4 >> 6, px = (idx4 & 63) * 4;
                 const int co = n0 + m * 32 + col;
                 const int prow = px / TW, pcol = px - prow * TW;
@@ -524,17 +527,23 @@ static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int ha
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_kernel<TW, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const size_t smem_pc = (size_t)(2 * 4 * plane + 2 * ntx_max * 4 * NT) * 16;
     const int nt_min = (k.transposed ? 1 : k.kh);               // fewest tap rows of any parity class
     const int passes = (plane + 255) / 256;
-    const bool regs_ok = (ntx_max * 4 * NT <= 256 * CB_WR) && (passes <= CB_XQ * nt_min);
+    const bool regs_ok = (ntx_max <= 3) && (passes <= CB_XQ * nt_min);
+    // (8 staging waves for <= 64 output channels were measured slower: the steps are latency- not staging-bound)
+    constexpr bool kManyStagers = false;
     if (smem_pc <= 156 * 1024 && regs_ok) {  // double-buffered producer / consumer form
         dim3 grid(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
         static const int ablate = getenv("CCVS_CONV_ABLATE") ? atoi(getenv("CCVS_CONV_ABLATE")) : 0;  // timing experiments only (1: no staging, 2: no MFMA)
-        hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB>), grid, dim3(512), smem_pc, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
+        if (kManyStagers)
+            hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 8>), grid, dim3(768), smem_pc, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
+        else
+            hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 4>), grid, dim3(512), smem_pc, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
         CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
         return CCVS_OK;
     }
