@@ -5,6 +5,58 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------
+// Software-pipelined decode step.  The ~120 launches of one token are a strict dependency chain of
+// short (5-15 us) kernels, each of which starts with a cold HBM stream of its weights.  Launching
+// them alternately on two HIP streams lets kernel k+1 start -- and put its weight loads in flight
+// -- while kernel k is still running; the true dependency is carried by a device counter instead
+// of the kernel boundary:
+//   * every workgroup of kernel k adds 1 to counter[k] after its last store (release, agent scope);
+//   * kernel k+1 issues the loads that do not depend on k, then one wave per workgroup polls
+//     counter[k] until it reaches (epoch + 1) * workgroups(k) (acquire), epoch being the
+//     device-resident number of completed steps, so counters never need resetting and a captured
+//     hipGraph replays as is;
+//   * stream order keeps k-1 -> k+1, so at most two kernels are resident (no deadlock: a polling
+//     kernel never fills the chip) and everything k+1 WRITES happens after k has fully finished:
+//     the result is bit-identical to the sequential schedule.
+// A poll that runs out of patience (~0.5 s) sets state[1] and lets the step finish (wrong, but the
+// device is not hung); the host checks that flag.
+// ---------------------------------------------------------------------------------------
+struct Chain {
+    int* state;         // [0] epoch (completed steps), [1] broken flag, [2] ticket of the final kernel
+    const int* wait;    // counter of the producer kernel (nullptr: nothing to wait for)
+    int wait_n;         // workgroups of the producer kernel
+    int* signal;        // this kernel's counter (nullptr: do not signal)
+};
+
+#define CHAIN_PATIENCE (1 << 20)
+
+// all threads of the workgroup; returns after the producer kernel's stores are visible
+__device__ __forceinline__ void chain_wait(const Chain& c) {
+    if (!c.wait) return;
+    if (threadIdx.x == 0) {
+        const int target = (c.state[0] + 1) * c.wait_n;
+        int spins = 0;
+        while (__hip_atomic_load(c.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255) == 0) {
+                if (__hip_atomic_load(c.state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if (spins > CHAIN_PATIENCE) { __hip_atomic_store(c.state + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// one wave, after the workgroup's last global store (which that wave issued)
+__device__ __forceinline__ void chain_signal(const Chain& c) {
+    if (!c.signal) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(c.signal, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------
 // x[(b,t)][:] = tok_emb[idx[b*idx_sB + t]] + pos_table[pos_off[b] + pos0 + t]
 // (mingpt.py:234-236,242-244; the factored s_emb/t_emb (+delta_length) or flat pos_emb rows
 // are pre-summed by the host into pos_table once per call).
@@ -12,7 +64,7 @@
 __global__ __launch_bounds__(256) void gpt_embed_kernel(const int64_t* __restrict__ idx, long idx_sB, const int32_t* __restrict__ pos_off,
                                                         int pos0, const int32_t* __restrict__ pos_dev, int Tq,
                                                         const float* __restrict__ tok, const float* __restrict__ pos,
-                                                        float* __restrict__ x, long total, int C, int vocab) {
+                                                        float* __restrict__ x, long total, int C, int vocab, Chain chain) {
     if (pos_dev) pos0 += *pos_dev;  // device-resident position: lets a captured hipGraph replay at advancing positions
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long r = i / C;
@@ -24,6 +76,12 @@ __global__ __launch_bounds__(256) void gpt_embed_kernel(const int64_t* __restric
         const long prow = (pos_off ? pos_off[b] : 0) + pos0 + tq;
         x[i] = tok[t * C + c] + pos[prow * C + c];
     }
+    if (chain.signal) {  // every wave's stores, then one count per workgroup
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(chain.signal, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 extern "C" int ccvs_gpt_embed(const int64_t* idx, int64_t idx_sB, const int32_t* pos_off, int32_t pos0, const int32_t* pos_dev, int32_t Tq,
@@ -32,7 +90,7 @@ extern "C" int ccvs_gpt_embed(const int64_t* idx, int64_t idx_sB, const int32_t*
     CCVS_REQUIRE(B > 0 && Tq > 0 && C > 0 && vocab > 0 && (pos0 >= 0 || pos_dev), "ccvs_gpt_embed: empty tensor");
     const long total = (long)B * Tq * C;
     hipLaunchKernelGGL(gpt_embed_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, idx, (long)idx_sB, pos_off,
-                       pos0, pos_dev, Tq, tok_emb, pos_table, x, total, C, vocab);
+                       pos0, pos_dev, Tq, tok_emb, pos_table, x, total, C, vocab, Chain{});
     CCVS_CHECK_LAUNCH("ccvs_gpt_embed");
     return CCVS_OK;
 }
@@ -95,6 +153,7 @@ struct Gemm16 {
     int kz;            // K slices across workgroups (gridDim.z); > 1 only with a workspace
     float* ws_slabs;   // [tile][kz][64 lanes][4] partial accumulators
     int* ws_count;     // [tile] arrival counters, zero between launches
+    Chain chain;       // decode-step pipelining (all null outside ccvs_gpt_decode_step)
 };
 
 #define GEMM_U 8  // K steps (of 16) whose loads are issued together
@@ -110,19 +169,30 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
     const int nrow = min(ncol0 + li, p.N - 1), mrow = min(m0 + li, p.M - 1);  // tails: computed on a valid row, dropped at the store
     const int kper = p.K / (p.ks * p.kz);
     const int kbase = blockIdx.z * (p.K / p.kz);
+    const bool active = wave < p.ks;
+    const float* wp = p.w + (long)nrow * p.K + kbase + (active ? wave : 0) * kper + 4 * g;
+    const float* xp = p.x + (long)mrow * p.ldx + kbase + (active ? wave : 0) * kper + 4 * g;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float sx = 0.f, sxx = 0.f;
-    if (wave < p.ks) {
-        const float* wp = p.w + (long)nrow * p.K + kbase + wave * kper + 4 * g;
-        const float* xp = p.x + (long)mrow * p.ldx + kbase + wave * kper + 4 * g;
+
+    // The first 128-deep batch of W does not depend on the producer kernel: put it in flight, THEN wait
+    // for the activations (decode shapes have kper == 128: that is the workgroup's whole weight tile).
+    const bool full = active && kper >= 16 * GEMM_U;
+    float4 wv[GEMM_U], xv[GEMM_U];
+    if (full) {
+#pragma unroll
+        for (int u = 0; u < GEMM_U; ++u) wv[u] = *reinterpret_cast<const float4*>(wp + 16 * u);
+    }
+    chain_wait(p.chain);
+
+    if (active) {
         // full batches: GEMM_U unconditional float4 loads of W and of x in flight per lane (no
         // predicated loads -- hipcc would serialise them), then the MFMAs
         int k0 = 0;
         for (; k0 + 16 * GEMM_U <= kper; k0 += 16 * GEMM_U) {
-            float4 wv[GEMM_U], xv[GEMM_U];
 #pragma unroll
             for (int u = 0; u < GEMM_U; ++u) {
-                wv[u] = *reinterpret_cast<const float4*>(wp + k0 + 16 * u);
+                if (k0 > 0) wv[u] = *reinterpret_cast<const float4*>(wp + k0 + 16 * u);
                 xv[u] = *reinterpret_cast<const float4*>(xp + k0 + 16 * u);
             }
 #pragma unroll
@@ -138,15 +208,15 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
             }
         }
         for (; k0 < kper; k0 += 16) {  // remainder (small K only)
-            const float4 wv = *reinterpret_cast<const float4*>(wp + k0);
-            const float4 xv = *reinterpret_cast<const float4*>(xp + k0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.x, wv.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.y, wv.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.z, wv.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.w, wv.w, acc1, 0, 0, 0);
+            const float4 w1 = *reinterpret_cast<const float4*>(wp + k0);
+            const float4 x1 = *reinterpret_cast<const float4*>(xp + k0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, w1.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, w1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, w1.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, w1.w, acc1, 0, 0, 0);
             if (p.ln_s) {
-                sx += (xv.x + xv.y) + (xv.z + xv.w);
-                sxx += (xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w);
+                sx += (x1.x + x1.y) + (x1.z + x1.w);
+                sxx += (x1.x * x1.x + x1.y * x1.y) + (x1.z * x1.z + x1.w * x1.w);
             }
         }
     }
@@ -167,10 +237,11 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
         fin[tid * 2 + 1] = rsqrtf(var + p.ln_eps);
     }
     __syncthreads();
-    if (wave > 0) return;
+    if (wave > 0) return;  // wave 0 finishes the tile (and is the one that signals the chain)
 #pragma unroll
     for (int s = 0; s < 7; ++s) acc += *reinterpret_cast<const f32x4*>(red + (s * 64 + lane) * 4);
 
+    bool finisher = true;
     if (p.kz > 1) {
         // K is also split over gridDim.z workgroups (few output columns: keeps all 256 CUs streaming W).
         // Each publishes its 16x16 partial, the LAST arriver sums the slabs in slice order (bitwise
@@ -186,41 +257,45 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
         int ticket = 0;
         if (lane == 0) ticket = __hip_atomic_fetch_add(p.ws_count + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
-        if (ticket != p.kz - 1) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        acc = *reinterpret_cast<const f32x4*>(slabs + lane * 4);
-        for (int z = 1; z < p.kz; ++z) acc += *reinterpret_cast<const f32x4*>(slabs + (z * 64 + lane) * 4);
-        if (lane == 0) __hip_atomic_store(p.ws_count + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        finisher = ticket == p.kz - 1;
+        if (finisher) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            acc = *reinterpret_cast<const f32x4*>(slabs + lane * 4);
+            for (int z = 1; z < p.kz; ++z) acc += *reinterpret_cast<const f32x4*>(slabs + (z * 64 + lane) * 4);
+            if (lane == 0) __hip_atomic_store(p.ws_count + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 
     // D[row = 4*g + r][col = li]
     const int col = ncol0 + li;
-    if (col >= p.N) return;
-    const float bv = p.bias ? p.bias[col] : 0.f;
-    const float sn = p.ln_s ? p.ln_s[col] : 0.f;
-    int pos0 = p.pos0;
-    if (p.kcache && p.pos_dev) pos0 += *p.pos_dev;
+    if (finisher && col < p.N) {
+        const float bv = p.bias ? p.bias[col] : 0.f;
+        const float sn = p.ln_s ? p.ln_s[col] : 0.f;
+        int pos0 = p.pos0;
+        if (p.kcache && p.pos_dev) pos0 += *p.pos_dev;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = m0 + 4 * g + r;
-        if (row >= p.M) continue;
-        float v = acc[r];
-        if (p.ln_s) v = fin[(4 * g + r) * 2 + 1] * (v - fin[(4 * g + r) * 2] * sn);
-        v += bv;
-        if (p.epi == 1) v = gelu_erf(v);
-        if (p.epi == 2) v += p.res[(long)row * p.ldy + col];
-        if (p.kcache && col >= p.C) {
-            const int cc = col - p.C;
-            float* cache = cc >= p.C ? p.vcache : p.kcache;
-            const int c2 = cc >= p.C ? cc - p.C : cc;
-            const int h = c2 / p.D, d = c2 - h * p.D;
-            const int b = row / p.Tq, t = row - b * p.Tq;
-            if (pos0 + t < p.Tmax) cache[(((long)b * p.H + h) * p.Tmax + pos0 + t) * p.D + d] = v;
-        } else {
-            p.y[(long)row * p.ldy + col] = v;
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 4 * g + r;
+            if (row >= p.M) continue;
+            float v = acc[r];
+            if (p.ln_s) v = fin[(4 * g + r) * 2 + 1] * (v - fin[(4 * g + r) * 2] * sn);
+            v += bv;
+            if (p.epi == 1) v = gelu_erf(v);
+            if (p.epi == 2) v += p.res[(long)row * p.ldy + col];
+            if (p.kcache && col >= p.C) {
+                const int cc = col - p.C;
+                float* cache = cc >= p.C ? p.vcache : p.kcache;
+                const int c2 = cc >= p.C ? cc - p.C : cc;
+                const int h = c2 / p.D, d = c2 - h * p.D;
+                const int b = row / p.Tq, t = row - b * p.Tq;
+                if (pos0 + t < p.Tmax) cache[(((long)b * p.H + h) * p.Tmax + pos0 + t) * p.D + d] = v;
+            } else {
+                p.y[(long)row * p.ldy + col] = v;
+            }
         }
     }
+    chain_signal(p.chain);  // every workgroup counts once, after its last store (partial slab or output tile)
 }
 
 static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
@@ -382,7 +457,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 template <int D>
 __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __restrict__ q, long q_sB, const float* __restrict__ kc,
                                                                const float* __restrict__ vc, float* __restrict__ out, int H, int pos0,
-                                                               const int32_t* __restrict__ pos_dev, int Tmax, float scale) {
+                                                               const int32_t* __restrict__ pos_dev, int Tmax, float scale, Chain chain) {
     constexpr int LPK = D / 4;     // lanes per key row
     constexpr int KPI = 64 / LPK;  // key rows per wave-instruction
     constexpr int NW = 8;
@@ -396,17 +471,29 @@ __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __re
     if (pos_dev) pos0 += *pos_dev;
     const int L = min(pos0 + 1, Tmax);
     const int kk = lane / LPK, d4 = lane - kk * LPK;
-    const float4 qv = *reinterpret_cast<const float4*>(q + (long)b * q_sB + h * D + 4 * d4);
     const float* kbase = kc + (long)bh * Tmax * D + 4 * d4;
     const float* vbase = vc + (long)bh * Tmax * D + 4 * d4;
 
     constexpr int AU = 8;  // key rows per lane whose loads are issued together (64 KiB in flight per workgroup)
-    float lmax = -INFINITY;
-    for (int j0 = wave * KPI; j0 < L; j0 += NW * KPI * AU) {
-        float4 kv[AU];
+    constexpr int BATCH = NW * KPI * AU;
+    // Only row L-1 of the cache is written by this step's QKV kernel: when the first batch of key rows lies
+    // entirely below it, those loads go out before the chain wait.
+    const bool early = chain.wait && L > BATCH;
+    float4 kv[AU];
+    if (early) {
 #pragma unroll
-        for (int u = 0; u < AU; ++u)  // unconditional loads from clamped rows (predicated loads would serialise)
-            kv[u] = *reinterpret_cast<const float4*>(kbase + (long)min(j0 + u * NW * KPI + kk, L - 1) * D);
+        for (int u = 0; u < AU; ++u) kv[u] = *reinterpret_cast<const float4*>(kbase + (long)(wave * KPI + u * NW * KPI + kk) * D);
+    }
+    chain_wait(chain);
+    const float4 qv = *reinterpret_cast<const float4*>(q + (long)b * q_sB + h * D + 4 * d4);
+
+    float lmax = -INFINITY;
+    for (int j0 = wave * KPI; j0 < L; j0 += BATCH) {
+        if (!(early && j0 < BATCH)) {
+#pragma unroll
+            for (int u = 0; u < AU; ++u)  // unconditional loads from clamped rows (predicated loads would serialise)
+                kv[u] = *reinterpret_cast<const float4*>(kbase + (long)min(j0 + u * NW * KPI + kk, L - 1) * D);
+        }
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
             const int j = j0 + u * NW * KPI + kk;
@@ -462,6 +549,7 @@ __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __re
             for (int s2 = 0; s2 < KPI; ++s2) o += pv[(w * 64 + s2 * LPK + dd4) * 4 + comp];
         out[(long)b * (H * D) + h * D + tid] = o / tot;
     }
+    if (wave == 0) chain_signal(chain);
 }
 
 extern "C" int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const float* kcache, const float* vcache, float* out, int32_t B,
@@ -477,9 +565,9 @@ extern "C" int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const f
         const size_t smem = (size_t)(16 + 8 * 256 + maxL) * sizeof(float);
         CCVS_REQUIRE(smem <= 64 * 1024, "ccvs_attention: sequence too long for the LDS score buffer");
         const dim3 grid((unsigned)(B * H));
-        if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
-        else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
-        else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
+        if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale, Chain{});
+        else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale, Chain{});
+        else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale, Chain{});
     } else {
         const size_t smem = (size_t)(80 + 256 + maxL) * sizeof(float);
         CCVS_REQUIRE(smem <= 64 * 1024, "ccvs_attention: sequence too long for the LDS score buffer");
@@ -512,8 +600,16 @@ __device__ __forceinline__ int block_sum_int(int v, int* red, int tid) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+struct Advance {       // decode-step bookkeeping folded into the sampling kernel (all null outside ccvs_gpt_decode_step)
+    int64_t* codes;    // [B][codes_sB] generated sequence: codes[b][*widx] = picked token
+    long codes_sB;
+    int32_t* widx;     // device-resident write index, +1 per step
+    int32_t* len;      // device-resident cache length, +1 per step
+};
+
 __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restrict__ logits, long ld, const float* __restrict__ noise,
-                                                          int64_t* __restrict__ out, long out_stride, int V, int top_k, float temperature) {
+                                                          int64_t* __restrict__ out, long out_stride, int V, int top_k, float temperature,
+                                                          Chain chain, Advance adv) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                 // [V]
     int* redi = (int*)(smem + V);     // [4]
@@ -522,6 +618,7 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const float* lr = logits + (long)b * ld;
+    chain_wait(chain);
     float lmax = -INFINITY;
     for (int j = tid; j < V; j += 256) {
         const float v = lr[j] / temperature;
@@ -574,6 +671,21 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
         for (int w = 1; w < 4; ++w)
             if (redf[w] > best || (redf[w] == best && redj[w] < bi)) { best = redf[w]; bi = redj[w]; }
         out[(long)b * out_stride] = bi;
+        if (adv.codes) {
+            adv.codes[(long)b * adv.codes_sB + *adv.widx] = bi;
+            // the last row to finish advances the device-resident counters (nobody reads them any more in this
+            // step: every other kernel has signalled completion down the chain) and closes the epoch
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const int ticket = __hip_atomic_fetch_add(chain.state + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == (int)gridDim.x - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                *adv.widx += 1;
+                *adv.len += 1;
+                chain.state[0] += 1;
+                __hip_atomic_store(chain.state + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -589,7 +701,151 @@ extern "C" int ccvs_sample_topk(const float* logits, int64_t ld, const float* no
     }
     CCVS_REQUIRE(smem <= 160 * 1024, "ccvs_sample_topk: vocabulary %d too large", V);
     hipLaunchKernelGGL(sample_topk_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, logits, (long)ld, noise, out, (long)out_stride, V,
-                       top_k, temperature);
+                       top_k, temperature, Chain{}, Advance{});
     CCVS_CHECK_LAUNCH("ccvs_sample_topk");
+    return CCVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// One decode step: the launch sequence of ccvs_gpt_embed / ccvs_gemm_ln_qkv / ccvs_attention /
+// ccvs_gemm_nt / ccvs_gemm_ln / ccvs_sample_topk for a single new position, software-pipelined
+// over two streams (Chain, top of this file).
+// ---------------------------------------------------------------------------------------
+#define CHAIN_HDR 8  // state words before the per-kernel counters
+
+extern "C" int32_t ccvs_gpt_decode_chain_words(int32_t n_layer) { return CHAIN_HDR + 5 * n_layer + 3; }
+
+extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream, void* stream2) {
+    CCVS_REQUIRE(d && d->layers && d->tok_emb && d->pos_table && d->head_w && d->head_b && d->head_s, "ccvs_gpt_decode_step: null pointer");
+    CCVS_REQUIRE(d->tok && d->codes && d->widx && d->len && d->x && d->q && d->att && d->h && d->logits && d->chain,
+                 "ccvs_gpt_decode_step: null state pointer");
+    CCVS_REQUIRE(d->B > 0 && d->C > 0 && d->H > 0 && d->C % d->H == 0 && d->F > 0 && d->n_layer > 0 && d->Tmax > 0 && d->vocab > 0 && d->V > 0,
+                 "ccvs_gpt_decode_step: bad shape");
+    const int D = d->C / d->H;
+    CCVS_REQUIRE(D == 64 || D == 32 || D == 16, "ccvs_gpt_decode_step: head dim %d unsupported (16, 32, 64)", D);
+    CCVS_REQUIRE(d->temperature > 0.f, "ccvs_gpt_decode_step: bad temperature");
+    const size_t smem_att = (size_t)(16 + 8 * 256 + d->Tmax) * sizeof(float);
+    const size_t smem_pick = (size_t)(d->V + 16) * sizeof(float);
+    CCVS_REQUIRE(smem_att <= 64 * 1024, "ccvs_gpt_decode_step: sequence too long for the LDS score buffer");
+    CCVS_REQUIRE(smem_pick <= 160 * 1024, "ccvs_gpt_decode_step: vocabulary %d too large", d->V);
+
+    hipStream_t st[2] = {(hipStream_t)stream, stream2 ? (hipStream_t)stream2 : (hipStream_t)stream};
+    const bool piped = stream2 != nullptr && stream2 != stream;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (piped && !ev_fork) {
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
+            ccvs_set_error("ccvs_gpt_decode_step: cannot create events");
+            return CCVS_ERR_LAUNCH;
+        }
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)sample_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (piped) {
+        if (hipEventRecord(ev_fork, st[0]) != hipSuccess || hipStreamWaitEvent(st[1], ev_fork, 0) != hipSuccess) {
+            ccvs_set_error("ccvs_gpt_decode_step: fork failed");
+            return CCVS_ERR_LAUNCH;
+        }
+    }
+
+    int* state = d->chain;
+    int* counters = d->chain + CHAIN_HDR;
+    const int last = 5 * d->n_layer + 2;
+    int k = 0, prev_n = 0;
+    // the link of kernel k: wait for kernel k-1 (prev_n workgroups), count on counters[k]
+    auto link = [&](int n_this) {
+        Chain c = {};
+        if (piped) {
+            c.state = state;
+            if (k > 0) { c.wait = counters + k - 1; c.wait_n = prev_n; }
+            if (k < last) c.signal = counters + k;
+        }
+        prev_n = n_this;
+        return c;
+    };
+    auto stream_of = [&](int kk) { return kk == last ? st[0] : st[kk & 1]; };
+
+    // 0: embedding of the last picked token at row pos_off + *len
+    {
+        const long total = (long)d->B * d->C;
+        const int nwg = (int)cdiv64(total, 256);
+        hipLaunchKernelGGL(gpt_embed_kernel, dim3(nwg), dim3(256), 0, stream_of(k), d->tok, 1L, (const int32_t*)nullptr, d->pos_off,
+                           (const int32_t*)d->len, 1, d->tok_emb, d->pos_table, d->x, total, d->C, d->vocab, link(nwg));
+        CCVS_CHECK_LAUNCH("ccvs_gpt_decode_step(embed)");
+        ++k;
+    }
+    auto gemm = [&](Gemm16& g, const char* name) -> int {
+        // launch_gemm16 fixes the grid; the link needs the workgroup count first
+        const int tiles = cdiv(g.N, 16) * cdiv(g.M, 16);
+        int kz = 1;
+        if (g.ws_slabs && !g.ln_s)
+            while (g.K >= 2048 && kz < 4 && tiles * kz * 2 <= 256 && g.K % (16 * 8 * kz * 2) == 0 && tiles <= GEMM_WS_TILES) kz *= 2;
+        g.chain = link(tiles * kz);
+        const int rc = launch_gemm16(g, stream_of(k), name);
+        ++k;
+        return rc;
+    };
+    float* ws_slabs = (float*)d->workspace;
+    int* ws_count = d->workspace ? (int*)((char*)d->workspace + (size_t)GEMM_WS_TILES * 4 * 256 * sizeof(float)) : nullptr;
+    const float scale = 1.0f / sqrtf((float)D);
+    for (int l = 0; l < d->n_layer; ++l) {
+        const ccvs_gpt_layer& L = d->layers[l];
+        CCVS_REQUIRE(L.qkv_w && L.qkv_b && L.qkv_s && L.proj_w && L.proj_b && L.fc_w && L.fc_b && L.fc_s && L.fc2_w && L.fc2_b && L.kcache && L.vcache,
+                     "ccvs_gpt_decode_step: null pointer in layer %d", l);
+        Gemm16 g = {};  // ln1 + QKV + cache scatter
+        g.x = d->x; g.ldx = d->C; g.w = L.qkv_w; g.bias = L.qkv_b; g.y = d->q; g.ldy = d->C; g.M = d->B; g.N = 3 * d->C; g.K = d->C;
+        g.ln_s = L.qkv_s; g.ln_eps = d->ln_eps;
+        g.kcache = L.kcache; g.vcache = L.vcache; g.C = d->C; g.H = d->H; g.D = D; g.Tq = 1; g.Tmax = d->Tmax; g.pos0 = 0; g.pos_dev = d->len;
+        int rc = gemm(g, "ccvs_gpt_decode_step(qkv)");
+        if (rc != CCVS_OK) return rc;
+        {   // attention over the cache
+            const dim3 grid((unsigned)(d->B * d->H));
+            const Chain c = link((int)grid.x);
+            hipStream_t s = stream_of(k);
+            if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(512), smem_att, s, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, d->Tmax, scale, c);
+            else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(512), smem_att, s, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, d->Tmax, scale, c);
+            else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(512), smem_att, s, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, d->Tmax, scale, c);
+            CCVS_CHECK_LAUNCH("ccvs_gpt_decode_step(attention)");
+            ++k;
+        }
+        g = Gemm16{};  // proj + residual (in place on x)
+        g.x = d->att; g.ldx = d->C; g.w = L.proj_w; g.bias = L.proj_b; g.res = d->x; g.y = d->x; g.ldy = d->C; g.M = d->B; g.N = d->C; g.K = d->C; g.epi = 2;
+        g.ws_slabs = ws_slabs; g.ws_count = ws_count;
+        if ((rc = gemm(g, "ccvs_gpt_decode_step(proj)")) != CCVS_OK) return rc;
+        g = Gemm16{};  // ln2 + fc + GELU
+        g.x = d->x; g.ldx = d->C; g.w = L.fc_w; g.bias = L.fc_b; g.y = d->h; g.ldy = d->F; g.M = d->B; g.N = d->F; g.K = d->C; g.epi = 1;
+        g.ln_s = L.fc_s; g.ln_eps = d->ln_eps;
+        if ((rc = gemm(g, "ccvs_gpt_decode_step(fc)")) != CCVS_OK) return rc;
+        g = Gemm16{};  // fc2 + residual (in place on x)
+        g.x = d->h; g.ldx = d->F; g.w = L.fc2_w; g.bias = L.fc2_b; g.res = d->x; g.y = d->x; g.ldy = d->C; g.M = d->B; g.N = d->C; g.K = d->F; g.epi = 2;
+        g.ws_slabs = ws_slabs; g.ws_count = ws_count;
+        if ((rc = gemm(g, "ccvs_gpt_decode_step(fc2)")) != CCVS_OK) return rc;
+    }
+    {   // ln_f + head
+        Gemm16 g = {};
+        g.x = d->x; g.ldx = d->C; g.w = d->head_w; g.bias = d->head_b; g.y = d->logits; g.ldy = d->V; g.M = d->B; g.N = d->V; g.K = d->C;
+        g.ln_s = d->head_s; g.ln_eps = d->ln_eps;
+        const int rc = gemm(g, "ccvs_gpt_decode_step(head)");
+        if (rc != CCVS_OK) return rc;
+    }
+    if (piped && (last & 1) == 0) {
+        // the head ran on stream2: close that branch (the pick below waits for it through the chain)
+        if (hipEventRecord(ev_join, st[1]) != hipSuccess) { ccvs_set_error("ccvs_gpt_decode_step: join failed"); return CCVS_ERR_LAUNCH; }
+    }
+    {   // pick + bookkeeping, always on `stream`
+        Chain c = link(d->B);
+        if (!piped) c.state = state;  // the ticket word is used in both modes
+        Advance adv = {d->codes, (long)d->codes_sB, d->widx, d->len};
+        hipLaunchKernelGGL(sample_topk_kernel, dim3(d->B), dim3(256), smem_pick, st[0], d->logits, (long)d->V, d->noise, d->tok, 1L, d->V,
+                           d->top_k, d->temperature, c, adv);
+        CCVS_CHECK_LAUNCH("ccvs_gpt_decode_step(pick)");
+    }
+    if (piped) {
+        if ((last & 1) != 0 && hipEventRecord(ev_join, st[1]) != hipSuccess) { ccvs_set_error("ccvs_gpt_decode_step: join failed"); return CCVS_ERR_LAUNCH; }
+        if (hipStreamWaitEvent(st[0], ev_join, 0) != hipSuccess) { ccvs_set_error("ccvs_gpt_decode_step: join failed"); return CCVS_ERR_LAUNCH; }
+    }
     return CCVS_OK;
 }

@@ -15,7 +15,7 @@ EXPORTS = [
     "ccvs_last_error", "ccvs_abi_version", "ccvs_conv2d", "ccvs_conv2d_bf16x3", "ccvs_upfirdn2d", "ccvs_dwconvT4x4s2",
     "ccvs_correlation7x7", "ccvs_backwarp", "ccvs_warp_fuse_blend", "ccvs_tap_shift_add", "ccvs_vq_argmin", "ccvs_embed_gather",
     "ccvs_gpt_embed", "ccvs_layernorm", "ccvs_gemm_workspace_bytes", "ccvs_gemm_nt", "ccvs_gemm_ln", "ccvs_gemm_ln_qkv", "ccvs_attention", "ccvs_kv_append", "ccvs_sample_topk",
-    "ccvs_pack_u8",
+    "ccvs_gpt_decode_chain_words", "ccvs_gpt_decode_step", "ccvs_pack_u8",
 ]
 
 
@@ -29,6 +29,28 @@ class ConvDesc(C.Structure):
         ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("transposed", C.c_int32),
         ("act", C.c_int32), ("accumulate", C.c_int32), ("out_scale", C.c_float),
         ("pre", C.c_void_p), ("pre_sN", C.c_int64), ("pre_sC", C.c_int64), ("pre_div", C.c_int32),
+    ]
+
+
+class GptLayer(C.Structure):
+    """Mirror of `ccvs_gpt_layer`."""
+    _fields_ = [(n, C.c_void_p) for n in ("qkv_w", "qkv_b", "qkv_s", "proj_w", "proj_b", "fc_w", "fc_b", "fc_s", "fc2_w", "fc2_b",
+                                          "kcache", "vcache")]
+
+
+class GptDecode(C.Structure):
+    """Mirror of `ccvs_gpt_decode`."""
+    _fields_ = [
+        ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("F", C.c_int32), ("n_layer", C.c_int32), ("Tmax", C.c_int32),
+        ("vocab", C.c_int32), ("V", C.c_int32), ("ln_eps", C.c_float),
+        ("layers", C.POINTER(GptLayer)),
+        ("tok_emb", C.c_void_p), ("pos_table", C.c_void_p), ("pos_off", C.c_int32),
+        ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("head_s", C.c_void_p),
+        ("tok", C.c_void_p), ("codes", C.c_void_p), ("codes_sB", C.c_int64),
+        ("widx", C.c_void_p), ("len", C.c_void_p),
+        ("x", C.c_void_p), ("q", C.c_void_p), ("att", C.c_void_p), ("h", C.c_void_p), ("logits", C.c_void_p),
+        ("noise", C.c_void_p), ("top_k", C.c_int32), ("temperature", C.c_float),
+        ("workspace", C.c_void_p), ("chain", C.c_void_p),
     ]
 
 
@@ -73,6 +95,8 @@ def load():
         "ccvs_attention": [vp, i64, i64, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp],
         "ccvs_kv_append": [vp, vp, i64, i64, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp],
         "ccvs_sample_topk": [vp, i64, vp, vp, i64, i32, i32, i32, f32, vp],
+        "ccvs_gpt_decode_chain_words": [i32],
+        "ccvs_gpt_decode_step": [C.POINTER(GptDecode), vp, vp],
         "ccvs_pack_u8": [vp, vp, i64, i32, i32, f32, f32, vp],
     }
     for name, argtypes in sigs.items():

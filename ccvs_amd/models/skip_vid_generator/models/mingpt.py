@@ -15,7 +15,14 @@ with the residual add in its epilogue, LayerNorm, MLP GEMMs with GELU / residual
 import torch
 import torch.nn as nn
 
+import os
+
 from .... import ops
+
+# Two-stream software pipelining of the decode step (include/ccvs_hip.h: ccvs_gpt_decode_step).  Bit-identical to the
+# one-stream schedule (tests/test_ops_gpu.py) but OFF by default: on ROCm 7.2 / MI355X kernels of one hipGraph that sit on
+# two hardware queues dispatch 20-40 us apart, so the pipelined step measured 4.15 ms/token against 1.32 ms on one stream.
+DECODE_PIPELINE = os.environ.get("CCVS_DECODE_PIPELINE", "0") == "1"
 
 
 class GPTConfig:
@@ -137,7 +144,7 @@ class GPT(nn.Module):
         self.apply(self._init_weights)
         self.config = config
         self._cache = None
-        self._lanes, self._graphs, self._side_stream = {}, {}, None
+        self._graphs, self._side_stream = {}, None
 
     def get_block_size(self):
         return self.block_size
@@ -179,26 +186,32 @@ class GPT(nn.Module):
 
     # ------------------------------------------------------------------ incremental engine
     @torch.no_grad()
-    def begin(self, batch, max_len, lane=0):
-        """Allocate (or reuse) the KV cache and the device-resident decode state of decode lane `lane`
-        for `batch` sequences of at most `max_len` positions, and make it the current lane."""
+    def begin(self, batch, max_len):
+        """Allocate (or reuse) the KV cache and the device-resident decode state for `batch` sequences of
+        at most `max_len` positions."""
         cfg = self.config
         assert max_len <= self.block_size, "Cannot forward, model block size is exhausted."  # mingpt.py:299
         dev = self.tok_emb.weight.device
         d = cfg.n_embd // cfg.n_head
-        if not hasattr(self, "_lanes"):
-            self._lanes, self._graphs, self._side_stream = {}, {}, None
-        c = self._lanes.get(lane)
+        c = self._cache
         if c is None or c["B"] != batch or c["T"] < max_len or c["dev"] != dev:
-            self._graphs = {k: v for k, v in self._graphs.items() if lane not in k[-1]}  # graphs hold the old buffers
-            kc = [torch.empty(batch, cfg.n_head, max_len, d, dtype=torch.float32, device=dev) for _ in range(cfg.n_layer)]
-            vc = [torch.empty(batch, cfg.n_head, max_len, d, dtype=torch.float32, device=dev) for _ in range(cfg.n_layer)]
-            c = self._lanes[lane] = {"B": batch, "T": max_len, "dev": dev, "k": kc, "v": vc,
-                               "len_dev": torch.zeros(1, dtype=torch.int32, device=dev),     # cache positions filled
-                               "tok": torch.zeros(batch, 1, dtype=torch.int64, device=dev),  # last sampled token
-                               "widx": torch.zeros(batch, 1, dtype=torch.int64, device=dev), # where the next token is stored
-                               "codes": torch.zeros(batch, max_len, dtype=torch.int64, device=dev)}
-        self._cache = c
+            self._graphs = {}  # captured graphs hold the old buffers
+            C, V = cfg.n_embd, self.head.weight.shape[0]
+            f32 = dict(dtype=torch.float32, device=dev)
+            kc = [torch.empty(batch, cfg.n_head, max_len, d, **f32) for _ in range(cfg.n_layer)]
+            vc = [torch.empty(batch, cfg.n_head, max_len, d, **f32) for _ in range(cfg.n_layer)]
+            c = self._cache = {
+                "B": batch, "T": max_len, "dev": dev, "k": kc, "v": vc,
+                "len_dev": torch.zeros(1, dtype=torch.int32, device=dev),      # cache positions filled
+                "widx": torch.zeros(1, dtype=torch.int32, device=dev),         # column of `codes` the next token goes to
+                "tok": torch.zeros(batch, 1, dtype=torch.int64, device=dev),   # last sampled token
+                "codes": torch.zeros(batch, max_len, dtype=torch.int64, device=dev),
+                # scratch of ccvs_gpt_decode_step
+                "x": torch.empty(batch, C, **f32), "q": torch.empty(batch, C, **f32), "att": torch.empty(batch, C, **f32),
+                "h": torch.empty(batch, 4 * C, **f32), "logits": torch.empty(batch, V, **f32), "noise": torch.empty(batch, V, **f32),
+                "chain": torch.zeros(ops.gpt_decode_chain_words(cfg.n_layer), dtype=torch.int32, device=dev),
+                "desc": None,
+            }
         c["len"] = 0
         table = self.get_pos_emb(min(c["T"], self.block_size))[0]
         if "pos_table" in c:
@@ -227,14 +240,17 @@ class GPT(nn.Module):
             c["len"] = pos0 + tq
         return x
 
-    def _head(self, x):
-        """ln_f folded into the (bias-free) head projection."""
+    def _head_packed(self):
+        """ln_f folded into the (bias-free) head projection: (key, (W*gamma, W beta, rowsum))."""
         src = (self.ln_f.weight, self.ln_f.bias, self.head.weight)
         key = tuple((t.data_ptr(), t._version) for t in src) + (src[0].device,)
         hf = getattr(self, "_head_folded", None)
         if hf is None or hf[0] != key:
             hf = self._head_folded = (key, ops.pack_ln_linear(self.head.weight, None, self.ln_f.weight, self.ln_f.bias))
-        return ops.gemm_ln(x, *hf[1], eps=self.ln_f.eps)
+        return hf
+
+    def _head(self, x):
+        return ops.gemm_ln(x, *self._head_packed()[1], eps=self.ln_f.eps)
 
     @torch.no_grad()
     def prefill(self, idx, cond_idx=None, delta_length_cond=None, all_logits=False):
@@ -278,106 +294,116 @@ class GPT(nn.Module):
         return self._head(x)
 
     # -- sampled generation: prefill + (add_len - 1) decode steps, all state on the device ----------
-    def _emit(self, logits, sampler, noise):
-        """Pick the next token from `logits` into c['tok'] and store it in c['codes'] at c['widx']."""
+    def _decode_desc(self, sampler):
+        """The `ccvs_gpt_decode` descriptor of the current cache (rebuilt when weights or sampler change)."""
+        c = self._cache
+        cfg = self.config
+        folded = [blk.folded() for blk in self.blocks]
+        head_key, (hw, hb, hs) = self._head_packed()
+        key = (tuple(blk._folded[0] for blk in self.blocks), head_key, sampler["sample"], sampler["top_k"],
+               sampler["temperature"], c["frame_pos0"])
+        if c["desc"] is None or c["desc"][0] != key:
+            layers = []
+            for i, blk in enumerate(self.blocks):
+                (qw, qb, qs), (fw, fb, fs) = folded[i]
+                layers.append(dict(qkv_w=qw, qkv_b=qb, qkv_s=qs, proj_w=blk.attn.proj.weight, proj_b=blk.attn.proj.bias,
+                                   fc_w=fw, fc_b=fb, fc_s=fs, fc2_w=blk.mlp[3].weight, fc2_b=blk.mlp[3].bias,
+                                   kcache=c["k"][i], vcache=c["v"][i]))
+            desc = ops.GptDecodeStep(
+                layers, B=c["B"], C=cfg.n_embd, H=cfg.n_head, Tmax=c["T"], ln_eps=self.ln_f.eps,
+                tok_emb=self.tok_emb.weight, pos_table=c["pos_table"], pos_off=-c["frame_pos0"], head=(hw, hb, hs),
+                tok=c["tok"], codes=c["codes"], widx=c["widx"], length=c["len_dev"],
+                x=c["x"], q=c["q"], att=c["att"], h=c["h"], logits=c["logits"],
+                noise=c["noise"] if sampler["sample"] else None, top_k=sampler["top_k"], temperature=sampler["temperature"],
+                chain=c["chain"])
+            c["desc"] = (key, desc)
+        return c["desc"][1]
+
+    def _emit(self, logits, sampler, noise, col):
+        """Pick the next token from `logits` into c['tok'] and store it in column `col` of c['codes']."""
         c = self._cache
         ops.sample_topk(logits, sampler["top_k"], sampler["temperature"], noise=noise, out=c["tok"])
-        c["codes"].scatter_(1, c["widx"], c["tok"])
-        c["widx"].add_(1)
+        c["codes"][:, col] = c["tok"][:, 0]
+        c["widx"].fill_(col + 1)
 
     def _decode_body(self, sampler, noise=None, trace=None):
-        """One decode step driven entirely by device-resident state, hence hipGraph-capturable:
-        embed c['tok'] at frame position len - frame_pos0, run the layers against the cache, pick
-        and store the next token, advance the counters."""
+        """One decode step driven entirely by device-resident state, hence hipGraph-capturable: embed
+        c['tok'] at frame position len - frame_pos0, run the layers against the cache, pick and store the
+        next token, advance the counters -- one `ccvs_gpt_decode_step` call whose launches are
+        software-pipelined over the current stream and a side stream (include/ccvs_hip.h)."""
         c = self._cache
-        b = c["B"]
-        x = ops.gpt_embed(c["tok"], self.tok_emb.weight, c["pos_table"], -c["frame_pos0"], None, c["len_dev"])
-        x = self._layers(x, b, 1, pos_dev=c["len_dev"])
-        logits = self._head(x)
+        desc = self._decode_desc(sampler)
+        if sampler["sample"]:
+            if noise is None:
+                c["noise"].exponential_(1)
+            else:
+                c["noise"].copy_(noise, non_blocking=True)
+        side = None
+        if DECODE_PIPELINE:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream()
+            side = self._side_stream
+        desc.launch(side)
         if trace is not None:
-            trace.append(logits.clone())
-        if noise is None and sampler["sample"] and sampler["noise"] == "device":
-            noise = torch.empty_like(logits).exponential_(1)
-        self._emit(logits, sampler, noise)
-        c["len_dev"].add_(1)
+            trace.append(c["logits"].clone())
+
+    def check_decode(self):
+        """Raise if a dependency wait of the pipelined decode step gave up (the tokens of that call are invalid)."""
+        c = self._cache
+        if c is not None and int(c["chain"][1].item()) != 0:
+            c["chain"].zero_()
+            raise RuntimeError("ccvs_gpt_decode_step: a pipelined dependency wait timed out; set CCVS_DECODE_PIPELINE=0")
 
     @torch.no_grad()
     def generate(self, code, add_len, cond_idx=None, delta_length_cond=None, sample=False, top_k=None, temperature=1.0,
-                 noise="device", host_noise=None, trace=None, use_graph=True, lanes=None):
+                 noise="device", host_noise=None, trace=None, use_graph=True):
         """code [B,t0] -> [B, t0+add_len]: one prefill, then KV-cached decode steps.
 
         With device (or no) noise and no trace the decode step is captured ONCE in a hipGraph and
-        replayed.  `lanes` > 1 additionally splits the batch into independent micro-batches whose steps are
-        captured as parallel branches of that graph (two HIP streams forked / joined per step) -- kept as an
-        option; it did not pay on this stack (see the default below).
-        With host-supplied noise (`host_noise(b, v) -> [B,V]`, reference-reproducible) it runs eagerly."""
+        replayed.  With host-supplied noise (`host_noise(b, v) -> [B,V]`, reference-reproducible) the same
+        step runs eagerly."""
         b, t0 = code.shape
         use_cond = cond_idx is not None and 0 not in cond_idx.size()
         n_cond = cond_idx.shape[1] if use_cond else 0
         sampler = {"sample": bool(sample), "top_k": top_k, "temperature": float(temperature), "noise": noise}
         eager = trace is not None or (sample and noise != "device") or not use_graph or add_len < 3
-        if lanes is None:
-            lanes = 1  # measured on MI355X / ROCm 7.2: two parallel graph branches run 25 % SLOWER than one chain
-                       # of full-batch launches (1.78 s vs 1.43 s per BAIR batch), so one lane is the default
-        if eager:
-            lanes = 1
-        per = b // lanes
         max_len = n_cond + t0 + add_len
-        caches = [self.begin(per, max_len, lane=i) for i in range(lanes)]
+        c = self.begin(b, max_len)
 
-        def on_lane(i, fn):
-            self._cache = caches[i]
-            return fn()
-
-        graph = None
-        if not eager:
-            key = (bool(sample), top_k, float(temperature), n_cond, per, tuple(range(lanes)))
-            graph = self._graphs.get(key)
-            if graph is None:
-                if self._side_stream is None:
-                    self._side_stream = torch.cuda.Stream()
-                side = self._side_stream
-                for c in caches:
-                    c["frame_pos0"] = n_cond
-                    c["len_dev"].fill_(n_cond)
-                    c["widx"].zero_()
-                    c["tok"].zero_()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):               # warm-up: one-time attribute calls, allocator
-                    for i in range(lanes):
-                        on_lane(i, lambda: self._decode_body(sampler))
-                torch.cuda.current_stream().wait_stream(side)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    main = torch.cuda.current_stream()
-                    if lanes > 1:
-                        side.wait_stream(main)              # fork
-                        with torch.cuda.stream(side):
-                            on_lane(1, lambda: self._decode_body(sampler))
-                    on_lane(0, lambda: self._decode_body(sampler))
-                    if lanes > 1:
-                        main.wait_stream(side)              # join
-                self._graphs[key] = graph
-
-        def draw(rows, logits):
+        def draw(logits):
             if not sample:
                 return None
             if noise == "device":
                 return torch.empty_like(logits).exponential_(1)
-            return host_noise(rows, logits.shape[1]).to(logits.device, non_blocking=True)
+            return host_noise(b, logits.shape[1]).to(logits.device, non_blocking=True)
 
-        for i, c in enumerate(caches):
-            rows = slice(i * per, (i + 1) * per)
-            self._cache = c
-            c["len"] = 0
-            logits = self.prefill(code[rows], cond_idx[rows] if use_cond else None,
-                                  (delta_length_cond[rows] if delta_length_cond.numel() == b else delta_length_cond) if use_cond else None)
-            if trace is not None:
-                trace.append(logits.clone())
-            c["codes"][:, :t0] = code[rows]
-            c["widx"].fill_(t0)
-            c["len_dev"].fill_(n_cond + t0)
-            self._emit(logits, sampler, draw(per, logits))
+        logits = self.prefill(code, cond_idx if use_cond else None, delta_length_cond if use_cond else None)
+        if trace is not None:
+            trace.append(logits.clone())
+        c["codes"][:, :t0] = code
+        c["len_dev"].fill_(n_cond + t0)
+        self._emit(logits, sampler, draw(logits), t0)
+
+        graph = None
+        if not eager:
+            key = (bool(sample), top_k, float(temperature), n_cond, b)
+            graph = self._graphs.get(key)
+            if graph is None:
+                # capture on live state: the warm-up step and the captured step are steps 1 and 2 of this very call
+                state = {k: c[k].clone() for k in ("len_dev", "widx", "tok", "codes")}
+                warm = torch.cuda.Stream()
+                warm.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(warm):               # warm-up: one-time attribute calls, descriptor, events
+                    self._decode_body(sampler)
+                torch.cuda.current_stream().wait_stream(warm)
+                for k, v in state.items():
+                    c[k].copy_(v)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._decode_body(sampler)
+                for k, v in state.items():                  # capture does not execute; restore is a no-op kept for clarity
+                    c[k].copy_(v)
+                self._graphs[key] = graph
         for _ in range(add_len - 1):
             if graph is not None:
                 graph.replay()
@@ -386,9 +412,10 @@ class GPT(nn.Module):
                 if sample and noise != "device":
                     nz = host_noise(b, self.head.weight.shape[0]).to(code.device, non_blocking=True)
                 self._decode_body(sampler, noise=nz, trace=trace)
-        for c in caches:
-            c["len"] = n_cond + t0 + add_len - 1
-        return torch.cat([c["codes"][:, :t0 + add_len] for c in caches], dim=0)
+        c["len"] = n_cond + t0 + add_len - 1
+        out = c["codes"][:, :t0 + add_len].clone()
+        self.check_decode()
+        return out
 
     # ------------------------------------------------------------------ reference-shaped forward
     @torch.no_grad()

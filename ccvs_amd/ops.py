@@ -411,6 +411,58 @@ def sample_topk(logits, top_k, temperature, noise=None, out=None):
     return out
 
 
+def gpt_decode_chain_words(n_layer):
+    return int(_lib.load().ccvs_gpt_decode_chain_words(int(n_layer)))
+
+
+class GptDecodeStep:
+    """A filled `ccvs_gpt_decode` descriptor (include/ccvs_hip.h) plus the tensors it points at.
+    `launch(side_stream)` enqueues one whole decode step on the current stream (pipelined over
+    `side_stream` when given)."""
+
+    def __init__(self, layers, B, C, H, Tmax, ln_eps, tok_emb, pos_table, pos_off, head, tok, codes, widx, length,
+                 x, q, att, h, logits, noise, top_k, temperature, chain):
+        hw, hb, hs = head
+        keep = [tok_emb, pos_table, hw, hb, hs, tok, codes, widx, length, x, q, att, h, logits, noise, chain]
+        for t in keep:
+            if t is not None:
+                _need_gpu(t)
+        f32 = [tok_emb, pos_table, hw, hb, hs, x, q, att, h, logits] + ([noise] if noise is not None else [])
+        assert all(t.dtype == torch.float32 and t.is_contiguous() for t in f32)
+        assert tok.dtype == torch.int64 and tok.numel() == B and tok.is_contiguous() and codes.dtype == torch.int64 and codes.stride(1) == 1
+        assert widx.dtype == torch.int32 and length.dtype == torch.int32 and chain.dtype == torch.int32
+        assert chain.numel() >= gpt_decode_chain_words(len(layers))
+        arr = (_lib.GptLayer * len(layers))()
+        for i, lay in enumerate(layers):
+            for name, t in lay.items():
+                t = t.detach()
+                _need_gpu(t)
+                assert t.dtype == torch.float32 and t.is_contiguous(), name
+                keep.append(t)
+                setattr(arr[i], name, _p(t))
+        F = layers[0]["fc_w"].shape[0]
+        assert x.shape == (B, C) and h.shape == (B, F) and logits.shape == (B, hw.shape[0])
+        self.ws = _gemm_workspace(x.device)
+        d = _lib.GptDecode()
+        d.B, d.C, d.H, d.F, d.n_layer, d.Tmax, d.vocab, d.V = B, C, H, F, len(layers), Tmax, tok_emb.shape[0], hw.shape[0]
+        d.ln_eps = ln_eps
+        d.layers = arr
+        d.tok_emb, d.pos_table, d.pos_off = _p(tok_emb.detach()), _p(pos_table), int(pos_off)
+        d.head_w, d.head_b, d.head_s = _p(hw), _p(hb), _p(hs)
+        d.tok, d.codes, d.codes_sB = _p(tok), _p(codes), codes.stride(0)
+        d.widx, d.len = _p(widx), _p(length)
+        d.x, d.q, d.att, d.h, d.logits = _p(x), _p(q), _p(att), _p(h), _p(logits)
+        d.noise = _p(noise)
+        d.top_k, d.temperature = 0 if top_k is None else int(top_k), float(temperature)
+        d.workspace, d.chain = _p(self.ws), _p(chain)
+        self.desc, self._arr, self._keep = d, arr, keep
+
+    def launch(self, side_stream=None):
+        L = _lib.load()
+        side = C.c_void_p(0) if side_stream is None else C.c_void_p(side_stream.cuda_stream)
+        _lib.check(L.ccvs_gpt_decode_step(C.byref(self.desc), _stream(), side), "ccvs_gpt_decode_step")
+
+
 def pack_u8(vid, lo=-1.0, hi=1.0):
     """[..., 3, H, W] fp32 -> [..., H, W, 3] uint8 (helpers/generator.py:306-309)."""
     _need_gpu(vid)

@@ -200,6 +200,44 @@ int ccvs_kv_append(const float* k, const float* v, int64_t sB, int64_t ld, float
 int ccvs_sample_topk(const float* logits, int64_t ld, const float* noise, int64_t* out, int64_t out_stride, int32_t B, int32_t V,
                      int32_t top_k, float temperature, void* stream);
 
+/* One whole KV-cached decode step of the sampling loop (transformer_model.py:395-409 calling
+ * mingpt.py:219-305 for ONE new position): embed `tok` -> n_layer x [ln1+QKV+cache | attention |
+ * proj+res | ln2+fc+GELU | fc2+res] -> ln_f+head -> get_icode pick -> codes[b][*widx] = tok[b] = pick;
+ * ++*widx; ++*len.  All per-step state is device-resident, so the call is hipGraph-capturable and a
+ * captured step replays unchanged.
+ * The ~5*n_layer+3 dependent launches are issued alternately on `stream` and `stream2` and chained by
+ * device counters in `chain`, so that each kernel's weight loads are in flight while its predecessor
+ * still runs (see gpt.hip); results are bit-identical to issuing the same kernels in order on one
+ * stream, which is what happens when stream2 is NULL.
+ * `chain`: int32[ccvs_gpt_decode_chain_words(n_layer)], zeroed by the caller once (and again whenever
+ * chain[1] != 0 was observed: a dependency wait ran out of patience and the step's result is invalid). */
+typedef struct ccvs_gpt_layer {
+    const float *qkv_w, *qkv_b, *qkv_s; /* ln1 folded into [q;k;v]: W*gamma [3C,C], b + W beta [3C], rowsum(W*gamma) [3C] */
+    const float *proj_w, *proj_b;       /* [C,C], [C] */
+    const float *fc_w, *fc_b, *fc_s;    /* ln2 folded into mlp[0]: [F,C], [F], [F] */
+    const float *fc2_w, *fc2_b;         /* mlp[3]: [C,F], [C] */
+    float *kcache, *vcache;             /* [B,H,Tmax,C/H] */
+} ccvs_gpt_layer;
+
+typedef struct ccvs_gpt_decode {
+    int32_t B, C, H, F, n_layer, Tmax, vocab, V; /* F = mlp width (4C); vocab = embedding rows; V = head outputs */
+    float ln_eps;
+    const ccvs_gpt_layer* layers;       /* host array [n_layer] */
+    const float *tok_emb, *pos_table;   /* [vocab,C]; [rows,C] pre-summed positional rows (as ccvs_gpt_embed) */
+    int32_t pos_off;                    /* embedding row of this step = pos_off + *len */
+    const float *head_w, *head_b, *head_s; /* ln_f folded into head: W*gamma [V,C], W beta [V], rowsum [V] */
+    int64_t* tok;                       /* [B] in: last token, out: picked token */
+    int64_t* codes; int64_t codes_sB;   /* generated sequences */
+    int32_t *widx, *len;                /* device-resident write index / cache length */
+    float *x, *q, *att, *h, *logits;    /* scratch [B,C] [B,C] [B,C] [B,F] [B,V] */
+    const float* noise;                 /* [B,V] Exp(1) noise, or NULL for greedy picks */
+    int32_t top_k; float temperature;
+    void* workspace;                    /* ccvs_gemm_workspace_bytes(), zeroed once */
+    int32_t* chain;
+} ccvs_gpt_decode;
+int32_t ccvs_gpt_decode_chain_words(int32_t n_layer);
+int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream, void* stream2);
+
 /* ---- output stage ---------------------------------------------------------------------
  * save_video_batch's clamp / rescale / x255 / uint8 / channels-last pack
  * (helpers/generator.py:306-309).  vid [N,3,H,W] fp32 in [lo,hi] -> out [N,H,W,3] u8. */

@@ -360,3 +360,38 @@ def test_gpt_embed_pack(ops):
     close(ops.gpt_embed(wide.cuda()[:, 4:5], tok.cuda(), pos.cuda(), 6), tok[wide[:, 4]] + pos[6], 0)
     vid = torch.randn(2, 3, 3, 9, 11) * 1.5
     assert torch.equal(ops.pack_u8(vid.cuda()).cpu(), O.pack_u8(vid))
+
+
+def test_gpt_decode_step_pipelined_matches_sequential(ops):
+    """ccvs_gpt_decode_step: two-stream software-pipelined launch == one-stream launch == per-op step(), bit for bit
+    (graph replay and eager), and the dependency chain never times out."""
+    from ccvs_amd.models.skip_vid_generator.models import mingpt
+    torch.manual_seed(3)
+    for n_embd, n_head in ((256, 4), (128, 8)):
+        net = mingpt.GPT(vocab_size=200, block_size=160, num_blocks=10, n_layer=3, n_head=n_head, n_embd=n_embd,
+                         emb_mode="temporal", shape=(4, 4)).cuda()
+        for p in net.parameters():  # non-trivial LayerNorm / bias values
+            p.data.add_(0.05 * torch.randn_like(p))
+        code = torch.randint(0, 200, (16, 16), device="cuda")
+        outs = {}
+        old = mingpt.DECODE_PIPELINE
+        try:
+            for pipe in (True, False):
+                mingpt.DECODE_PIPELINE = pipe
+                net._cache, net._graphs = None, {}
+                outs[("graph", pipe)] = net.generate(code, 100, sample=False, top_k=10).cpu()
+                outs[("eager", pipe)] = net.generate(code, 100, sample=False, top_k=10, use_graph=False).cpu()
+        finally:
+            mingpt.DECODE_PIPELINE = old
+        # per-op engine: prefill + step() + argmax
+        net.begin(16, 116)
+        logits = net.prefill(code)
+        seq = [code]
+        for i in range(100):
+            tok = logits.argmax(dim=-1, keepdim=True)
+            seq.append(tok)
+            if i < 99:
+                logits = net.step(tok)
+        want = torch.cat(seq, dim=1).cpu()
+        for k, v in outs.items():
+            assert torch.equal(v, want), k
