@@ -183,6 +183,21 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
 #pragma unroll
         for (int u = 0; u < GEMM_U; ++u) wv[u] = *reinterpret_cast<const float4*>(wp + 16 * u);
     }
+    // the finishing wave also fetches its epilogue operands now: after the K loop they would be a second
+    // dependent trip to memory (~1 us of a ~8 us kernel)
+    const int col = ncol0 + li;
+    float bv = 0.f, sn = 0.f, rv[4] = {0.f, 0.f, 0.f, 0.f};
+    int pos0 = p.pos0;
+    if (p.kcache && p.pos_dev) pos0 += *p.pos_dev;
+    if (wave == 0) {
+        const int colc = min(col, p.N - 1);
+        if (p.bias) bv = p.bias[colc];
+        if (p.ln_s) sn = p.ln_s[colc];
+        if (p.epi == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rv[r] = p.res[(long)min(m0 + 4 * g + r, p.M - 1) * p.ldy + colc];
+        }
+    }
     chain_wait(p.chain);
 
     if (active) {
@@ -268,12 +283,7 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
     }
 
     // D[row = 4*g + r][col = li]
-    const int col = ncol0 + li;
     if (finisher && col < p.N) {
-        const float bv = p.bias ? p.bias[col] : 0.f;
-        const float sn = p.ln_s ? p.ln_s[col] : 0.f;
-        int pos0 = p.pos0;
-        if (p.kcache && p.pos_dev) pos0 += *p.pos_dev;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + 4 * g + r;
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
             if (p.ln_s) v = fin[(4 * g + r) * 2 + 1] * (v - fin[(4 * g + r) * 2] * sn);
             v += bv;
             if (p.epi == 1) v = gelu_erf(v);
-            if (p.epi == 2) v += p.res[(long)row * p.ldy + col];
+            if (p.epi == 2) v += rv[r];
             if (p.kcache && col >= p.C) {
                 const int cc = col - p.C;
                 float* cache = cc >= p.C ? p.vcache : p.kcache;
@@ -591,13 +601,17 @@ __device__ __forceinline__ unsigned fkey(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__device__ __forceinline__ int block_sum_int(int v, int* red, int tid) {
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so every (row, element, step) gets its own draw
+// with no generator state to advance between hipGraph replays.
+__device__ __forceinline__ unsigned philox_first(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
 }
 
 struct Advance {       // decode-step bookkeeping folded into the sampling kernel (all null outside ccvs_gpt_decode_step)
@@ -605,16 +619,52 @@ struct Advance {       // decode-step bookkeeping folded into the sampling kerne
     long codes_sB;
     int32_t* widx;     // device-resident write index, +1 per step
     int32_t* len;      // device-resident cache length, +1 per step
+    int rng;           // draw the Exp(1) noise here: Philox keyed by chain.state[4..5], counter (element, row, step)
 };
+
+// k-th largest key of xs[0..V) by a 4-pass radix-256 descent (LDS histogram + suffix scan per pass).
+__device__ __forceinline__ unsigned kth_largest_key(const float* xs, int V, int top_k, int* hist, int* wtot, int* sel, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned prefix = 0u, mask = 0u;
+    int need = top_k;
+#pragma unroll 1
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        for (int j = tid; j < V; j += 256) {
+            const unsigned key = fkey(xs[j]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        const int h = hist[tid];
+        int s = h;  // suffix sum over bins >= tid
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_down(s, o, 64);
+            if (lane + o < 64) s += t;
+        }
+        if (lane == 0) wtot[wave] = s;
+        __syncthreads();
+        for (int w = wave + 1; w < 4; ++w) s += wtot[w];
+        if (s >= need && s - h < need) { sel[0] = tid; sel[1] = need - (s - h); }
+        __syncthreads();
+        prefix |= (unsigned)sel[0] << shift;
+        mask |= 255u << shift;
+        need = sel[1];
+    }
+    return prefix;
+}
 
 __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restrict__ logits, long ld, const float* __restrict__ noise,
                                                           int64_t* __restrict__ out, long out_stride, int V, int top_k, float temperature,
                                                           Chain chain, Advance adv) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;                 // [V]
-    int* redi = (int*)(smem + V);     // [4]
-    float* redf = smem + V + 4;       // [4]
-    int* redj = (int*)(smem + V + 8); // [4]
+    float* xs = smem;                  // [V]
+    float* redf = smem + V;            // [4]
+    int* redj = (int*)(smem + V + 4);  // [4]
+    int* wtot = (int*)(smem + V + 8);  // [4]
+    int* sel = (int*)(smem + V + 12);  // [2]
+    int* hist = (int*)(smem + V + 16); // [256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const float* lr = logits + (long)b * ld;
@@ -626,20 +676,12 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
         lmax = fmaxf(lmax, v);
     }
     lmax = wave_max(lmax);
-    __syncthreads();
     if (lane == 0) redf[wave] = lmax;
     __syncthreads();
     const float gmax = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
 
     unsigned thr = 0u;  // key of the k-th largest value; 0 keeps everything
-    if (top_k > 0 && top_k < V) {
-        for (int bit = 31; bit >= 0; --bit) {
-            const unsigned cand = thr | (1u << bit);
-            int cnt = 0;
-            for (int j = tid; j < V; j += 256) cnt += (fkey(xs[j]) >= cand) ? 1 : 0;
-            if (block_sum_int(cnt, redi, tid) >= top_k) thr = cand;
-        }
-    }
+    if (top_k > 0 && top_k < V) thr = kth_largest_key(xs, V, top_k, hist, wtot, sel, tid);
     float lsum = 0.f;
     for (int j = tid; j < V; j += 256) {
         const float e = (fkey(xs[j]) >= thr) ? expf(xs[j] - gmax) : 0.f;
@@ -651,11 +693,17 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
     if (lane == 0) redf[wave] = lsum;
     __syncthreads();
     const float tot = ((redf[0] + redf[1]) + redf[2]) + redf[3];
+    unsigned k0 = 0u, k1 = 0u, step = 0u;
+    if (adv.rng) { k0 = (unsigned)chain.state[4]; k1 = (unsigned)chain.state[5]; step = (unsigned)chain.state[0]; }
     float best = -1.f;
     int bi = 0x7fffffff;
     for (int j = tid; j < V; j += 256) {
         float p = xs[j] / tot;
         if (noise) p = p / noise[(long)b * V + j];
+        else if (adv.rng) {
+            const float u = ((float)philox_first((unsigned)j, (unsigned)b, step, 0u, k0, k1) + 0.5f) * 2.3283064365386963e-10f;  // (0, 1]
+            p = p / fmaxf(-logf(u), 1e-30f);
+        }
         if (p > best) { best = p; bi = j; }
     }
 #pragma unroll
@@ -689,11 +737,13 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
     }
 }
 
+#define PICK_SMEM_WORDS(V) ((V) + 16 + 256)
+
 extern "C" int ccvs_sample_topk(const float* logits, int64_t ld, const float* noise, int64_t* out, int64_t out_stride, int32_t B, int32_t V,
                                 int32_t top_k, float temperature, void* stream) {
     CCVS_REQUIRE(logits && out, "ccvs_sample_topk: null pointer");
     CCVS_REQUIRE(B > 0 && V > 0 && temperature > 0.f, "ccvs_sample_topk: bad arguments");
-    const size_t smem = (size_t)(V + 16) * sizeof(float);
+    const size_t smem = (size_t)PICK_SMEM_WORDS(V) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)sample_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -725,7 +775,7 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream, void
     CCVS_REQUIRE(D == 64 || D == 32 || D == 16, "ccvs_gpt_decode_step: head dim %d unsupported (16, 32, 64)", D);
     CCVS_REQUIRE(d->temperature > 0.f, "ccvs_gpt_decode_step: bad temperature");
     const size_t smem_att = (size_t)(16 + 8 * 256 + d->Tmax) * sizeof(float);
-    const size_t smem_pick = (size_t)(d->V + 16) * sizeof(float);
+    const size_t smem_pick = (size_t)PICK_SMEM_WORDS(d->V) * sizeof(float);
     CCVS_REQUIRE(smem_att <= 64 * 1024, "ccvs_gpt_decode_step: sequence too long for the LDS score buffer");
     CCVS_REQUIRE(smem_pick <= 160 * 1024, "ccvs_gpt_decode_step: vocabulary %d too large", d->V);
 
@@ -838,7 +888,7 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream, void
     {   // pick + bookkeeping, always on `stream`
         Chain c = link(d->B);
         if (!piped) c.state = state;  // the ticket word is used in both modes
-        Advance adv = {d->codes, (long)d->codes_sB, d->widx, d->len};
+        Advance adv = {d->codes, (long)d->codes_sB, d->widx, d->len, (d->rng && !d->noise) ? 1 : 0};
         hipLaunchKernelGGL(sample_topk_kernel, dim3(d->B), dim3(256), smem_pick, st[0], d->logits, (long)d->V, d->noise, d->tok, 1L, d->V,
                            d->top_k, d->temperature, c, adv);
         CCVS_CHECK_LAUNCH("ccvs_gpt_decode_step(pick)");

@@ -49,7 +49,7 @@ class GptDecode(C.Structure):
         ("tok", C.c_void_p), ("codes", C.c_void_p), ("codes_sB", C.c_int64),
         ("widx", C.c_void_p), ("len", C.c_void_p),
         ("x", C.c_void_p), ("q", C.c_void_p), ("att", C.c_void_p), ("h", C.c_void_p), ("logits", C.c_void_p),
-        ("noise", C.c_void_p), ("top_k", C.c_int32), ("temperature", C.c_float),
+        ("noise", C.c_void_p), ("rng", C.c_int32), ("top_k", C.c_int32), ("temperature", C.c_float),
         ("workspace", C.c_void_p), ("chain", C.c_void_p),
     ]
 

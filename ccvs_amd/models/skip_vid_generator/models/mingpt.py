@@ -300,8 +300,9 @@ class GPT(nn.Module):
         cfg = self.config
         folded = [blk.folded() for blk in self.blocks]
         head_key, (hw, hb, hs) = self._head_packed()
+        device_rng = sampler["sample"] and sampler["noise"] == "device"
         key = (tuple(blk._folded[0] for blk in self.blocks), head_key, sampler["sample"], sampler["top_k"],
-               sampler["temperature"], c["frame_pos0"])
+               sampler["temperature"], device_rng, c["frame_pos0"])
         if c["desc"] is None or c["desc"][0] != key:
             layers = []
             for i, blk in enumerate(self.blocks):
@@ -314,8 +315,8 @@ class GPT(nn.Module):
                 tok_emb=self.tok_emb.weight, pos_table=c["pos_table"], pos_off=-c["frame_pos0"], head=(hw, hb, hs),
                 tok=c["tok"], codes=c["codes"], widx=c["widx"], length=c["len_dev"],
                 x=c["x"], q=c["q"], att=c["att"], h=c["h"], logits=c["logits"],
-                noise=c["noise"] if sampler["sample"] else None, top_k=sampler["top_k"], temperature=sampler["temperature"],
-                chain=c["chain"])
+                noise=c["noise"] if (sampler["sample"] and not device_rng) else None, rng=device_rng,
+                top_k=sampler["top_k"], temperature=sampler["temperature"], chain=c["chain"])
             c["desc"] = (key, desc)
         return c["desc"][1]
 
@@ -333,11 +334,8 @@ class GPT(nn.Module):
         software-pipelined over the current stream and a side stream (include/ccvs_hip.h)."""
         c = self._cache
         desc = self._decode_desc(sampler)
-        if sampler["sample"]:
-            if noise is None:
-                c["noise"].exponential_(1)
-            else:
-                c["noise"].copy_(noise, non_blocking=True)
+        if sampler["sample"] and sampler["noise"] != "device":
+            c["noise"].copy_(noise, non_blocking=True)   # host-drawn Exp(1) noise (reference-reproducible stream)
         side = None
         if DECODE_PIPELINE:
             if self._side_stream is None:
@@ -382,6 +380,9 @@ class GPT(nn.Module):
             trace.append(logits.clone())
         c["codes"][:, :t0] = code
         c["len_dev"].fill_(n_cond + t0)
+        c["chain"].zero_()                # step counter (= Philox counter word) and pipelining counters restart with the call
+        if sample and noise == "device":  # key of the in-kernel Philox draws, from torch's generator (honours torch.manual_seed)
+            c["chain"][4:6] = torch.randint(-2**31, 2**31 - 1, (2,), dtype=torch.int64).to(torch.int32).to(c["chain"].device)
         self._emit(logits, sampler, draw(logits), t0)
 
         graph = None
@@ -390,7 +391,7 @@ class GPT(nn.Module):
             graph = self._graphs.get(key)
             if graph is None:
                 # capture on live state: the warm-up step and the captured step are steps 1 and 2 of this very call
-                state = {k: c[k].clone() for k in ("len_dev", "widx", "tok", "codes")}
+                state = {k: c[k].clone() for k in ("len_dev", "widx", "tok", "codes", "chain")}
                 warm = torch.cuda.Stream()
                 warm.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(warm):               # warm-up: one-time attribute calls, descriptor, events

@@ -421,7 +421,7 @@ class GptDecodeStep:
     `side_stream` when given)."""
 
     def __init__(self, layers, B, C, H, Tmax, ln_eps, tok_emb, pos_table, pos_off, head, tok, codes, widx, length,
-                 x, q, att, h, logits, noise, top_k, temperature, chain):
+                 x, q, att, h, logits, noise, top_k, temperature, chain, rng=False):
         hw, hb, hs = head
         keep = [tok_emb, pos_table, hw, hb, hs, tok, codes, widx, length, x, q, att, h, logits, noise, chain]
         for t in keep:
@@ -453,6 +453,7 @@ class GptDecodeStep:
         d.widx, d.len = _p(widx), _p(length)
         d.x, d.q, d.att, d.h, d.logits = _p(x), _p(q), _p(att), _p(h), _p(logits)
         d.noise = _p(noise)
+        d.rng = 1 if (rng and noise is None) else 0
         d.top_k, d.temperature = 0 if top_k is None else int(top_k), float(temperature)
         d.workspace, d.chain = _p(self.ws), _p(chain)
         self.desc, self._arr, self._keep = d, arr, keep

@@ -209,7 +209,7 @@ int ccvs_sample_topk(const float* logits, int64_t ld, const float* noise, int64_
  * device counters in `chain`, so that each kernel's weight loads are in flight while its predecessor
  * still runs (see gpt.hip); results are bit-identical to issuing the same kernels in order on one
  * stream, which is what happens when stream2 is NULL.
- * `chain`: int32[ccvs_gpt_decode_chain_words(n_layer)], zeroed by the caller once (and again whenever
+ * `chain`: int32[ccvs_gpt_decode_chain_words(n_layer)] ([0] completed steps, [1] broken flag, [4..5] RNG key), zeroed by the caller once (and again whenever
  * chain[1] != 0 was observed: a dependency wait ran out of patience and the step's result is invalid). */
 typedef struct ccvs_gpt_layer {
     const float *qkv_w, *qkv_b, *qkv_s; /* ln1 folded into [q;k;v]: W*gamma [3C,C], b + W beta [3C], rowsum(W*gamma) [3C] */
@@ -230,7 +230,9 @@ typedef struct ccvs_gpt_decode {
     int64_t* codes; int64_t codes_sB;   /* generated sequences */
     int32_t *widx, *len;                /* device-resident write index / cache length */
     float *x, *q, *att, *h, *logits;    /* scratch [B,C] [B,C] [B,C] [B,F] [B,V] */
-    const float* noise;                 /* [B,V] Exp(1) noise, or NULL for greedy picks */
+    const float* noise;                 /* [B,V] Exp(1) noise (host-reproducible sampling), or NULL */
+    int32_t rng;                        /* noise == NULL: 0 greedy pick, 1 draw the Exp(1) noise in the kernel (Philox4x32-10,
+                                           key = chain[4..5] set by the caller, counter = (element, row, step)) */
     int32_t top_k; float temperature;
     void* workspace;                    /* ccvs_gemm_workspace_bytes(), zeroed once */
     int32_t* chain;

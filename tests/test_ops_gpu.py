@@ -395,3 +395,37 @@ def test_gpt_decode_step_pipelined_matches_sequential(ops):
         want = torch.cat(seq, dim=1).cpu()
         for k, v in outs.items():
             assert torch.equal(v, want), k
+
+
+def test_gpt_decode_device_rng_sampling(ops):
+    """In-kernel Philox noise: argmax(p / Exp(1)) draws from p -- uniform logits give uniform tokens; the key comes from
+    torch's generator (same seed -> same tokens, new seed -> new tokens); top-k restricts the support."""
+    from ccvs_amd.models.skip_vid_generator.models import mingpt
+    torch.manual_seed(5)
+    net = mingpt.GPT(vocab_size=16, block_size=512, num_blocks=32, n_layer=1, n_head=2, n_embd=32, emb_mode="temporal", shape=(4, 4)).cuda()
+    with torch.no_grad():
+        net.head.weight.zero_()  # logits == 0: uniform over the vocabulary
+    code = torch.zeros(16, 1, dtype=torch.int64, device="cuda")
+    torch.manual_seed(11)
+    a = net.generate(code, 400, sample=True, top_k=None).cpu()[:, 1:]
+    torch.manual_seed(11)
+    b = net.generate(code, 400, sample=True, top_k=None).cpu()[:, 1:]
+    c = net.generate(code, 400, sample=True, top_k=None).cpu()[:, 1:]
+    assert torch.equal(a[:, 1:], b[:, 1:]) and not torch.equal(a[:, 1:], c[:, 1:])  # column 0 is the prefill pick (torch noise)
+    counts = torch.bincount(a.reshape(-1), minlength=16).float()
+    assert counts.sum() == 16 * 400
+    assert (counts - 400).abs().max() < 5 * (400 * 15 / 16) ** 0.5, counts  # 5 sigma of a binomial bin
+    assert (a[0] != a[1]).float().mean() > 0.8 and (a[:, 1:] != a[:, :-1]).float().mean() > 0.8  # rows / steps independent
+    # skewed distribution + top-k: only the k most likely tokens appear, in the right proportions
+    lg = torch.log(torch.tensor([8.0, 4.0, 2.0, 1.0] + [0.5] * 12, device="cuda"))
+    with torch.no_grad():  # in-place on the parameters themselves: bumps their version, so the folded weights are re-packed
+        net.head.weight.zero_()
+        net.head.weight[:, 0] = lg
+        net.ln_f.weight.zero_()  # LN output == bias = e0: logits = lg exactly
+        net.ln_f.bias.zero_()
+        net.ln_f.bias[0] = 1.0
+    d = net.generate(code, 400, sample=True, top_k=3).cpu()[:, 2:]
+    cnt = torch.bincount(d.reshape(-1), minlength=16).float()
+    assert cnt[3:].sum() == 0
+    frac = cnt[:3] / cnt.sum()
+    assert (frac - torch.tensor([8.0, 4.0, 2.0]) / 14.0).abs().max() < 0.03, frac
