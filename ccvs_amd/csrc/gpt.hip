@@ -3,58 +3,7 @@
 // Reference: models/skip_vid_generator/models/mingpt.py:33-117,186-305 and
 // models/skip_vid_generator/models/transformer_model.py:256-260,395-409.
 #include "common.h"
-
-// ---------------------------------------------------------------------------------------
-// Software-pipelined decode step.  The ~120 launches of one token are a strict dependency chain of
-// short (5-15 us) kernels, each of which starts with a cold HBM stream of its weights.  Launching
-// them alternately on two HIP streams lets kernel k+1 start -- and put its weight loads in flight
-// -- while kernel k is still running; the true dependency is carried by a device counter instead
-// of the kernel boundary:
-//   * every workgroup of kernel k adds 1 to counter[k] after its last store (release, agent scope);
-//   * kernel k+1 issues the loads that do not depend on k, then one wave per workgroup polls
-//     counter[k] until it reaches (epoch + 1) * workgroups(k) (acquire), epoch being the
-//     device-resident number of completed steps, so counters never need resetting and a captured
-//     hipGraph replays as is;
-//   * stream order keeps k-1 -> k+1, so at most two kernels are resident (no deadlock: a polling
-//     kernel never fills the chip) and everything k+1 WRITES happens after k has fully finished:
-//     the result is bit-identical to the sequential schedule.
-// A poll that runs out of patience (~0.5 s) sets state[1] and lets the step finish (wrong, but the
-// device is not hung); the host checks that flag.
-// ---------------------------------------------------------------------------------------
-struct Chain {
-    int* state;         // [0] epoch (completed steps), [1] broken flag, [2] ticket of the final kernel
-    const int* wait;    // counter of the producer kernel (nullptr: nothing to wait for)
-    int wait_n;         // workgroups of the producer kernel
-    int* signal;        // this kernel's counter (nullptr: do not signal)
-};
-
-#define CHAIN_PATIENCE (1 << 20)
-
-// all threads of the workgroup; returns after the producer kernel's stores are visible
-__device__ __forceinline__ void chain_wait(const Chain& c) {
-    if (!c.wait) return;
-    if (threadIdx.x == 0) {
-        const int target = (c.state[0] + 1) * c.wait_n;
-        int spins = 0;
-        while (__hip_atomic_load(c.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 255) == 0) {
-                if (__hip_atomic_load(c.state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                if (spins > CHAIN_PATIENCE) { __hip_atomic_store(c.state + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-
-// one wave, after the workgroup's last global store (which that wave issued)
-__device__ __forceinline__ void chain_signal(const Chain& c) {
-    if (!c.signal) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(c.signal, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------
 // x[(b,t)][:] = tok_emb[idx[b*idx_sB + t]] + pos_table[pos_off[b] + pos0 + t]
@@ -64,7 +13,7 @@ __device__ __forceinline__ void chain_signal(const Chain& c) {
 __global__ __launch_bounds__(256) void gpt_embed_kernel(const int64_t* __restrict__ idx, long idx_sB, const int32_t* __restrict__ pos_off,
                                                         int pos0, const int32_t* __restrict__ pos_dev, int Tq,
                                                         const float* __restrict__ tok, const float* __restrict__ pos,
-                                                        float* __restrict__ x, long total, int C, int vocab, Chain chain) {
+                                                        float* __restrict__ x, long total, int C, int vocab) {
     if (pos_dev) pos0 += *pos_dev;  // device-resident position: lets a captured hipGraph replay at advancing positions
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long r = i / C;
@@ -76,12 +25,6 @@ __global__ __launch_bounds__(256) void gpt_embed_kernel(const int64_t* __restric
         const long prow = (pos_off ? pos_off[b] : 0) + pos0 + tq;
         x[i] = tok[t * C + c] + pos[prow * C + c];
     }
-    if (chain.signal) {  // every wave's stores, then one count per workgroup
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(chain.signal, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 extern "C" int ccvs_gpt_embed(const int64_t* idx, int64_t idx_sB, const int32_t* pos_off, int32_t pos0, const int32_t* pos_dev, int32_t Tq,
@@ -90,7 +33,7 @@ extern "C" int ccvs_gpt_embed(const int64_t* idx, int64_t idx_sB, const int32_t*
     CCVS_REQUIRE(B > 0 && Tq > 0 && C > 0 && vocab > 0 && (pos0 >= 0 || pos_dev), "ccvs_gpt_embed: empty tensor");
     const long total = (long)B * Tq * C;
     hipLaunchKernelGGL(gpt_embed_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, idx, (long)idx_sB, pos_off,
-                       pos0, pos_dev, Tq, tok_emb, pos_table, x, total, C, vocab, Chain{});
+                       pos0, pos_dev, Tq, tok_emb, pos_table, x, total, C, vocab);
     CCVS_CHECK_LAUNCH("ccvs_gpt_embed");
     return CCVS_OK;
 }
@@ -153,7 +96,6 @@ struct Gemm16 {
     int kz;            // K slices across workgroups (gridDim.z); > 1 only with a workspace
     float* ws_slabs;   // [tile][kz][64 lanes][4] partial accumulators
     int* ws_count;     // [tile] arrival counters, zero between launches
-    Chain chain;       // decode-step pipelining (all null outside ccvs_gpt_decode_step)
 };
 
 #define GEMM_U 8  // K steps (of 16) whose loads are issued together
@@ -175,8 +117,7 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float sx = 0.f, sxx = 0.f;
 
-    // The first 128-deep batch of W does not depend on the producer kernel: put it in flight, THEN wait
-    // for the activations (decode shapes have kper == 128: that is the workgroup's whole weight tile).
+    // first 128-deep batch of W (decode shapes have kper == 128: the workgroup's whole weight tile) goes out first
     const bool full = active && kper >= 16 * GEMM_U;
     float4 wv[GEMM_U], xv[GEMM_U];
     if (full) {
@@ -198,8 +139,6 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
             for (int r = 0; r < 4; ++r) rv[r] = p.res[(long)min(m0 + 4 * g + r, p.M - 1) * p.ldy + colc];
         }
     }
-    chain_wait(p.chain);
-
     if (active) {
         // full batches: GEMM_U unconditional float4 loads of W and of x in flight per lane (no
         // predicated loads -- hipcc would serialise them), then the MFMAs
@@ -252,7 +191,7 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
         fin[tid * 2 + 1] = rsqrtf(var + p.ln_eps);
     }
     __syncthreads();
-    if (wave > 0) return;  // wave 0 finishes the tile (and is the one that signals the chain)
+    if (wave > 0) return;  // wave 0 finishes the tile
 #pragma unroll
     for (int s = 0; s < 7; ++s) acc += *reinterpret_cast<const f32x4*>(red + (s * 64 + lane) * 4);
 
@@ -260,24 +199,27 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
     if (p.kz > 1) {
         // K is also split over gridDim.z workgroups (few output columns: keeps all 256 CUs streaming W).
         // Each publishes its 16x16 partial, the LAST arriver sums the slabs in slice order (bitwise
-        // reproducible) and runs the epilogue.  One wave does all of it: slab stores -> vmcnt(0) ->
-        // agent release -> ticket; the reducer: agent acquire -> plain loads (cdna_hip_programming.md
-        // section 6 Guideline 16, counter form).  The reducer re-zeroes the counter for the next launch.
+        // reproducible) and runs the epilogue.  The slabs are written and read with agent-scope (sc1)
+        // accesses, which go through to memory and bypass the per-XCD L2s: no release / acquire fence is
+        // needed -- on this chip a fence is an L2 write-back + invalidate costing several us, and all the
+        // hand-off needs is slab stores acknowledged (vmcnt 0) before the ticket, and slab loads after it.
         const int tile = blockIdx.y * gridDim.x + blockIdx.x;
         float* slabs = p.ws_slabs + (long)tile * p.kz * 256;
-        *reinterpret_cast<f32x4*>(slabs + (blockIdx.z * 64 + lane) * 4) = acc;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        float* mine = slabs + (blockIdx.z * 64 + lane) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) __hip_atomic_store(mine + c, acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int ticket = 0;
         if (lane == 0) ticket = __hip_atomic_fetch_add(p.ws_count + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         finisher = ticket == p.kz - 1;
         if (finisher) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            acc = *reinterpret_cast<const f32x4*>(slabs + lane * 4);
-            for (int z = 1; z < p.kz; ++z) acc += *reinterpret_cast<const f32x4*>(slabs + (z * 64 + lane) * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = __hip_atomic_load(slabs + lane * 4 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int z = 1; z < p.kz; ++z) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] += __hip_atomic_load(slabs + (z * 64 + lane) * 4 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (lane == 0) __hip_atomic_store(p.ws_count + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -305,7 +247,18 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
             }
         }
     }
-    chain_signal(p.chain);  // every workgroup counts once, after its last store (partial slab or output tile)
+}
+
+// K slices across workgroups (split-K): spreads GEMMs with few output columns over the chip.  Pays only for deep K:
+// the release/acquire hand-off costs ~3-4 us (measured).
+static int gemm_kz(const Gemm16& g) {
+    static int kz_max = -1;
+    if (kz_max < 0) { const char* e = getenv("CCVS_GEMM_KZ_MAX"); kz_max = e ? atoi(e) : 4; }
+    const int tiles = cdiv(g.N, 16) * cdiv(g.M, 16);
+    int kz = 1;
+    if (g.ws_slabs && !g.ln_s)
+        while (g.K >= 2048 && kz < kz_max && tiles * kz * 2 <= 256 && g.K % (16 * 8 * kz * 2) == 0 && tiles <= GEMM_WS_TILES) kz *= 2;
+    return kz;
 }
 
 static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
@@ -313,12 +266,7 @@ static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
     if (!(g.M > 0 && g.N > 0 && g.K > 0)) { ccvs_set_error("%s: empty tensor", name); return CCVS_ERR_ARG; }
     if (g.K % 16 != 0 || g.ldx % 4 != 0) { ccvs_set_error("%s: K=%d must be a multiple of 16 (ldx %% 4 == 0)", name, g.K); return CCVS_ERR_ARG; }
     if (g.epi < 0 || g.epi > 2 || (g.epi == 2 && !g.res)) { ccvs_set_error("%s: bad epilogue", name); return CCVS_ERR_ARG; }
-    const int tiles = cdiv(g.N, 16) * cdiv(g.M, 16);
-    g.kz = 1;
-    if (g.ws_slabs && !g.ln_s) {  // spread small-N GEMMs over the chip: K slices across workgroups
-        // (pays only for deep K: the release/acquire hand-off costs ~3 us, measured)
-        while (g.K >= 2048 && g.kz < 4 && tiles * g.kz * 2 <= 256 && g.K % (16 * 8 * g.kz * 2) == 0 && tiles <= GEMM_WS_TILES) g.kz *= 2;
-    }
+    g.kz = gemm_kz(g);
     g.ks = 8;
     while (g.ks > 1 && g.K % (16 * g.ks * g.kz) != 0) g.ks >>= 1;
     hipLaunchKernelGGL(gemm16_kernel, dim3(cdiv(g.N, 16), cdiv(g.M, 16), g.kz), dim3(512), 0, st, g);
@@ -464,13 +412,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // 64/(D/4) whole rows: 1 KiB, fully coalesced); the partial dots are summed across those lanes
 // with xor shuffles.  PV uses the same lane map (lane owns 4 head dims of one key slot); the
 // key slots of a wave and the 8 waves are reduced through LDS in a fixed order.
+// The kernel is a latency chain (L/256 batches of K, a softmax reduction, L/256 batches of V), so the
+// batches are double-buffered in registers -- batch i+1 is in flight while batch i is consumed -- and
+// the first V batch is requested before the softmax reduction starts.
 template <int D>
 __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __restrict__ q, long q_sB, const float* __restrict__ kc,
                                                                const float* __restrict__ vc, float* __restrict__ out, int H, int pos0,
-                                                               const int32_t* __restrict__ pos_dev, int Tmax, float scale, Chain chain) {
+                                                               const int32_t* __restrict__ pos_dev, int Tmax, float scale) {
     constexpr int LPK = D / 4;     // lanes per key row
     constexpr int KPI = 64 / LPK;  // key rows per wave-instruction
     constexpr int NW = 8;
+    constexpr int AU = 8;          // key rows per lane whose loads are issued together (64 KiB in flight per workgroup and buffer)
+    constexpr int BATCH = NW * KPI * AU;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* red = smem;                    // [16]
     float* pv = smem + 16;                // [NW][64][4]
@@ -483,30 +436,22 @@ __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __re
     const int kk = lane / LPK, d4 = lane - kk * LPK;
     const float* kbase = kc + (long)bh * Tmax * D + 4 * d4;
     const float* vbase = vc + (long)bh * Tmax * D + 4 * d4;
+    const int jw = wave * KPI + kk;  // this lane's row within a batch, + u * NW * KPI
+    const int nbatch = (L + BATCH - 1) / BATCH;
 
-    constexpr int AU = 8;  // key rows per lane whose loads are issued together (64 KiB in flight per workgroup)
-    constexpr int BATCH = NW * KPI * AU;
-    // Only row L-1 of the cache is written by this step's QKV kernel: when the first batch of key rows lies
-    // entirely below it, those loads go out before the chain wait.
-    const bool early = chain.wait && L > BATCH;
-    float4 kv[AU];
-    if (early) {
-#pragma unroll
-        for (int u = 0; u < AU; ++u) kv[u] = *reinterpret_cast<const float4*>(kbase + (long)(wave * KPI + u * NW * KPI + kk) * D);
-    }
-    chain_wait(chain);
+    // unconditional loads from clamped rows (predicated loads would serialise)
+#define ATT_LOAD(dst, base, bi)                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < AU; ++u)                                                                       \
+        dst[u] = *reinterpret_cast<const float4*>(base + (long)min((bi) * BATCH + jw + u * NW * KPI, L - 1) * D)
+
+    float4 ka[AU], kb[AU];
+    ATT_LOAD(ka, kbase, 0);
     const float4 qv = *reinterpret_cast<const float4*>(q + (long)b * q_sB + h * D + 4 * d4);
-
     float lmax = -INFINITY;
-    for (int j0 = wave * KPI; j0 < L; j0 += BATCH) {
-        if (!(early && j0 < BATCH)) {
-#pragma unroll
-            for (int u = 0; u < AU; ++u)  // unconditional loads from clamped rows (predicated loads would serialise)
-                kv[u] = *reinterpret_cast<const float4*>(kbase + (long)min(j0 + u * NW * KPI + kk, L - 1) * D);
-        }
+    auto scores = [&](const float4 (&kv)[AU], int bi) {
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
-            const int j = j0 + u * NW * KPI + kk;
+            const int j = bi * BATCH + jw + u * NW * KPI;
             float s = kv[u].x * qv.x + kv[u].y * qv.y + kv[u].z * qv.z + kv[u].w * qv.w;
 #pragma unroll
             for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
@@ -516,7 +461,18 @@ __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __re
                 lmax = fmaxf(lmax, s);
             }
         }
+    };
+    for (int bi = 0; bi < nbatch; bi += 2) {
+        if (bi + 1 < nbatch) ATT_LOAD(kb, kbase, bi + 1);
+        scores(ka, bi);
+        if (bi + 1 < nbatch) {
+            if (bi + 2 < nbatch) ATT_LOAD(ka, kbase, bi + 2);
+            scores(kb, bi + 1);
+        }
     }
+    float4 va[AU], vb[AU];
+    ATT_LOAD(va, vbase, 0);  // in flight during the softmax reductions
+
     lmax = wave_max(lmax);
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
@@ -538,18 +494,23 @@ __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __re
     for (int w = 1; w < NW; ++w) tot += red[w];
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j0 = wave * KPI; j0 < L; j0 += NW * KPI * AU) {
-        float4 vv[AU];
-#pragma unroll
-        for (int u = 0; u < AU; ++u)
-            vv[u] = *reinterpret_cast<const float4*>(vbase + (long)min(j0 + u * NW * KPI + kk, L - 1) * D);
+    auto weigh = [&](const float4 (&vv)[AU], int bi) {
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
-            const int j = j0 + u * NW * KPI + kk;
+            const int j = bi * BATCH + jw + u * NW * KPI;
             const float p = (j < L) ? ps[min(j, L - 1)] : 0.f;
             acc.x += p * vv[u].x; acc.y += p * vv[u].y; acc.z += p * vv[u].z; acc.w += p * vv[u].w;
         }
+    };
+    for (int bi = 0; bi < nbatch; bi += 2) {
+        if (bi + 1 < nbatch) ATT_LOAD(vb, vbase, bi + 1);
+        weigh(va, bi);
+        if (bi + 1 < nbatch) {
+            if (bi + 2 < nbatch) ATT_LOAD(va, vbase, bi + 2);
+            weigh(vb, bi + 1);
+        }
     }
+#undef ATT_LOAD
     *reinterpret_cast<float4*>(pv + (wave * 64 + lane) * 4) = acc;
     __syncthreads();
     if (tid < D) {
@@ -559,7 +520,6 @@ __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __re
             for (int s2 = 0; s2 < KPI; ++s2) o += pv[(w * 64 + s2 * LPK + dd4) * 4 + comp];
         out[(long)b * (H * D) + h * D + tid] = o / tot;
     }
-    if (wave == 0) chain_signal(chain);
 }
 
 extern "C" int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const float* kcache, const float* vcache, float* out, int32_t B,
@@ -575,9 +535,9 @@ extern "C" int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const f
         const size_t smem = (size_t)(16 + 8 * 256 + maxL) * sizeof(float);
         CCVS_REQUIRE(smem <= 64 * 1024, "ccvs_attention: sequence too long for the LDS score buffer");
         const dim3 grid((unsigned)(B * H));
-        if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale, Chain{});
-        else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale, Chain{});
-        else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale, Chain{});
+        if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
+        else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
+        else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
     } else {
         const size_t smem = (size_t)(80 + 256 + maxL) * sizeof(float);
         CCVS_REQUIRE(smem <= 64 * 1024, "ccvs_attention: sequence too long for the LDS score buffer");
@@ -619,7 +579,8 @@ struct Advance {       // decode-step bookkeeping folded into the sampling kerne
     long codes_sB;
     int32_t* widx;     // device-resident write index, +1 per step
     int32_t* len;      // device-resident cache length, +1 per step
-    int rng;           // draw the Exp(1) noise here: Philox keyed by chain.state[4..5], counter (element, row, step)
+    int rng;           // draw the Exp(1) noise here: Philox keyed by state[4..5], counter (element, row, step = state[0])
+    int* state;        // int32[8]: [0] completed steps, [2] arrival ticket of this kernel's rows, [4..5] Philox key
 };
 
 // k-th largest key of xs[0..V) by a 4-pass radix-256 descent (LDS histogram + suffix scan per pass).
@@ -657,7 +618,7 @@ __device__ __forceinline__ unsigned kth_largest_key(const float* xs, int V, int 
 
 __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restrict__ logits, long ld, const float* __restrict__ noise,
                                                           int64_t* __restrict__ out, long out_stride, int V, int top_k, float temperature,
-                                                          Chain chain, Advance adv) {
+                                                          Advance adv) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                  // [V]
     float* redf = smem + V;            // [4]
@@ -668,7 +629,6 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const float* lr = logits + (long)b * ld;
-    chain_wait(chain);
     float lmax = -INFINITY;
     for (int j = tid; j < V; j += 256) {
         const float v = lr[j] / temperature;
@@ -694,7 +654,7 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
     __syncthreads();
     const float tot = ((redf[0] + redf[1]) + redf[2]) + redf[3];
     unsigned k0 = 0u, k1 = 0u, step = 0u;
-    if (adv.rng) { k0 = (unsigned)chain.state[4]; k1 = (unsigned)chain.state[5]; step = (unsigned)chain.state[0]; }
+    if (adv.rng) { k0 = (unsigned)adv.state[4]; k1 = (unsigned)adv.state[5]; step = (unsigned)adv.state[0]; }
     float best = -1.f;
     int bi = 0x7fffffff;
     for (int j = tid; j < V; j += 256) {
@@ -721,17 +681,16 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
         out[(long)b * out_stride] = bi;
         if (adv.codes) {
             adv.codes[(long)b * adv.codes_sB + *adv.widx] = bi;
-            // the last row to finish advances the device-resident counters (nobody reads them any more in this
-            // step: every other kernel has signalled completion down the chain) and closes the epoch
+            // the last row to finish advances the device-resident counters (every row has read them by then)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            const int ticket = __hip_atomic_fetch_add(chain.state + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int ticket = __hip_atomic_fetch_add(adv.state + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (ticket == (int)gridDim.x - 1) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 *adv.widx += 1;
                 *adv.len += 1;
-                chain.state[0] += 1;
-                __hip_atomic_store(chain.state + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                adv.state[0] += 1;
+                __hip_atomic_store(adv.state + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -751,23 +710,19 @@ extern "C" int ccvs_sample_topk(const float* logits, int64_t ld, const float* no
     }
     CCVS_REQUIRE(smem <= 160 * 1024, "ccvs_sample_topk: vocabulary %d too large", V);
     hipLaunchKernelGGL(sample_topk_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, logits, (long)ld, noise, out, (long)out_stride, V,
-                       top_k, temperature, Chain{}, Advance{});
+                       top_k, temperature, Advance{});
     CCVS_CHECK_LAUNCH("ccvs_sample_topk");
     return CCVS_OK;
 }
 
 // ---------------------------------------------------------------------------------------
 // One decode step: the launch sequence of ccvs_gpt_embed / ccvs_gemm_ln_qkv / ccvs_attention /
-// ccvs_gemm_nt / ccvs_gemm_ln / ccvs_sample_topk for a single new position, software-pipelined
-// over two streams (Chain, top of this file).
+// ccvs_gemm_nt / ccvs_gemm_ln / ccvs_sample_topk for a single new position, 5 * n_layer + 3 launches
+// on one stream, every per-step quantity device-resident (hipGraph-capturable).
 // ---------------------------------------------------------------------------------------
-#define CHAIN_HDR 8  // state words before the per-kernel counters
-
-extern "C" int32_t ccvs_gpt_decode_chain_words(int32_t n_layer) { return CHAIN_HDR + 5 * n_layer + 3; }
-
-extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream, void* stream2) {
+extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream) {
     CCVS_REQUIRE(d && d->layers && d->tok_emb && d->pos_table && d->head_w && d->head_b && d->head_s, "ccvs_gpt_decode_step: null pointer");
-    CCVS_REQUIRE(d->tok && d->codes && d->widx && d->len && d->x && d->q && d->att && d->h && d->logits && d->chain,
+    CCVS_REQUIRE(d->tok && d->codes && d->widx && d->len && d->x && d->q && d->att && d->h && d->logits && d->state,
                  "ccvs_gpt_decode_step: null state pointer");
     CCVS_REQUIRE(d->B > 0 && d->C > 0 && d->H > 0 && d->C % d->H == 0 && d->F > 0 && d->n_layer > 0 && d->Tmax > 0 && d->vocab > 0 && d->V > 0,
                  "ccvs_gpt_decode_step: bad shape");
@@ -778,69 +733,23 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream, void
     const size_t smem_pick = (size_t)PICK_SMEM_WORDS(d->V) * sizeof(float);
     CCVS_REQUIRE(smem_att <= 64 * 1024, "ccvs_gpt_decode_step: sequence too long for the LDS score buffer");
     CCVS_REQUIRE(smem_pick <= 160 * 1024, "ccvs_gpt_decode_step: vocabulary %d too large", d->V);
-
-    hipStream_t st[2] = {(hipStream_t)stream, stream2 ? (hipStream_t)stream2 : (hipStream_t)stream};
-    const bool piped = stream2 != nullptr && stream2 != stream;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    if (piped && !ev_fork) {
-        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
-            ccvs_set_error("ccvs_gpt_decode_step: cannot create events");
-            return CCVS_ERR_LAUNCH;
-        }
-    }
+    hipStream_t st = (hipStream_t)stream;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)sample_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (piped) {
-        if (hipEventRecord(ev_fork, st[0]) != hipSuccess || hipStreamWaitEvent(st[1], ev_fork, 0) != hipSuccess) {
-            ccvs_set_error("ccvs_gpt_decode_step: fork failed");
-            return CCVS_ERR_LAUNCH;
-        }
-    }
 
-    int* state = d->chain;
-    int* counters = d->chain + CHAIN_HDR;
-    const int last = 5 * d->n_layer + 2;
-    int k = 0, prev_n = 0;
-    // the link of kernel k: wait for kernel k-1 (prev_n workgroups), count on counters[k]
-    auto link = [&](int n_this) {
-        Chain c = {};
-        if (piped) {
-            c.state = state;
-            if (k > 0) { c.wait = counters + k - 1; c.wait_n = prev_n; }
-            if (k < last) c.signal = counters + k;
-        }
-        prev_n = n_this;
-        return c;
-    };
-    auto stream_of = [&](int kk) { return kk == last ? st[0] : st[kk & 1]; };
-
-    // 0: embedding of the last picked token at row pos_off + *len
-    {
+    {   // embedding of the last picked token at row pos_off + *len
         const long total = (long)d->B * d->C;
-        const int nwg = (int)cdiv64(total, 256);
-        hipLaunchKernelGGL(gpt_embed_kernel, dim3(nwg), dim3(256), 0, stream_of(k), d->tok, 1L, (const int32_t*)nullptr, d->pos_off,
-                           (const int32_t*)d->len, 1, d->tok_emb, d->pos_table, d->x, total, d->C, d->vocab, link(nwg));
+        hipLaunchKernelGGL(gpt_embed_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, d->tok, 1L, (const int32_t*)nullptr, d->pos_off,
+                           (const int32_t*)d->len, 1, d->tok_emb, d->pos_table, d->x, total, d->C, d->vocab);
         CCVS_CHECK_LAUNCH("ccvs_gpt_decode_step(embed)");
-        ++k;
     }
-    auto gemm = [&](Gemm16& g, const char* name) -> int {
-        // launch_gemm16 fixes the grid; the link needs the workgroup count first
-        const int tiles = cdiv(g.N, 16) * cdiv(g.M, 16);
-        int kz = 1;
-        if (g.ws_slabs && !g.ln_s)
-            while (g.K >= 2048 && kz < 4 && tiles * kz * 2 <= 256 && g.K % (16 * 8 * kz * 2) == 0 && tiles <= GEMM_WS_TILES) kz *= 2;
-        g.chain = link(tiles * kz);
-        const int rc = launch_gemm16(g, stream_of(k), name);
-        ++k;
-        return rc;
-    };
     float* ws_slabs = (float*)d->workspace;
     int* ws_count = d->workspace ? (int*)((char*)d->workspace + (size_t)GEMM_WS_TILES * 4 * 256 * sizeof(float)) : nullptr;
     const float scale = 1.0f / sqrtf((float)D);
+    int rc;
     for (int l = 0; l < d->n_layer; ++l) {
         const ccvs_gpt_layer& L = d->layers[l];
         CCVS_REQUIRE(L.qkv_w && L.qkv_b && L.qkv_s && L.proj_w && L.proj_b && L.fc_w && L.fc_b && L.fc_s && L.fc2_w && L.fc2_b && L.kcache && L.vcache,
@@ -849,53 +758,38 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream, void
         g.x = d->x; g.ldx = d->C; g.w = L.qkv_w; g.bias = L.qkv_b; g.y = d->q; g.ldy = d->C; g.M = d->B; g.N = 3 * d->C; g.K = d->C;
         g.ln_s = L.qkv_s; g.ln_eps = d->ln_eps;
         g.kcache = L.kcache; g.vcache = L.vcache; g.C = d->C; g.H = d->H; g.D = D; g.Tq = 1; g.Tmax = d->Tmax; g.pos0 = 0; g.pos_dev = d->len;
-        int rc = gemm(g, "ccvs_gpt_decode_step(qkv)");
-        if (rc != CCVS_OK) return rc;
+        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(qkv)")) != CCVS_OK) return rc;
         {   // attention over the cache
             const dim3 grid((unsigned)(d->B * d->H));
-            const Chain c = link((int)grid.x);
-            hipStream_t s = stream_of(k);
-            if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(512), smem_att, s, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, d->Tmax, scale, c);
-            else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(512), smem_att, s, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, d->Tmax, scale, c);
-            else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(512), smem_att, s, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, d->Tmax, scale, c);
+            if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(512), smem_att, st, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, d->Tmax, scale);
+            else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(512), smem_att, st, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, d->Tmax, scale);
+            else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(512), smem_att, st, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, d->Tmax, scale);
             CCVS_CHECK_LAUNCH("ccvs_gpt_decode_step(attention)");
-            ++k;
         }
         g = Gemm16{};  // proj + residual (in place on x)
         g.x = d->att; g.ldx = d->C; g.w = L.proj_w; g.bias = L.proj_b; g.res = d->x; g.y = d->x; g.ldy = d->C; g.M = d->B; g.N = d->C; g.K = d->C; g.epi = 2;
         g.ws_slabs = ws_slabs; g.ws_count = ws_count;
-        if ((rc = gemm(g, "ccvs_gpt_decode_step(proj)")) != CCVS_OK) return rc;
+        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(proj)")) != CCVS_OK) return rc;
         g = Gemm16{};  // ln2 + fc + GELU
         g.x = d->x; g.ldx = d->C; g.w = L.fc_w; g.bias = L.fc_b; g.y = d->h; g.ldy = d->F; g.M = d->B; g.N = d->F; g.K = d->C; g.epi = 1;
         g.ln_s = L.fc_s; g.ln_eps = d->ln_eps;
-        if ((rc = gemm(g, "ccvs_gpt_decode_step(fc)")) != CCVS_OK) return rc;
+        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(fc)")) != CCVS_OK) return rc;
         g = Gemm16{};  // fc2 + residual (in place on x)
         g.x = d->h; g.ldx = d->F; g.w = L.fc2_w; g.bias = L.fc2_b; g.res = d->x; g.y = d->x; g.ldy = d->C; g.M = d->B; g.N = d->C; g.K = d->F; g.epi = 2;
         g.ws_slabs = ws_slabs; g.ws_count = ws_count;
-        if ((rc = gemm(g, "ccvs_gpt_decode_step(fc2)")) != CCVS_OK) return rc;
+        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(fc2)")) != CCVS_OK) return rc;
     }
     {   // ln_f + head
         Gemm16 g = {};
         g.x = d->x; g.ldx = d->C; g.w = d->head_w; g.bias = d->head_b; g.y = d->logits; g.ldy = d->V; g.M = d->B; g.N = d->V; g.K = d->C;
         g.ln_s = d->head_s; g.ln_eps = d->ln_eps;
-        const int rc = gemm(g, "ccvs_gpt_decode_step(head)");
-        if (rc != CCVS_OK) return rc;
+        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(head)")) != CCVS_OK) return rc;
     }
-    if (piped && (last & 1) == 0) {
-        // the head ran on stream2: close that branch (the pick below waits for it through the chain)
-        if (hipEventRecord(ev_join, st[1]) != hipSuccess) { ccvs_set_error("ccvs_gpt_decode_step: join failed"); return CCVS_ERR_LAUNCH; }
-    }
-    {   // pick + bookkeeping, always on `stream`
-        Chain c = link(d->B);
-        if (!piped) c.state = state;  // the ticket word is used in both modes
-        Advance adv = {d->codes, (long)d->codes_sB, d->widx, d->len, (d->rng && !d->noise) ? 1 : 0};
-        hipLaunchKernelGGL(sample_topk_kernel, dim3(d->B), dim3(256), smem_pick, st[0], d->logits, (long)d->V, d->noise, d->tok, 1L, d->V,
-                           d->top_k, d->temperature, c, adv);
+    {   // pick + bookkeeping
+        Advance adv = {d->codes, (long)d->codes_sB, d->widx, d->len, (d->rng && !d->noise) ? 1 : 0, d->state};
+        hipLaunchKernelGGL(sample_topk_kernel, dim3(d->B), dim3(256), smem_pick, st, d->logits, (long)d->V, d->noise, d->tok, 1L, d->V,
+                           d->top_k, d->temperature, adv);
         CCVS_CHECK_LAUNCH("ccvs_gpt_decode_step(pick)");
-    }
-    if (piped) {
-        if ((last & 1) != 0 && hipEventRecord(ev_join, st[1]) != hipSuccess) { ccvs_set_error("ccvs_gpt_decode_step: join failed"); return CCVS_ERR_LAUNCH; }
-        if (hipStreamWaitEvent(st[0], ev_join, 0) != hipSuccess) { ccvs_set_error("ccvs_gpt_decode_step: join failed"); return CCVS_ERR_LAUNCH; }
     }
     return CCVS_OK;
 }

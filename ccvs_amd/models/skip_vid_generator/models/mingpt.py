@@ -15,14 +15,7 @@ with the residual add in its epilogue, LayerNorm, MLP GEMMs with GELU / residual
 import torch
 import torch.nn as nn
 
-import os
-
 from .... import ops
-
-# Two-stream software pipelining of the decode step (include/ccvs_hip.h: ccvs_gpt_decode_step).  Bit-identical to the
-# one-stream schedule (tests/test_ops_gpu.py) but OFF by default: on ROCm 7.2 / MI355X kernels of one hipGraph that sit on
-# two hardware queues dispatch 20-40 us apart, so the pipelined step measured 4.15 ms/token against 1.32 ms on one stream.
-DECODE_PIPELINE = os.environ.get("CCVS_DECODE_PIPELINE", "0") == "1"
 
 
 class GPTConfig:
@@ -144,7 +137,7 @@ class GPT(nn.Module):
         self.apply(self._init_weights)
         self.config = config
         self._cache = None
-        self._graphs, self._side_stream = {}, None
+        self._graphs = {}
 
     def get_block_size(self):
         return self.block_size
@@ -209,7 +202,7 @@ class GPT(nn.Module):
                 # scratch of ccvs_gpt_decode_step
                 "x": torch.empty(batch, C, **f32), "q": torch.empty(batch, C, **f32), "att": torch.empty(batch, C, **f32),
                 "h": torch.empty(batch, 4 * C, **f32), "logits": torch.empty(batch, V, **f32), "noise": torch.empty(batch, V, **f32),
-                "chain": torch.zeros(ops.gpt_decode_chain_words(cfg.n_layer), dtype=torch.int32, device=dev),
+                "state": torch.zeros(8, dtype=torch.int32, device=dev),    # [0] steps done, [4..5] Philox key (ccvs_hip.h)
                 "desc": None,
             }
         c["len"] = 0
@@ -316,7 +309,7 @@ class GPT(nn.Module):
                 tok=c["tok"], codes=c["codes"], widx=c["widx"], length=c["len_dev"],
                 x=c["x"], q=c["q"], att=c["att"], h=c["h"], logits=c["logits"],
                 noise=c["noise"] if (sampler["sample"] and not device_rng) else None, rng=device_rng,
-                top_k=sampler["top_k"], temperature=sampler["temperature"], chain=c["chain"])
+                top_k=sampler["top_k"], temperature=sampler["temperature"], state=c["state"])
             c["desc"] = (key, desc)
         return c["desc"][1]
 
@@ -330,27 +323,14 @@ class GPT(nn.Module):
     def _decode_body(self, sampler, noise=None, trace=None):
         """One decode step driven entirely by device-resident state, hence hipGraph-capturable: embed
         c['tok'] at frame position len - frame_pos0, run the layers against the cache, pick and store the
-        next token, advance the counters -- one `ccvs_gpt_decode_step` call whose launches are
-        software-pipelined over the current stream and a side stream (include/ccvs_hip.h)."""
+        next token, advance the counters -- one `ccvs_gpt_decode_step` call (include/ccvs_hip.h)."""
         c = self._cache
         desc = self._decode_desc(sampler)
         if sampler["sample"] and sampler["noise"] != "device":
             c["noise"].copy_(noise, non_blocking=True)   # host-drawn Exp(1) noise (reference-reproducible stream)
-        side = None
-        if DECODE_PIPELINE:
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream()
-            side = self._side_stream
-        desc.launch(side)
+        desc.launch()
         if trace is not None:
             trace.append(c["logits"].clone())
-
-    def check_decode(self):
-        """Raise if a dependency wait of the pipelined decode step gave up (the tokens of that call are invalid)."""
-        c = self._cache
-        if c is not None and int(c["chain"][1].item()) != 0:
-            c["chain"].zero_()
-            raise RuntimeError("ccvs_gpt_decode_step: a pipelined dependency wait timed out; set CCVS_DECODE_PIPELINE=0")
 
     @torch.no_grad()
     def generate(self, code, add_len, cond_idx=None, delta_length_cond=None, sample=False, top_k=None, temperature=1.0,
@@ -380,9 +360,9 @@ class GPT(nn.Module):
             trace.append(logits.clone())
         c["codes"][:, :t0] = code
         c["len_dev"].fill_(n_cond + t0)
-        c["chain"].zero_()                # step counter (= Philox counter word) and pipelining counters restart with the call
+        c["state"].zero_()                # the step counter (= Philox counter word) restarts with the call
         if sample and noise == "device":  # key of the in-kernel Philox draws, from torch's generator (honours torch.manual_seed)
-            c["chain"][4:6] = torch.randint(-2**31, 2**31 - 1, (2,), dtype=torch.int64).to(torch.int32).to(c["chain"].device)
+            c["state"][4:6] = torch.randint(-2**31, 2**31 - 1, (2,), dtype=torch.int64).to(torch.int32).to(c["state"].device)
         self._emit(logits, sampler, draw(logits), t0)
 
         graph = None
@@ -391,7 +371,7 @@ class GPT(nn.Module):
             graph = self._graphs.get(key)
             if graph is None:
                 # capture on live state: the warm-up step and the captured step are steps 1 and 2 of this very call
-                state = {k: c[k].clone() for k in ("len_dev", "widx", "tok", "codes", "chain")}
+                state = {k: c[k].clone() for k in ("len_dev", "widx", "tok", "codes", "state")}
                 warm = torch.cuda.Stream()
                 warm.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(warm):               # warm-up: one-time attribute calls, descriptor, events
@@ -414,9 +394,7 @@ class GPT(nn.Module):
                     nz = host_noise(b, self.head.weight.shape[0]).to(code.device, non_blocking=True)
                 self._decode_body(sampler, noise=nz, trace=trace)
         c["len"] = n_cond + t0 + add_len - 1
-        out = c["codes"][:, :t0 + add_len].clone()
-        self.check_decode()
-        return out
+        return c["codes"][:, :t0 + add_len].clone()
 
     # ------------------------------------------------------------------ reference-shaped forward
     @torch.no_grad()

@@ -411,27 +411,21 @@ def sample_topk(logits, top_k, temperature, noise=None, out=None):
     return out
 
 
-def gpt_decode_chain_words(n_layer):
-    return int(_lib.load().ccvs_gpt_decode_chain_words(int(n_layer)))
-
-
 class GptDecodeStep:
     """A filled `ccvs_gpt_decode` descriptor (include/ccvs_hip.h) plus the tensors it points at.
-    `launch(side_stream)` enqueues one whole decode step on the current stream (pipelined over
-    `side_stream` when given)."""
+    `launch()` enqueues one whole decode step on the current stream."""
 
     def __init__(self, layers, B, C, H, Tmax, ln_eps, tok_emb, pos_table, pos_off, head, tok, codes, widx, length,
-                 x, q, att, h, logits, noise, top_k, temperature, chain, rng=False):
+                 x, q, att, h, logits, noise, top_k, temperature, state, rng=False):
         hw, hb, hs = head
-        keep = [tok_emb, pos_table, hw, hb, hs, tok, codes, widx, length, x, q, att, h, logits, noise, chain]
+        keep = [tok_emb, pos_table, hw, hb, hs, tok, codes, widx, length, x, q, att, h, logits, noise, state]
         for t in keep:
             if t is not None:
                 _need_gpu(t)
         f32 = [tok_emb, pos_table, hw, hb, hs, x, q, att, h, logits] + ([noise] if noise is not None else [])
         assert all(t.dtype == torch.float32 and t.is_contiguous() for t in f32)
         assert tok.dtype == torch.int64 and tok.numel() == B and tok.is_contiguous() and codes.dtype == torch.int64 and codes.stride(1) == 1
-        assert widx.dtype == torch.int32 and length.dtype == torch.int32 and chain.dtype == torch.int32
-        assert chain.numel() >= gpt_decode_chain_words(len(layers))
+        assert widx.dtype == torch.int32 and length.dtype == torch.int32 and state.dtype == torch.int32 and state.numel() >= 8
         arr = (_lib.GptLayer * len(layers))()
         for i, lay in enumerate(layers):
             for name, t in lay.items():
@@ -455,13 +449,12 @@ class GptDecodeStep:
         d.noise = _p(noise)
         d.rng = 1 if (rng and noise is None) else 0
         d.top_k, d.temperature = 0 if top_k is None else int(top_k), float(temperature)
-        d.workspace, d.chain = _p(self.ws), _p(chain)
+        d.workspace, d.state = _p(self.ws), _p(state)
         self.desc, self._arr, self._keep = d, arr, keep
 
-    def launch(self, side_stream=None):
+    def launch(self):
         L = _lib.load()
-        side = C.c_void_p(0) if side_stream is None else C.c_void_p(side_stream.cuda_stream)
-        _lib.check(L.ccvs_gpt_decode_step(C.byref(self.desc), _stream(), side), "ccvs_gpt_decode_step")
+        _lib.check(L.ccvs_gpt_decode_step(C.byref(self.desc), _stream()), "ccvs_gpt_decode_step")
 
 
 def pack_u8(vid, lo=-1.0, hi=1.0):

@@ -203,14 +203,10 @@ int ccvs_sample_topk(const float* logits, int64_t ld, const float* noise, int64_
 /* One whole KV-cached decode step of the sampling loop (transformer_model.py:395-409 calling
  * mingpt.py:219-305 for ONE new position): embed `tok` -> n_layer x [ln1+QKV+cache | attention |
  * proj+res | ln2+fc+GELU | fc2+res] -> ln_f+head -> get_icode pick -> codes[b][*widx] = tok[b] = pick;
- * ++*widx; ++*len.  All per-step state is device-resident, so the call is hipGraph-capturable and a
- * captured step replays unchanged.
- * The ~5*n_layer+3 dependent launches are issued alternately on `stream` and `stream2` and chained by
- * device counters in `chain`, so that each kernel's weight loads are in flight while its predecessor
- * still runs (see gpt.hip); results are bit-identical to issuing the same kernels in order on one
- * stream, which is what happens when stream2 is NULL.
- * `chain`: int32[ccvs_gpt_decode_chain_words(n_layer)] ([0] completed steps, [1] broken flag, [4..5] RNG key), zeroed by the caller once (and again whenever
- * chain[1] != 0 was observed: a dependency wait ran out of patience and the step's result is invalid). */
+ * ++*widx; ++*len; ++state[0].  5*n_layer+3 launches on `stream`.  All per-step state is device-resident,
+ * so the call is hipGraph-capturable and a captured step replays unchanged.
+ * `state`: int32[8] owned by the caller: [0] steps completed (also the Philox counter word), [2] internal
+ * (zero between calls), [4..5] Philox key; the caller zeroes it and sets the key when a sequence starts. */
 typedef struct ccvs_gpt_layer {
     const float *qkv_w, *qkv_b, *qkv_s; /* ln1 folded into [q;k;v]: W*gamma [3C,C], b + W beta [3C], rowsum(W*gamma) [3C] */
     const float *proj_w, *proj_b;       /* [C,C], [C] */
@@ -232,13 +228,12 @@ typedef struct ccvs_gpt_decode {
     float *x, *q, *att, *h, *logits;    /* scratch [B,C] [B,C] [B,C] [B,F] [B,V] */
     const float* noise;                 /* [B,V] Exp(1) noise (host-reproducible sampling), or NULL */
     int32_t rng;                        /* noise == NULL: 0 greedy pick, 1 draw the Exp(1) noise in the kernel (Philox4x32-10,
-                                           key = chain[4..5] set by the caller, counter = (element, row, step)) */
+                                           key = state[4..5], counter = (element, row, step = state[0])) */
     int32_t top_k; float temperature;
     void* workspace;                    /* ccvs_gemm_workspace_bytes(), zeroed once */
-    int32_t* chain;
+    int32_t* state;
 } ccvs_gpt_decode;
-int32_t ccvs_gpt_decode_chain_words(int32_t n_layer);
-int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream, void* stream2);
+int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream);
 
 /* ---- output stage ---------------------------------------------------------------------
  * save_video_batch's clamp / rescale / x255 / uint8 / channels-last pack
