@@ -24,6 +24,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define CB_MAX_E 5
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // two floats -> two bf16 (round to nearest even) in one v_cvt_pk_bf16_f32; element 0 in the low half
@@ -218,13 +220,24 @@ __global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4
 // ---------------------------------------------------------------------------------------
 #define CB_XQ 1  // halo-tile pixel passes per producer thread per step (passes <= CB_XQ * nt)
 
-// NPW = staging waves (4, or 8 when the MFMA work per staged byte is low: few output channels)
-template <int TW, int MB, int NPW>
-__global__ __launch_bounds__(256 + 64 * NPW, (MB == 1 && NPW == 4) ? 4 : 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
+// VEC (stride-1 dense convolutions on 16-byte aligned rows): the halo tile is staged from ALIGNED float4 loads.
+// A staging thread owns one item = 4 consecutive pixels x 8 channels (8 x global_load_dwordx4, 8 x ds_write_b128
+// after the split) of the tile widened to 4-pixel boundaries; a whole chunk is one item per thread, requested a
+// full chunk (nt steps) before it is converted.  Against the scalar form (16 dword loads per thread and step)
+// that is 4.5x fewer load instructions and 1.6x the bytes in flight per CU -- the staging side was latency-bound.
+// NTY > 0 selects VEC with NTY tap rows per chunk (1 or 3) as a compile-time constant: the staging loop is then
+// unrolled over a chunk's steps, every load is unconditional (clamped at the tail), and hipcc can give each
+// s_waitcnt the exact vmcnt -- with run-time step structure it falls back to vmcnt(0) at every LDS store, which
+// drags the HBM latency of the activation loads into every step.  NTY == 0: scalar staging, any tap count.
+template <int TW, int MB, int NTY>
+__global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
+    constexpr bool VEC = NTY > 0;
     constexpr int TH = 256 / TW;
     constexpr int NT = 32 * MB;
-    constexpr int NP = 64 * NPW;  // staging threads
-    constexpr int CB_WR = (3 * 4 * NT + NP - 1) / NP;  // uint4 of tap-row weights per staging thread (3 taps per row)
+    constexpr int NP = 256;               // staging threads (waves 4-7)
+    constexpr int NPW = 256;              // ... all of which stage weights
+    constexpr int NPX = 256;              // ... and (VEC) one activation item each
+    constexpr int CB_WR = (3 * 4 * NT + NPW - 1) / NPW;  // uint4 of tap-row weights per weight-staging thread (3 taps per row)
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -232,6 +245,15 @@ __global__ __launch_bounds__(256 + 64 * NPW, (MB == 1 && NPW == 4) ? 4 : 2) void
     //  waves, both cost ~25 % on the 195->128 3x3 shape with hipcc / ROCm 7.2 -- left as plain predication)
     const bool producer = wave >= 4;
     const int rt = producer ? tid - 256 : tid, rw = wave & 3;  // thread / wave index inside the role
+    // VEC: the staging waves handle the activations only; the pre-split weights need no conversion and go
+    // global -> LDS by LDS-DMA (global_load_lds_dwordx4) issued by the MFMA waves themselves.  Loads retire in order
+    // per wave: with both operands in one wave's queue, waiting for next step's weights also waits for the
+    // activation loads issued before them, which caps their latency budget at two steps; alone in the queue they
+    // get a whole chunk (NTY steps).  (Measured alternative: waves 4-5 activations / 6-7 weights was 10 % slower --
+    // the conversion work then sits on two of the four SIMDs.)
+    const bool xrole = VEC && producer;
+    const bool wrole = VEC ? !producer : producer;
+    const int rtw = rt;
     const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
     const int n0 = blockIdx.y * NT;
     int n = blockIdx.z, cls = 0;
@@ -242,8 +264,12 @@ __global__ __launch_bounds__(256 + 64 * NPW, (MB == 1 && NPW == 4) ? 4 : 2) void
 
     const int IH = (TH - 1) * ay.s + ay.ext + 1;
     const int IW = (TW - 1) * ax.s + ax.ext + 1;
-    const int plane = IH * IW;
     const int iy0 = ty * TH * ay.s + ay.lo, ix0 = tx * TW * ax.s + ax.lo;
+    // VEC: the LDS image starts at the 4-pixel boundary at or left of ix0 (xsh pixels earlier) and has NQ float4 columns
+    const int xsh = VEC ? ((ax.lo % 4) + 4) % 4 : 0;
+    const int NQ = (xsh + IW + 3) >> 2;
+    const int IWS = VEC ? 4 * NQ : IW;   // LDS row stride in pixels
+    const int plane = IH * IWS;
     const int in_sz = 4 * plane, w_sz = ntx_max * 4 * NT;
     uint4* in_buf = smem4;               // [2][half 2][part 2][plane]
     uint4* w_buf = smem4 + 2 * in_sz;    // [2][ntx][half 2][part 2][NT]
@@ -257,12 +283,13 @@ __global__ __launch_bounds__(256 + 64 * NPW, (MB == 1 && NPW == 4) ? 4 : 2) void
     // ---- producer helpers -------------------------------------------------------------------
     // All per-lane address parts are computed ONCE; per step only wave-uniform (scalar) bases change,
     // so a load is `uniform base + 32-bit lane offset` with no vector address arithmetic.
-    int offs[CB_MAX_E];  // halo element -> plane offset; -2: no such element, -1: outside the image
+    constexpr int NE = VEC ? 1 : CB_MAX_E;
+    int offs[NE];  // halo element -> plane offset; -2: no such element, -1: outside the image
 #pragma unroll
-    for (int j = 0; j < CB_MAX_E; ++j) {
+    for (int j = 0; j < NE; ++j) {
         const int e = rt + NP * j;
         offs[j] = -2;
-        if (producer && e < plane) {
+        if (!VEC && producer && e < plane) {
             const int r = e / IW, c = e - r * IW;
             const int gy = iy0 + r, gx = ix0 + c;
             offs[j] = (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) ? gy * p.Win + gx : -1;
@@ -271,19 +298,44 @@ __global__ __launch_bounds__(256 + 64 * NPW, (MB == 1 && NPW == 4) ? 4 : 2) void
     auto pix_offset = [&](int j) -> int {  // register-array select without dynamic indexing
         int o = -2;
 #pragma unroll
-        for (int jj = 0; jj < CB_MAX_E; ++jj) o = (j == jj) ? offs[jj] : o;
+        for (int jj = 0; jj < NE; ++jj) o = (j == jj) ? offs[jj] : o;
         return o;
     };
+    // VEC item of this thread: half vh (8 channels), tile row vr, float4 column vq
+    constexpr int NI = 1;
+    bool vitem[NI], vin[NI];
+    int ve[NI], vh[NI];
+    const float* vptr[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) { vitem[j] = false; vin[j] = false; ve[j] = 0; vh[j] = 0; vptr[j] = xn; }
+    if (xrole) {
+        const int n_items = IH * NQ * 2;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int it0_ = rt + NPX * j;
+            vitem[j] = it0_ < n_items;
+            const int it = min(it0_, n_items - 1);
+            vh[j] = it / (IH * NQ);
+            const int rem = it - vh[j] * IH * NQ;
+            const int vr = rem / NQ, vq = rem - vr * NQ;
+            const int gy = iy0 + vr, gxa = ix0 - xsh + 4 * vq;
+            vin[j] = gy >= 0 && gy < p.Hin && gxa >= 0 && gxa < p.Win;  // aligned and Win % 4 == 0: all 4 pixels in or out
+            vptr[j] = xn + (long)(8 * vh[j]) * p.in_sC + (vin[j] ? gy * p.Win + gxa : 0);
+            ve[j] = vr * IWS + 4 * vq;
+        }
+    }
+    f32x4 xv[NI][VEC ? 8 : 1];
+    int xvc0 = -1;  // first channel of the chunk held in xv; -1: nothing
     int wofs[CB_WR];  // lane part of the weight address (uint4 units): tap column, half, hi|lo, cout
 #pragma unroll
     for (int i = 0; i < CB_WR; ++i) {
-        const int ic = min(rt + NP * i, wunits - 1);
+        const int ic = min(rtw + NPW * i, wunits - 1);
         const int b = ic / (4 * NT), rem = ic - b * (4 * NT);
         const int hp = rem / NT, co = rem - hp * NT;
         wofs[i] = ((b * ax.dw * CinG + (hp >> 1)) * 2 + (hp & 1)) * p.CoutPad + co;
     }
     u32x4 wraw[CB_WR];  // native vector type: HIP's uint4 struct array does not stay in registers across the loop
-    float xraw[CB_XQ][16];
+    float xraw[CB_XQ][VEC ? 1 : 16];
     int xoff[CB_XQ], xc0 = 0;
 #pragma unroll
     for (int q = 0; q < CB_XQ; ++q) xoff[q] = -2;
@@ -298,7 +350,55 @@ __global__ __launch_bounds__(256 + 64 * NPW, (MB == 1 && NPW == 4) ? 4 : 2) void
     auto store_w = [&](uint4* dst) {
 #pragma unroll
         for (int i = 0; i < CB_WR; ++i)
-            if (rt + NP * i < wunits) *reinterpret_cast<u32x4*>(dst + rt + NP * i) = wraw[i];
+            if (rtw + NPW * i < wunits) *reinterpret_cast<u32x4*>(dst + rtw + NPW * i) = wraw[i];
+    };
+    // LDS-DMA of one tap row of weights: wave-instruction i of wave rw fills 64 consecutive uint4 of the row image
+    auto dma_w = [&](int ci_, int a_, uint4* dst) {
+        const uint4* base = wsplit + ((((long)(ay_w0 + a_ * ay_dw) * kw_ + ax_w0) * CinG + ci_ * 2) * 2) * cout_pad + n0;  // uniform
+#pragma unroll
+        for (int i = 0; i < CB_WR; ++i)
+            if (rtw + NPW * i < wunits)
+                __builtin_amdgcn_global_load_lds((glb_void*)(base + wofs[i]), (lds_void*)(dst + rw * 64 + NPW * i), 16, 0, 0);
+    };
+    auto load_xv = [&](int c_) {
+        xvc0 = c_ * CB_CC;
+        if (ablate & 16) return;
+        const bool full = xvc0 + CB_CC <= cin_;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+#pragma unroll
+            for (int i = 0; i < (VEC ? 8 : 1); ++i) {
+                const int c = full ? xvc0 + i : min(xvc0 + 8 * vh[j] + i, cin_ - 1) - 8 * vh[j];
+                xv[j][i] = *reinterpret_cast<const f32x4*>(vptr[j] + (long)c * in_sC);
+            }
+        }
+    };
+    auto store_xv = [&](uint4* dst) {
+        if (xvc0 < 0) return;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (!vitem[j]) continue;
+            const bool plain = vin[j] && (xvc0 + CB_CC <= cin_);
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = xv[j][VEC ? i : 0][px];
+                if (!plain) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (vin[j] && xvc0 + 8 * vh[j] + i < cin_) ? v[i] : 0.f;
+                }
+                uint4 hi, lo;
+                if (ablate & 8) {
+                    hi = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+                    lo = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
+                } else {
+                    split8(v, hi, lo);
+                }
+                dst[(vh[j] * 2 + 0) * plane + ve[j] + px] = hi;
+                dst[(vh[j] * 2 + 1) * plane + ve[j] + px] = lo;
+            }
+        }
     };
     auto load_x = [&](int c_, int slot) {
         xc0 = c_ * CB_CC;
@@ -309,7 +409,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (MB == 1 && NPW == 4) ? 4 : 2) void
             if (xoff[q] != -2) {
                 const int o = max(xoff[q], 0);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
+                for (int i = 0; i < (VEC ? 1 : 16); ++i) {
                     const float* cb = xn + (long)(full ? xc0 + i : min(xc0 + i, cin_ - 1)) * in_sC;  // uniform
                     xraw[q][i] = cb[o];
                 }
@@ -326,7 +426,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (MB == 1 && NPW == 4) ? 4 : 2) void
             for (int h = 0; h < 2; ++h) {
                 float v[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = xraw[q][8 * h + i];
+                for (int i = 0; i < 8; ++i) v[i] = xraw[q][VEC ? 0 : 8 * h + i];
                 if (!plain) {  // border pixel or channel tail: zero what lies outside
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = (xoff[q] >= 0 && xc0 + 8 * h + i < cin_) ? v[i] : 0.f;
@@ -345,7 +445,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (MB == 1 && NPW == 4) ? 4 : 2) void
     for (int pp = 0; pp < 2; ++pp) {
         const int pj = (rw * 2 + pp) * 32 + (lane & 31);
         const int prow = pj / TW, pcol = pj - prow * TW;
-        bofs[pp] = prow * ay.s * IW + pcol * ax.s;
+        bofs[pp] = prow * ay.s * IWS + pcol * ax.s + xsh;
     }
     const int khalf = lane >> 5;
     f32x16 acc[MB][2];
@@ -358,21 +458,46 @@ __global__ __launch_bounds__(256 + 64 * NPW, (MB == 1 && NPW == 4) ? 4 : 2) void
 
     if (producer) {
         // prologue: chunk 0's halo tile and step 0's weights, synchronously and straight into LDS
-        for (int j = 0; j < CB_MAX_E; ++j) {
-            const int o = pix_offset(j);
-            if (o != -2) stage_pixel(xn, p.in_sC, p.Cin, 0, o, in_buf, plane, rt + NP * j);
+        if (xrole) {
+            load_xv(0);
+            store_xv(in_buf);
+        } else if (!VEC) {
+            for (int j = 0; j < NE; ++j) {
+                const int o = pix_offset(j);
+                if (o != -2) stage_pixel(xn, p.in_sC, p.Cin, 0, o, in_buf, plane, rt + NP * j);
+            }
         }
-        const uint4* base = wsplit + ((((long)ay_w0 * kw_ + ax_w0) * CinG) * 2) * cout_pad + n0;
+        if (!VEC) {
+            const uint4* base = wsplit + ((((long)ay_w0 * kw_ + ax_w0) * CinG) * 2) * cout_pad + n0;
 #pragma unroll
-        for (int i = 0; i < CB_WR; ++i)
-            if (rt + NP * i < wunits) w_buf[rt + NP * i] = base[wofs[i]];
+            for (int i = 0; i < CB_WR; ++i)
+                if (rtw + NPW * i < wunits) w_buf[rtw + NPW * i] = base[wofs[i]];
+        }
     }
 
     // Step -1 only lets the producers fetch the first register bundle (everyone meets at the barrier);
     // steps 0 .. nsteps-1 are the real ones.  (ci, a) = (chunk, tap row) of step s.
-    int ci = -1, a = nt - 1;
-    for (int s = -1; s < nsteps; ++s) {
-        if (producer && !(ablate & 1)) {
+    // The two roles run SEPARATE loops that meet at the same barrier once per step: in one shared loop the register
+    // allocator keeps the staging bundle live across the MFMA code and the accumulators live across the staging code.
+    if (producer && VEC) {
+        // chunk c is requested at step (c-2, 0) and converted + stored at step (c-1, 0), a whole chunk later; these are
+        // the wave's only outstanding loads.  Requests past the end re-read the last chunk (and are never stored).
+        constexpr int NTYc = VEC ? NTY : 1;
+        const bool work = !(ablate & 1);
+        if (work) load_xv(min(1, nchunks - 1));
+        __syncthreads();
+        for (int ci = 0; ci < nchunks; ++ci) {
+            if (work) {
+                if (ci + 1 < nchunks) store_xv(in_buf + ((ci + 1) & 1) * in_sz);
+                load_xv(min(ci + 2, nchunks - 1));
+            }
+#pragma unroll
+            for (int a = 0; a < NTYc; ++a) __syncthreads();
+        }
+    } else if (producer) {
+      int ci = -1, a = nt - 1;
+      for (int s = -1; s < nsteps; ++s) {
+        if (!(ablate & 1)) {
             if (s >= 0) {  // (1) convert + store the bundle loaded during the previous step
                 if (s + 1 < nsteps) store_w(w_buf + ((s + 1) & 1) * w_sz);
                 if (ci + 1 < nchunks) store_x(a, in_buf + ((ci + 1) & 1) * in_sz);
@@ -390,33 +515,72 @@ __global__ __launch_bounds__(256 + 64 * NPW, (MB == 1 && NPW == 4) ? 4 : 2) void
 #pragma unroll
                 for (int q = 0; q < CB_XQ; ++q) xoff[q] = -2;
             }
-        } else if (!producer && s >= 0 && !(ablate & 2)) {
-            const uint4* it0 = in_buf + (ci & 1) * in_sz + (khalf * 2) * plane + (ay.d0 + a * ay.dd - ay.lo) * IW;
-            const uint4* wt0 = w_buf + (s & 1) * w_sz + (khalf * 2) * NT + (lane & 31);
-            for (int b = 0; b < ax.nt; ++b) {
-                const uint4* it = it0 + (ax.d0 + b * ax.dd - ax.lo);
-                const uint4* wt = wt0 + b * 4 * NT;
-                bf16x8 bh[2], bl[2];
-#pragma unroll
-                for (int pp = 0; pp < 2; ++pp) {
-                    bh[pp] = __builtin_bit_cast(bf16x8, it[bofs[pp]]);
-                    bl[pp] = __builtin_bit_cast(bf16x8, it[plane + bofs[pp]]);
-                }
-#pragma unroll
-                for (int m = 0; m < MB; ++m) {
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, wt[m * 32]);
-                    const bf16x8 al = __builtin_bit_cast(bf16x8, wt[NT + m * 32]);
-#pragma unroll
-                    for (int pp = 0; pp < 2; ++pp) {
-                        acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[pp], acc[m][pp], 0, 0, 0);
-                        acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[pp], acc[m][pp], 0, 0, 0);
-                        acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[pp], acc[m][pp], 0, 0, 0);
-                    }
-                }
-            }
         }
         __syncthreads();
         if (++a == nt) { a = 0; ++ci; }
+      }
+    } else {
+      int ci = -1, a = nt - 1;
+      for (int s = -1; s < nsteps; ++s) {
+        if (VEC && !(ablate & 1) && s + 1 < nsteps) {  // weights of step s+1 by LDS-DMA; hipcc drains them (vmcnt 0) at the barrier
+            int a1 = a + 1, c1 = ci;
+            if (a1 == nt) { a1 = 0; ++c1; }
+            dma_w(c1, a1, w_buf + ((s + 1) & 1) * w_sz);
+        }
+        if (s >= 0 && !(ablate & 2)) {
+            const uint4* it0 = in_buf + (ci & 1) * in_sz + (khalf * 2) * plane + (ay.d0 + a * ay.dd - ay.lo) * IWS;
+            const uint4* wt0 = w_buf + (s & 1) * w_sz + (khalf * 2) * NT + (lane & 31);
+            // Software-pipelined fragment reads: the ds_reads of the NEXT 32-cout block (and, on a tap's last block,
+            // of the next tap's pixels) are issued before the current block's 6 MFMAs, into the other register
+            // set -- hipcc does not do this by itself and the lone MFMA wave of a SIMD then idles a full LDS
+            // latency after every 6 MFMAs.  Taps are unrolled by two so both sets stay statically indexed.
+            bf16x8 fa[2][2];     // [set][0 hi | 1 lo]       weights of one 32-cout block
+            bf16x8 fb[2][2][2];  // [set][pp][0 hi | 1 lo]   the two pixel blocks of one tap
+            const int ntx = ax.nt, xd0 = ax.d0 - ax.lo, xdd = ax.dd;
+#define CB_LD_B(SET, tb)                                                                        \
+    {                                                                                           \
+        const uint4* it_ = it0 + (xd0 + (tb) * xdd);                                            \
+        _Pragma("unroll") for (int pp = 0; pp < 2; ++pp) {                                      \
+            fb[SET][pp][0] = __builtin_bit_cast(bf16x8, it_[bofs[pp]]);                         \
+            fb[SET][pp][1] = __builtin_bit_cast(bf16x8, it_[plane + bofs[pp]]);                 \
+        }                                                                                       \
+    }
+#define CB_LD_A(SET, tb, m_)                                                                    \
+    {                                                                                           \
+        const uint4* wt_ = wt0 + (tb) * 4 * NT + (m_) * 32;                                     \
+        fa[SET][0] = __builtin_bit_cast(bf16x8, wt_[0]);                                        \
+        fa[SET][1] = __builtin_bit_cast(bf16x8, wt_[NT]);                                       \
+    }
+#define CB_TAP(BSET, A0, tb, has_next)                                                          \
+    _Pragma("unroll") for (int m = 0; m < MB; ++m) {                                            \
+        if (m + 1 < MB) {                                                                       \
+            CB_LD_A(((A0) + m + 1) & 1, tb, m + 1)                                              \
+        } else if (has_next) {                                                                  \
+            CB_LD_A(((A0) + m + 1) & 1, (tb) + 1, 0)                                            \
+            CB_LD_B((BSET) ^ 1, (tb) + 1)                                                       \
+        }                                                                                       \
+        __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ABOVE the MFMAs it is meant to hide under */ \
+        _Pragma("unroll") for (int pp = 0; pp < 2; ++pp) {                                      \
+            acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[((A0) + m) & 1][1], fb[BSET][pp][0], acc[m][pp], 0, 0, 0); \
+            acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[((A0) + m) & 1][0], fb[BSET][pp][1], acc[m][pp], 0, 0, 0); \
+            acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[((A0) + m) & 1][0], fb[BSET][pp][0], acc[m][pp], 0, 0, 0); \
+        }                                                                                       \
+    }
+            CB_LD_B(0, 0)
+            CB_LD_A(0, 0, 0)
+            int tb = 0;
+            for (; tb + 2 <= ntx; tb += 2) {
+                CB_TAP(0, 0, tb, true)
+                CB_TAP(1, (MB & 1), tb + 1, (tb + 2 < ntx))
+            }
+            if (tb < ntx) { CB_TAP(0, 0, tb, false) }
+#undef CB_LD_B
+#undef CB_LD_A
+#undef CB_TAP
+        }
+        __syncthreads();
+        if (++a == nt) { a = 0; ++ci; }
+      }
     }
     // ---- epilogue ------------------------------------------------------------------------------
     // Dense convolutions: the accumulators (one pixel column per lane, 16 couts in registers) go
@@ -519,7 +683,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (MB == 1 && NPW == 4) ? 4 : 2) void
 template <int TW, int MB>
 static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int halo_h, int halo_w, int ntx_max, int gz, hipStream_t st) {
     constexpr int NT = 32 * MB;
-    const int plane = halo_h * halo_w;
+    int plane = halo_h * halo_w;
     if (plane > 256 * CB_MAX_E) {
         ccvs_set_error("ccvs_conv2d_bf16x3: halo tile %dx%d too large", halo_h, halo_w);
         return CCVS_ERR_ARG;
@@ -527,23 +691,34 @@ static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int ha
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_kernel<TW, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
+    }
+    static const int ablate = getenv("CCVS_CONV_ABLATE") ? atoi(getenv("CCVS_CONV_ABLATE")) : 0;  // timing experiments only (1: no staging, 2: no MFMA, 4: scalar staging)
+    dim3 grid(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
+    // aligned float4 staging: dense stride-1 rows on 16-byte boundaries, one item per staging thread
+    const int xsh = ((-k.pad % 4) + 4) % 4, nq = (xsh + halo_w + 3) / 4;
+    const bool vec_ok = !k.transposed && k.stride == 1 && k.Win % 4 == 0 && k.in_sC % 4 == 0 && k.in_sN % 4 == 0 &&
+                        (reinterpret_cast<uintptr_t>(k.x) & 15) == 0 && TW >= 16 && halo_h * nq * 2 <= 256 && ntx_max <= 3 &&
+                        (k.kh == 1 || k.kh == 3) && !(ablate & 4);
+    if (vec_ok) {
+        const size_t smem_v = (size_t)(2 * 4 * halo_h * nq * 4 + 2 * ntx_max * 4 * NT) * 16;
+        if (smem_v <= 156 * 1024) {
+            if (k.kh == 3) hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 3>), grid, dim3(512), smem_v, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
+            else hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 1>), grid, dim3(512), smem_v, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
+            CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
+            return CCVS_OK;
+        }
     }
     const size_t smem_pc = (size_t)(2 * 4 * plane + 2 * ntx_max * 4 * NT) * 16;
     const int nt_min = (k.transposed ? 1 : k.kh);               // fewest tap rows of any parity class
     const int passes = (plane + 255) / 256;
     const bool regs_ok = (ntx_max <= 3) && (passes <= CB_XQ * nt_min);
     // (8 staging waves for <= 64 output channels were measured slower: the steps are latency- not staging-bound)
-    constexpr bool kManyStagers = false;
-    if (smem_pc <= 156 * 1024 && regs_ok) {  // double-buffered producer / consumer form
-        dim3 grid(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
-        static const int ablate = getenv("CCVS_CONV_ABLATE") ? atoi(getenv("CCVS_CONV_ABLATE")) : 0;  // timing experiments only (1: no staging, 2: no MFMA)
-        if (kManyStagers)
-            hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 8>), grid, dim3(768), smem_pc, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
-        else
-            hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 4>), grid, dim3(512), smem_pc, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
+    if (smem_pc <= 156 * 1024 && regs_ok) {  // double-buffered producer / consumer form, scalar staging
+        hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 0>), grid, dim3(512), smem_pc, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
         CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
         return CCVS_OK;
     }
@@ -552,7 +727,6 @@ static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int ha
         ccvs_set_error("ccvs_conv2d_bf16x3: %zu bytes of LDS needed", smem);
         return CCVS_ERR_ARG;
     }
-    dim3 grid(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
     hipLaunchKernelGGL((conv2d_bf16x3_kernel<TW, MB>), grid, dim3(256), smem, st, k, (const uint4*)wsplit, CinG);
     CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
     return CCVS_OK;
