@@ -228,3 +228,41 @@ def test_bair_scale_encode_decode_frame_vs_oracle():
         orgb, oflows, ooccs = O.decoder_forward(nets["g"], qopt, want["z"][:, :1].contiguous(), octx, return_all=True)
     assert maxdiff(rgb, orgb) < PIX_TOL, maxdiff(rgb, orgb)
     assert maxdiff(flows[-1], oflows[-1]) < PIX_TOL and maxdiff(occs[-1], ooccs[-1]) < PIX_TOL
+
+
+def test_multi_frame_conditioning_vs_oracle(tiny):
+    """Kinetics-style conditioning (BASELINE config 3 in miniature): 2 conditioning frames -> 2 predicted."""
+    from ccvs_amd.helpers.generator import Generator
+    xopt = tiny["xopt"]
+    old = xopt.cond_len
+    xopt.cond_len, xopt.sample = 128, False
+    try:
+        gen = Generator(tiny["opt"])
+        gen.vid_model, gen.transformer_model = tiny["qv"], tiny["tr"]
+        data = gen.synthetic_batch(2, seed=21)
+        out = gen.generate_vid({"vid": data["vid"].clone()})
+        trace = []
+        want = O.generate_vid(tiny["nets"], tiny["qopt"], xopt, data["vid"], trace=trace)
+        assert torch.equal(out["enc_code"].cpu(), want["enc_code"])
+        _audit_tokens(out["fake"]["code"], want["code"], lambda b, t: trace[t - 128][b])
+        if torch.equal(out["fake"]["code"].cpu(), want["code"]):
+            assert maxdiff(out["fake"]["vid"], want["vid"]) < PIX_TOL
+    finally:
+        xopt.cond_len = old
+
+
+def test_sliding_token_window_vs_oracle(tiny):
+    """total_len > z_len: the token window slides by one frame per fill (transformer_model.py:283-323); every slide
+    restarts positions at 0, so the KV-cached engine re-prefills the window."""
+    tr, xopt = tiny["tr"], tiny["xopt"]
+    xopt.sample, xopt.top_k = False, 10
+    code = torch.from_numpy(tiny["gold"]["gen_code_greedy"])[:, :64].clone()
+    total = 256 + 2 * 64   # z_len = 256: two slides
+    out = tr({"code": code.clone()}, mode="inference", total_len=total)["code"].cpu()
+    trace = []
+    want = O.generate_fake(tiny["nets"]["t"], xopt, code, total_len=total, trace=trace)
+    assert out.shape == want.shape == (2, total)
+    if not torch.equal(out, want):
+        b, t = (out != want).nonzero()[0].tolist()
+        lg = trace[t - 64][b]
+        assert (lg[out[b, t]] - lg[want[b, t]]).abs().item() < 1e-4
