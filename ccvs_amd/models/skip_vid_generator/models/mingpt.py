@@ -106,16 +106,16 @@ class GPT(nn.Module):
                  attn_pdrop=0., n_unmasked=0, resid_noise=False, emb_mode=None, shape=None, state_vocab_size=0, state_size=0,
                  use_start_token=False, num_lbl=0, use_lbl=False, state_front=False):
         super().__init__()
-        if state_vocab_size > 0 or state_size > 0 or use_start_token or use_lbl or n_unmasked:
-            raise NotImplementedError("state / start / label token streams are not on the MI355X path yet (SURVEY 8f)")
-        if (embd_pdrop or resid_pdrop or attn_pdrop) and False:
-            pass
+        if use_start_token or use_lbl or n_unmasked:
+            raise NotImplementedError("start / label tokens and unmasked prefixes are not on the MI355X path (SURVEY 8f)")
         config = GPTConfig(block_size=block_size, vocab_size=vocab_size, embd_pdrop=embd_pdrop, resid_pdrop=resid_pdrop,
                            attn_pdrop=attn_pdrop, n_layer=n_layer, n_head=n_head, n_embd=n_embd, n_unmasked=n_unmasked,
                            resid_noise=resid_noise, shape=shape, emb_mode=emb_mode, state_vocab_size=state_vocab_size,
                            state_size=state_size, use_start_token=use_start_token, num_blocks=num_blocks, num_lbl=num_lbl,
                            use_lbl=use_lbl, state_front=state_front)
         self.tok_emb = nn.Embedding(config.vocab_size, config.n_embd)
+        if config.state_vocab_size > 0:  # ancillary (state / STFT) token stream, mingpt.py:134-135
+            self.state_tok_emb = nn.Embedding(config.state_vocab_size, config.n_embd)
         height, width = config.shape
         if config.emb_mode is not None:
             if config.emb_mode == "spatio-temporal":
@@ -129,6 +129,11 @@ class GPT(nn.Module):
                 raise ValueError
         else:
             self.pos_emb = nn.Parameter(torch.zeros(1, config.num_blocks * height * width, config.n_embd))
+        if config.state_size > 0:  # mingpt.py:158-162
+            if config.emb_mode is not None:
+                self.state_s_emb = nn.Parameter(torch.zeros(1, config.state_size, config.n_embd))
+            else:
+                self.state_pos_emb = nn.Parameter(torch.zeros(1, config.num_blocks * config.state_size, config.n_embd))
         self.drop = nn.Dropout(config.embd_pdrop)
         self.blocks = nn.Sequential(*[Block(config) for _ in range(config.n_layer)])
         self.ln_f = nn.LayerNorm(config.n_embd)
@@ -177,13 +182,88 @@ class GPT(nn.Module):
             pos = pos + t_emb.view(n, length, 1, 1, -1)
         return pos.reshape(n, length * size, -1)[:, :t]
 
+    @torch.no_grad()
+    def get_state_pos_emb(self, t):
+        """[1, t, C] positional embeddings of the ancillary stream (mingpt.py:219-230)."""
+        cfg = self.config
+        size = cfg.state_size
+        if cfg.emb_mode is not None:
+            length = t // size + (1 if t % size != 0 else 0)
+            pos = self.state_s_emb.view(1, 1, size, -1) + self.t_emb[:, :length].view(1, length, 1, -1)
+            return pos.reshape(1, length * size, -1)[:, :t]
+        return self.state_pos_emb[:, :t]
+
+    # ------------------------------------------------------------------ ancillary stream layout
+    def stream_kinds(self, n_code, n_state):
+        """The merged sequence of `GPT.forward` (mingpt.py:246-282) for n_code frame tokens and n_state ancillary tokens:
+        a list of (kind, index) with kind 0 = frame token `index`, 1 = ancillary token `index`.  Per frame the
+        `state_size` ancillary tokens precede the frame's h*w tokens (`state_front`: all ancillary tokens first)."""
+        cfg = self.config
+        size, ss = cfg.shape[0] * cfg.shape[1], cfg.state_size
+        n_state = min(n_state, cfg.num_blocks * ss)  # mingpt.py:249
+        if n_state == 0:
+            return [(0, i) for i in range(n_code)]
+        if cfg.state_front:
+            return [(1, i) for i in range(n_state)] + [(0, i) for i in range(n_code)]
+        length = n_code // size
+        if length == 0:
+            # reference quirk (mingpt.py:281-282): with less than one whole frame the frame tokens are DROPPED
+            return [(1, i) for i in range(min(ss, n_state))]
+        assert n_state >= length * ss, "ancillary stream shorter than the frames it annotates (the reference's view() fails too)"
+        seq = []
+        for f in range(length):
+            seq += [(1, f * ss + i) for i in range(ss)] + [(0, f * size + i) for i in range(size)]
+        seq += [(1, i) for i in range(length * ss, min((length + 1) * ss, n_state))]
+        seq += [(0, i) for i in range(length * size, n_code)]
+        return seq
+
+    def _token_table(self):
+        """Embedding rows addressed by the engine: [tok_emb ; state_tok_emb] (an ancillary token v is row vocab_size + v)."""
+        if self.config.state_vocab_size <= 0:
+            return self.tok_emb.weight
+        src = (self.tok_emb.weight, self.state_tok_emb.weight)
+        key = tuple((t.data_ptr(), t._version) for t in src) + (src[0].device,)
+        tt = getattr(self, "_tok_table", None)
+        if tt is None or tt[0] != key:
+            tt = self._tok_table = (key, torch.cat([t.detach() for t in src], dim=0).contiguous())
+        return tt[1]
+
+    def _stream_rows(self, code, state_code):
+        """[B, T] embedding-table rows of the merged sequence of (code, state_code)."""
+        kinds = self.stream_kinds(code.shape[1], 0 if state_code is None else state_code.shape[1])
+        dev = code.device
+        kind = torch.tensor([k for k, _ in kinds], dtype=torch.bool, device=dev)
+        idx = torch.tensor([i for _, i in kinds], dtype=torch.long, device=dev)
+        frame_rows = code[:, idx.clamp(max=max(code.shape[1] - 1, 0))] if code.shape[1] else torch.zeros(code.shape[0], len(kinds), dtype=torch.long, device=dev)
+        if state_code is None or state_code.shape[1] == 0:
+            return frame_rows.contiguous()
+        state_rows = state_code[:, idx.clamp(max=state_code.shape[1] - 1)] + self.config.vocab_size
+        return torch.where(kind.view(1, -1), state_rows, frame_rows).contiguous()
+
+    def _stream_pos_table(self, n_rows, n_state_front=0):
+        """[n_rows, C] positional rows in merged-sequence order."""
+        cfg = self.config
+        size, ss = cfg.shape[0] * cfg.shape[1], cfg.state_size
+        if cfg.state_front:
+            parts = [self.get_state_pos_emb(n_state_front)[0]] if n_state_front else []
+            if n_rows - n_state_front > 0:
+                parts.append(self.get_pos_emb(n_rows - n_state_front)[0])
+            return torch.cat(parts, dim=0)
+        tot = size + ss
+        nf = (n_rows + tot - 1) // tot
+        assert nf <= cfg.num_blocks, "Cannot forward, model block size is exhausted."
+        fp = self.get_pos_emb(nf * size)[0].view(nf, size, -1)
+        sp = self.get_state_pos_emb(nf * ss)[0].view(nf, ss, -1)
+        return torch.cat([sp, fp], dim=1).reshape(nf * tot, -1)[:n_rows]
+
     # ------------------------------------------------------------------ incremental engine
     @torch.no_grad()
-    def begin(self, batch, max_len):
+    def begin(self, batch, max_len, stream=False, n_state_front=0):
         """Allocate (or reuse) the KV cache and the device-resident decode state for `batch` sequences of
-        at most `max_len` positions."""
+        at most `max_len` positions.  `stream`: positions are those of the merged frame / ancillary sequence."""
         cfg = self.config
-        assert max_len <= self.block_size, "Cannot forward, model block size is exhausted."  # mingpt.py:299
+        if not stream:
+            assert max_len <= self.block_size, "Cannot forward, model block size is exhausted."  # mingpt.py:299
         dev = self.tok_emb.weight.device
         d = cfg.n_embd // cfg.n_head
         c = self._cache
@@ -206,11 +286,17 @@ class GPT(nn.Module):
                 "desc": None,
             }
         c["len"] = 0
-        table = self.get_pos_emb(min(c["T"], self.block_size))[0]
-        if "pos_table" in c:
+        c["stream"] = bool(stream)
+        if stream:
+            tot = cfg.shape[0] * cfg.shape[1] + cfg.state_size
+            table = self._stream_pos_table(c["T"] if cfg.state_front else min(c["T"], cfg.num_blocks * tot), n_state_front)
+        else:
+            table = self.get_pos_emb(min(c["T"], self.block_size))[0]
+        if "pos_table" in c and c["pos_table"].shape == table.shape:
             c["pos_table"].copy_(table)   # same storage: captured graphs keep pointing at it
         else:
             c["pos_table"] = table.contiguous().clone()
+            c["desc"], self._graphs = None, {}
         c["frame_pos0"] = 0
         return c
 
@@ -247,7 +333,8 @@ class GPT(nn.Module):
 
     @torch.no_grad()
     def prefill(self, idx, cond_idx=None, delta_length_cond=None, all_logits=False):
-        """Run [cond prefix | idx] through the network, filling the cache from position 0.
+        """Run [cond prefix | idx] through the network, filling the cache from position 0.  `idx` holds rows of
+        `_token_table()` (= frame token ids; merged-sequence rows for a stream cache, see `_stream_rows`).
         Returns logits of the last position [B,V], or of every idx position [B,T,V]."""
         c = self._cache
         b, t = idx.shape
@@ -261,10 +348,10 @@ class GPT(nn.Module):
                 cond_tab = cond_tab.expand(b, -1, -1)
             table = torch.cat([c["pos_table"], cond_tab.reshape(-1, C)], dim=0).contiguous()
             off = (c["pos_table"].shape[0] + torch.arange(b, dtype=torch.int32) * t_cond).to(idx.device)
-            parts.append(ops.gpt_embed(cond_idx.contiguous(), self.tok_emb.weight, table, 0, off).view(b, t_cond, C))
+            parts.append(ops.gpt_embed(cond_idx.contiguous(), self._token_table(), table, 0, off).view(b, t_cond, C))
         else:
             t_cond = 0
-        parts.append(ops.gpt_embed(idx.contiguous(), self.tok_emb.weight, c["pos_table"], 0).view(b, t, C))
+        parts.append(ops.gpt_embed(idx.contiguous(), self._token_table(), c["pos_table"], 0).view(b, t, C))
         x = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
         tq = t_cond + t
         assert c["len"] == 0 and tq <= c["T"], "Cannot forward, model block size is exhausted."
@@ -282,9 +369,20 @@ class GPT(nn.Module):
         b = tok.shape[0]
         frame_pos = c["len"] - c["frame_pos0"]
         assert c["len"] < c["T"], "Cannot forward, model block size is exhausted."
-        x = ops.gpt_embed(tok, self.tok_emb.weight, c["pos_table"], frame_pos)
+        x = ops.gpt_embed(tok, self._token_table(), c["pos_table"], frame_pos)
         x = self._layers(x, b, 1)
         return self._head(x)
+
+    @torch.no_grad()
+    def extend(self, rows):
+        """Append tq >= 1 more positions (rows of `_token_table()`, [B,tq]) to the cache; logits of the last one [B,V]."""
+        c = self._cache
+        b, tq = rows.shape
+        C = self.config.n_embd
+        assert c["len"] + tq <= c["T"], "Cannot forward, model block size is exhausted."
+        x = ops.gpt_embed(rows.contiguous(), self._token_table(), c["pos_table"], c["len"] - c["frame_pos0"])
+        x = self._layers(x.view(b * tq, C), b, tq)
+        return self._head(x.view(b, tq, C)[:, -1].contiguous())
 
     # -- sampled generation: prefill + (add_len - 1) decode steps, all state on the device ----------
     def _decode_desc(self, sampler):
@@ -305,7 +403,7 @@ class GPT(nn.Module):
                                    kcache=c["k"][i], vcache=c["v"][i]))
             desc = ops.GptDecodeStep(
                 layers, B=c["B"], C=cfg.n_embd, H=cfg.n_head, Tmax=c["T"], ln_eps=self.ln_f.eps,
-                tok_emb=self.tok_emb.weight, pos_table=c["pos_table"], pos_off=-c["frame_pos0"], head=(hw, hb, hs),
+                tok_emb=self._token_table(), pos_table=c["pos_table"], pos_off=-c["frame_pos0"], head=(hw, hb, hs),
                 tok=c["tok"], codes=c["codes"], widx=c["widx"], length=c["len_dev"],
                 x=c["x"], q=c["q"], att=c["att"], h=c["h"], logits=c["logits"],
                 noise=c["noise"] if (sampler["sample"] and not device_rng) else None, rng=device_rng,
@@ -332,10 +430,139 @@ class GPT(nn.Module):
         if trace is not None:
             trace.append(c["logits"].clone())
 
+    def _decode_graph(self, sampler, key):
+        """The decode step of the current cache captured in a hipGraph (once per key).  Captured on live state: a warm-up
+        step runs first (one-time attribute calls, descriptor), then the device-resident state is put back."""
+        c = self._cache
+        graph = self._graphs.get(key)
+        if graph is None:
+            state = {k: c[k].clone() for k in ("len_dev", "widx", "tok", "codes", "state")}
+            warm = torch.cuda.Stream()
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                self._decode_body(sampler)
+            torch.cuda.current_stream().wait_stream(warm)
+            for k, v in state.items():
+                c[k].copy_(v)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._decode_body(sampler)
+            for k, v in state.items():   # capture does not execute; kept for clarity
+                c[k].copy_(v)
+            self._graphs[key] = graph
+        return graph
+
+    @torch.no_grad()
+    def _generate_stream(self, code, state_code, add_len, cond_idx, delta_length_cond, sampler, state_sampler, host_noise, trace,
+                         use_graph):
+        """`Transformer.fill_code` (transformer_model.py:343-392) for a frame + ancillary token stream on the KV cache.
+        The merged sequence only ever grows at its end, so each new token (plus, at a frame boundary, the next frame's
+        given ancillary tokens) is appended to the cache: runs of frame tokens replay the captured decode step, the
+        rest goes through `extend`."""
+        cfg = self.config
+        if cfg.state_front:
+            raise NotImplementedError("state_front generation re-orders the merged sequence at every ancillary token")
+        size, ss = cfg.shape[0] * cfg.shape[1], cfg.state_size
+        tot = size + ss
+        b, t0 = code.shape
+        ns0 = state_code.shape[1]
+        cap = cfg.num_blocks * ss
+        if t0 < size:
+            raise NotImplementedError("less than one whole frame of tokens with an ancillary stream (the reference drops them)")
+        n_cond = cond_idx.shape[1] if cond_idx is not None else 0
+        slen = lambda nc, nst: len(self.stream_kinds(nc, nst))
+        # which stream each of the add_len picks goes to (transformer_model.py:352), and whether the step before pick i
+        # appends exactly the frame token picked at i-1 (then it is a replay of the captured decode step)
+        plan, single = [], []
+        nc, nst = t0, ns0
+        for i in range(add_len):
+            fed = slen(nc, nst)
+            is_state = fed % tot < ss
+            plan.append(1 if is_state else 0)
+            single.append(i > 0 and plan[i - 1] == 0 and not is_state and fed - prev_fed == 1)
+            prev_fed = fed
+            if is_state:
+                nst += 1
+            else:
+                nc += 1
+        assert n_cond + nc <= self.block_size, "Cannot forward, model block size is exhausted."  # mingpt.py:299 (frame tokens)
+        max_len = n_cond + slen(nc, nst)
+        c = self.begin(b, max_len, stream=True)
+        dev = code.device
+        frame_codes = c["codes"]          # the captured step stores its picks here
+        frame_codes[:, :t0] = code
+        state_buf = torch.zeros(b, max(nst, ns0), dtype=torch.int64, device=dev)
+        state_buf[:, :ns0] = state_code
+        n_code, n_state = t0, ns0
+        device_noise = sampler["sample"] and sampler["noise"] == "device"
+        eager = trace is not None or (sampler["sample"] and not device_noise) or not use_graph
+        c["state"].zero_()
+        if device_noise:
+            c["state"][4:6] = torch.randint(-2**31, 2**31 - 1, (2,), dtype=torch.int64).to(torch.int32).to(dev)
+
+        def rows_of(lo, hi):  # merged-sequence rows [lo, hi) from the current buffers
+            kinds = self.stream_kinds(n_code, n_state)[lo:hi]
+            cols = [frame_codes[:, i:i + 1] if k == 0 else state_buf[:, i:i + 1] + cfg.vocab_size for k, i in kinds]
+            return torch.cat(cols, dim=1)
+
+        def draw(kind, width):
+            smp = state_sampler if kind else sampler
+            if not smp["sample"]:
+                return None
+            if smp.get("noise", sampler["noise"]) == "device" and device_noise:
+                return torch.empty(b, width, dtype=torch.float32, device=dev).exponential_(1)
+            return host_noise(b, width).to(dev, non_blocking=True)
+
+        logits = self.prefill(self._stream_rows(code, state_code), cond_idx, delta_length_cond)
+        fed = slen(n_code, n_state)
+        i = 0
+        while i < add_len:
+            if single[i] and not eager:
+                run = 1
+                while i + run < add_len and single[i + run]:
+                    run += 1
+                c["len_dev"].fill_(c["len"])
+                c["widx"].fill_(n_code)
+                graph = self._decode_graph(sampler, (sampler["sample"], sampler["top_k"], sampler["temperature"], n_cond, b, "stream"))
+                for _ in range(run):
+                    graph.replay()
+                c["len"] += run          # each replay appended the previous pick, then picked the next
+                n_code += run
+                fed += run
+                i += run
+                logits = None
+                continue
+            if logits is None:           # after a graph run: the last pick (and what follows it) is not in the cache yet
+                new_fed = slen(n_code, n_state)
+                logits = self.extend(rows_of(fed, new_fed))
+                fed = new_fed
+            if plan[i]:
+                lg = logits[:, :state_sampler["vocab"]].contiguous()
+                if trace is not None:
+                    trace.append(lg.clone())
+                tok = ops.sample_topk(lg, state_sampler["top_k"], state_sampler["temperature"], noise=draw(1, lg.shape[1]))
+                state_buf[:, n_state] = tok
+                n_state += 1
+            else:
+                if trace is not None:
+                    trace.append(logits.clone())
+                ops.sample_topk(logits, sampler["top_k"], sampler["temperature"], noise=draw(0, logits.shape[1]), out=c["tok"])
+                frame_codes[:, n_code] = c["tok"][:, 0]
+                n_code += 1
+            i += 1
+            logits = None
+            if i < add_len and not (single[i] and not eager):
+                new_fed = slen(n_code, n_state)
+                logits = self.extend(rows_of(fed, new_fed))
+                fed = new_fed
+        return frame_codes[:, :n_code].clone(), state_buf[:, :n_state].clone()
+
     @torch.no_grad()
     def generate(self, code, add_len, cond_idx=None, delta_length_cond=None, sample=False, top_k=None, temperature=1.0,
-                 noise="device", host_noise=None, trace=None, use_graph=True):
+                 noise="device", host_noise=None, trace=None, use_graph=True, state_code=None, state_sampler=None):
         """code [B,t0] -> [B, t0+add_len]: one prefill, then KV-cached decode steps.
+        With an ancillary stream (`state_code` [B,ns], `state_sampler` = dict(sample, top_k, temperature, vocab)) the
+        add_len new tokens are split between the two streams as the reference does and (code, state_code) is returned.
 
         With device (or no) noise and no trace the decode step is captured ONCE in a hipGraph and
         replayed.  With host-supplied noise (`host_noise(b, v) -> [B,V]`, reference-reproducible) the same
@@ -344,6 +571,9 @@ class GPT(nn.Module):
         use_cond = cond_idx is not None and 0 not in cond_idx.size()
         n_cond = cond_idx.shape[1] if use_cond else 0
         sampler = {"sample": bool(sample), "top_k": top_k, "temperature": float(temperature), "noise": noise}
+        if state_code is not None and 0 not in state_code.size():
+            return self._generate_stream(code, state_code, add_len, cond_idx if use_cond else None,
+                                         delta_length_cond if use_cond else None, sampler, state_sampler, host_noise, trace, use_graph)
         eager = trace is not None or (sample and noise != "device") or not use_graph or add_len < 3
         max_len = n_cond + t0 + add_len
         c = self.begin(b, max_len)
@@ -365,26 +595,7 @@ class GPT(nn.Module):
             c["state"][4:6] = torch.randint(-2**31, 2**31 - 1, (2,), dtype=torch.int64).to(torch.int32).to(c["state"].device)
         self._emit(logits, sampler, draw(logits), t0)
 
-        graph = None
-        if not eager:
-            key = (bool(sample), top_k, float(temperature), n_cond, b)
-            graph = self._graphs.get(key)
-            if graph is None:
-                # capture on live state: the warm-up step and the captured step are steps 1 and 2 of this very call
-                state = {k: c[k].clone() for k in ("len_dev", "widx", "tok", "codes", "state")}
-                warm = torch.cuda.Stream()
-                warm.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(warm):               # warm-up: one-time attribute calls, descriptor, events
-                    self._decode_body(sampler)
-                torch.cuda.current_stream().wait_stream(warm)
-                for k, v in state.items():
-                    c[k].copy_(v)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    self._decode_body(sampler)
-                for k, v in state.items():                  # capture does not execute; restore is a no-op kept for clarity
-                    c[k].copy_(v)
-                self._graphs[key] = graph
+        graph = None if eager else self._decode_graph(sampler, (bool(sample), top_k, float(temperature), n_cond, b))
         for _ in range(add_len - 1):
             if graph is not None:
                 graph.replay()
@@ -399,9 +610,16 @@ class GPT(nn.Module):
     # ------------------------------------------------------------------ reference-shaped forward
     @torch.no_grad()
     def forward(self, idx, cond_idx=torch.tensor([]), state_idx=torch.tensor([]), lbl_idx=torch.tensor([]), delta_length_cond=None):
-        """Teacher-forced logits [B, T, V] for positions after the conditioning prefix (mingpt.py:232-305)."""
-        if 0 not in state_idx.size() or 0 not in lbl_idx.size():
-            raise NotImplementedError("state / label token streams are not on the MI355X path yet (SURVEY 8f)")
+        """Teacher-forced logits [B, T, V] for positions after the conditioning prefix (mingpt.py:232-305); with an
+        ancillary stream T counts the merged sequence."""
+        if 0 not in lbl_idx.size():
+            raise NotImplementedError("label tokens are not on the MI355X path (SURVEY 8f)")
         t_cond = cond_idx.shape[1] if 0 not in cond_idx.size() else 0
+        assert t_cond + idx.shape[1] <= self.block_size, "Cannot forward, model block size is exhausted."  # mingpt.py:299
+        if 0 not in state_idx.size():
+            state_idx = state_idx[:, :self.config.num_blocks * self.config.state_size].to(idx.device)
+            rows = self._stream_rows(idx, state_idx)
+            self.begin(idx.shape[0], t_cond + rows.shape[1], stream=True, n_state_front=state_idx.shape[1])
+            return self.prefill(rows, cond_idx if t_cond else None, delta_length_cond, all_logits=True)
         self.begin(idx.shape[0], t_cond + idx.shape[1])
         return self.prefill(idx, cond_idx if t_cond else None, delta_length_cond, all_logits=True)

@@ -415,3 +415,22 @@ class SkipGANDecoder(nn.Module):
         if return_all:
             return out1, out2, inter_flows, inter_occs, [unflatten_vid(f, vid_size) for f in inter_dec]
         return out1, out2
+
+
+class StftEncoder(nn.Module):
+    """skip_autoencoder.py:530-542: spectrogram frame [1,H,W] -> [stft_size, H/8, W/8]: 1x1 conv, three blur + stride-2
+    3x3 convs, one 3x3 conv (all ConvLayers with bias + LeakyReLU(0.1))."""
+
+    def __init__(self, opt):
+        super().__init__()
+        convs = [ConvLayer(1, opt.stft_hsize, 1, downsample=False)]
+        for _ in range(3):
+            convs.append(ConvLayer(opt.stft_hsize, opt.stft_hsize, 3, downsample=True))
+        convs.append(ConvLayer(opt.stft_hsize, opt.stft_size, 3, downsample=False))
+        self.convs = nn.Sequential(*convs)
+
+    def forward(self, input):
+        x, vid_size = flatten_vid(input)
+        for conv in self.convs:
+            x = conv(x.contiguous())
+        return unflatten_vid(x, vid_size)

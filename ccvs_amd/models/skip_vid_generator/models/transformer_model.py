@@ -78,11 +78,10 @@ class Transformer(torch.nn.Module):
 
     @torch.no_grad()
     def generate_fake(self, code, state_code, cond_code, delta_length_cond, vid_lbl, total_len, show_progress=False):
-        """transformer_model.py:263-328, including the sliding token window for total_len > z_len
-        (each slide restarts positions at 0, so the window is re-prefilled)."""
-        if 0 not in state_code.size():
-            raise NotImplementedError("state / stft token streams are not on the MI355X path yet (SURVEY 8f)")
+        """transformer_model.py:263-328, including the sliding token window for total_len > z_len (each slide restarts
+        positions at 0, so the window is re-prefilled) and the ancillary (state / STFT) stream bookkeeping."""
         opt = self.opt
+        use_state = 0 not in state_code.size()
         n_cond = cond_code.size(1) if 0 not in cond_code.size() else 0
         if total_len is None:
             code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl)
@@ -90,6 +89,7 @@ class Transformer(torch.nn.Module):
         total_len = int(total_len)
         if total_len <= opt.z_len:
             add_len = total_len - code.size(1) - n_cond
+            add_len -= min(state_code.size(1), opt.state_size * opt.num_blocks) if use_state else 0
             code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl, add_len=add_len)
             return {"code": code, "state_code": state_code}
         code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl)
@@ -99,10 +99,15 @@ class Transformer(torch.nn.Module):
             add_len = total_len - curr_len if total_len - curr_len < opt.z_chunk else None
             if n_cond:
                 delta_length_cond = delta_length_cond - 1
+            tmp_state_code = state_code[:, i * self.state_size:] if use_state else state_code
             tmp_code = code[:, i * self.size:]
-            pred_code, _ = self.fill_code(tmp_code, state_code, cond_code, delta_length_cond, vid_lbl, add_len=add_len)
+            pred_code, pred_state_code = self.fill_code(tmp_code, tmp_state_code, cond_code, delta_length_cond, vid_lbl, add_len=add_len)
             delta_code = pred_code.size(1) - tmp_code.size(1)
             code = torch.cat([code, pred_code[:, -delta_code:]], dim=1)
+            if use_state:
+                delta_state_code = pred_state_code.size(1) - tmp_state_code.size(1)
+                if delta_state_code > 0:
+                    state_code = torch.cat([state_code, pred_state_code[:, -delta_state_code:]], dim=1)
             curr_len += add_len if add_len is not None else opt.z_chunk
             i += 1
         return {"code": code, "state_code": state_code}
@@ -121,16 +126,25 @@ class Transformer(torch.nn.Module):
             raise NotImplementedError("beam search is not on the MI355X path yet (SURVEY 8f)")
         b, t0 = code.shape
         n_cond = cond_code.size(1) if 0 not in cond_code.size() else 0
-        if add_len is None:
+        use_state = 0 not in state_code.size()
+        if add_len is None:  # transformer_model.py:336-339
             add_len = opt.z_len - t0 - n_cond
+            add_len -= min(state_code.size(1), opt.state_size * opt.num_blocks) if use_state else 0
         if add_len <= 0:
             return code, state_code
         def host_noise(nb, nv):  # the stream torch.multinomial would consume (module docstring)
             return torch.empty(nb, nv, dtype=torch.float32).exponential_(1, generator=self.generator)
 
+        state_sampler = None
+        if use_state:  # ancillary tokens: first state_num logits, their own sampling options (transformer_model.py:353-356)
+            state_sampler = {"sample": bool(opt.sample_state), "top_k": opt.top_k_state, "temperature": float(opt.temperature_state),
+                             "vocab": opt.state_num}
         out = self.net_t.generate(code, add_len, cond_code if n_cond else None, delta_length_cond if n_cond else None,
                                   sample=opt.sample, top_k=opt.top_k, temperature=opt.temperature, noise=self.sample_noise,
-                                  host_noise=host_noise, trace=self.trace, use_graph=getattr(opt, "use_graph", True))
+                                  host_noise=host_noise, trace=self.trace, use_graph=getattr(opt, "use_graph", True),
+                                  state_code=state_code if use_state else None, state_sampler=state_sampler)
+        if use_state:
+            return out
         return out, state_code
 
     @torch.no_grad()

@@ -25,7 +25,12 @@ class VectorQuantizer(nn.Module):
         key = (w.data_ptr(), w._version, w.device)
         if self._packed is None or self._packed[0] != key:
             wd = w.detach()
-            self._packed = (key, wd.t().contiguous(), (wd ** 2).sum(dim=1).contiguous())
+            cbt, esq = wd.t().contiguous(), (wd ** 2).sum(dim=1).contiguous()
+            pad = (-wd.shape[0]) % 32  # the argmin kernel streams the codebook in blocks of 32 codes
+            if pad:  # padding codes sit at distance +inf: never the nearest
+                cbt = torch.cat([cbt, torch.zeros(cbt.shape[0], pad, dtype=cbt.dtype, device=cbt.device)], dim=1).contiguous()
+                esq = torch.cat([esq, torch.full((pad,), float("inf"), dtype=esq.dtype, device=esq.device)]).contiguous()
+            self._packed = (key, cbt, esq)
         return self._packed[1], self._packed[2]
 
     @torch.no_grad()

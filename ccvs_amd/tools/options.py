@@ -124,6 +124,10 @@ class Options:
         p.add_argument("--a_stft_size", type=int, default=None)
         p.add_argument("--a_stft_shape", type=int, nargs="+", default=None)
         p.add_argument("--a_stft_num", type=int, default=None)
+        p.add_argument("--a_stft_hsize", type=int, default=128)
+        p.add_argument("--a_load_path", type=str, default=None)
+        p.add_argument("--a_which_iter", type=str, default=0)
+        p.add_argument("--a_not_strict", action="store_true")
         return parser
 
     def update_defaults(self, opt, parser):

@@ -131,6 +131,78 @@ def tiny_end_to_end(ns):
     return qopt, xopt
 
 
+def tiny_state_stream(ns):
+    """Ancillary-token stream (BASELINE config 5 in miniature): StftModel.encode, GPT.forward with the
+    state / frame interleave, and Transformer.generate_fake with given and with predicted STFT tokens."""
+    opt = rh.parse_reference_options(rh.TINY_STATE_ARGV)
+    xopt, aopt = opt["transformer"], opt["stft_ae"]
+    torch.manual_seed(0)
+    tr = ns.tm.Transformer(xopt, is_train=False, is_main=True).eval()
+    sm = ns.stft_model.StftModel(aopt, is_train=False, is_main=True).eval()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        tr.net_t.s_emb.normal_(0, 0.02, generator=g)
+        tr.net_t.t_emb.normal_(0, 0.02, generator=g)
+        tr.net_t.state_s_emb.normal_(0, 0.02, generator=g)
+    out = {}
+    with torch.no_grad():
+        torch.manual_seed(11)
+        stft = torch.rand(2, 5, 1, 16, 8) * 2 - 1
+        z = sm.net_e(stft)
+        torch.manual_seed(12)
+        sm.net_q.embedding.weight.copy_(torch.randn_like(sm.net_q.embedding.weight) * z.std())
+        state_code = sm({"stft": stft.clone()}, mode="vid_encoder")["state_code"]          # [2, 5 * 2]
+        out["stft"], out["stft_z"], out["state_code"] = stft, z, state_code
+        torch.manual_seed(13)
+        code = torch.randint(0, 32, (2, 64 * 3 + 10))
+        # teacher-forced logits, interleaved stream (3 full frames + a partial one, states of 4 frames)
+        out["tf_code"] = code
+        out["tf_logits"] = tr.net_t(code, state_idx=state_code[:, :8])
+        xopt.sample, xopt.top_k, xopt.sample_state = False, 10, False
+        # (a) STFT tokens of every frame given (keep_state): only frame tokens are predicted
+        total = 4 * 64 + 4 * 2
+        fa = tr({"code": code[:, :64].clone(), "state_code": state_code[:, :8].clone()}, mode="inference", total_len=total)
+        out["given_code"], out["given_state"] = fa["code"], fa["state_code"]
+        # (b) STFT tokens of the first frame only: the others are predicted too
+        fb = tr({"code": code[:, :64].clone(), "state_code": state_code[:, :2].clone()}, mode="inference", total_len=total)
+        out["pred_code"], out["pred_state"] = fb["code"], fb["state_code"]
+        # (c) 5 frames through the 4-frame window (one slide), STFT tokens given
+        total5 = 5 * 64 + 5 * 2
+        fc = tr({"code": code[:, :64].clone(), "state_code": state_code.clone()}, mode="inference", total_len=total5)
+        out["slide_code"], out["slide_state"] = fc["code"], fc["state_code"]
+        # (d) sampled, both streams (seeded multinomial)
+        xopt.sample, xopt.sample_state = True, True
+        torch.manual_seed(7)
+        fd = tr({"code": code[:, :64].clone(), "state_code": state_code[:, :2].clone()}, mode="inference", total_len=64 + 2 + 2 + 6)
+        out["samp_code"], out["samp_state"] = fd["code"], fd["state_code"]
+        xopt.sample, xopt.sample_state = False, False
+
+    nets = {"t": tr.net_t.state_dict(), "ae": sm.net_e.state_dict(), "aq": sm.net_q.state_dict()}
+    xo = O.namespace(**vars(xopt))
+    with torch.no_grad():
+        report("state/stft_code (mismatches)", (O.stft_encode(nets, aopt, stft) != state_code).float(), torch.zeros(1))
+        report("state/tf_logits", O.gpt_forward(nets["t"], xo, code, state_idx=state_code[:, :8]), out["tf_logits"])
+        oc, os_ = O.generate_fake(nets["t"], xo, code[:, :64], total, state_code=state_code[:, :8])
+        report("state/given (mismatches)", (oc != fa["code"]).float(), torch.zeros(1))
+        oc, os_ = O.generate_fake(nets["t"], xo, code[:, :64], total, state_code=state_code[:, :2])
+        report("state/pred code (mismatches)", (oc != fb["code"]).float(), torch.zeros(1))
+        report("state/pred state (mismatches)", (os_ != fb["state_code"]).float(), torch.zeros(1))
+        oc, os_ = O.generate_fake(nets["t"], xo, code[:, :64], total5, state_code=state_code)
+        report("state/slide (mismatches)", (oc != fc["code"]).float(), torch.zeros(1))
+        xo.sample, xo.sample_state = True, True
+        torch.manual_seed(7)
+        oc, os_ = O.generate_fake(nets["t"], xo, code[:, :64], 64 + 2 + 2 + 6, state_code=state_code[:, :2])
+        report("state/sampled code (mismatches)", (oc != fd["code"]).float(), torch.zeros(1))
+        report("state/sampled state (mismatches)", (os_ != fd["state_code"]).float(), torch.zeros(1))
+
+    arrays = {k: v.detach().cpu().numpy() for k, v in out.items()}
+    arrays.update(sd_np("t", tr.net_t))
+    arrays.update(sd_np("ae", sm.net_e))
+    arrays.update(sd_np("aq", sm.net_q))
+    np.savez_compressed(os.path.join(HERE, "tiny_state.npz"), **arrays)
+    print("  wrote tiny_state.npz", sum(a.nbytes for a in arrays.values()) / 1e6, "MB raw")
+
+
 def op_fixtures(ns):
     """Per-op vectors at a few real channel counts on small maps."""
     sae = ns.sae
@@ -275,7 +347,13 @@ def op_fixtures(ns):
 
 if __name__ == "__main__":
     ns = rh.load_reference()
-    print("== op fixtures")
-    op_fixtures(ns)
-    print("== tiny end-to-end")
-    tiny_end_to_end(ns)
+    which = sys.argv[1:] or ["ops", "tiny", "state"]
+    if "ops" in which:
+        print("== op fixtures")
+        op_fixtures(ns)
+    if "tiny" in which:
+        print("== tiny end-to-end")
+        tiny_end_to_end(ns)
+    if "state" in which:
+        print("== tiny ancillary-token stream")
+        tiny_state_stream(ns)

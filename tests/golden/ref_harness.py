@@ -120,13 +120,18 @@ def load_reference():
     from models.skip_vid_generator.models import transformer_model as tm
     from models.skip_vid_generator.models import mingpt
     from models.skip_vid_generator.modules import quantize
+    try:  # ancillary-stream models; perceptual.py only needs torchvision.models to exist
+        from models.skip_vid_generator.models import stft_model
+    except Exception as exc:  # pragma: no cover
+        stft_model = None
+        print("[ref_harness] stft_model not importable:", exc)
     upf = sys.modules["models.skip_vid_generator.modules.upfirdn2d"]  # the package re-exports the function under the same name
     from tools import options as ref_options
 
     sae.FunctionCorrelation = correlation_bruteforce
 
     ns = types.SimpleNamespace(sae=sae, qvm=qvm, tm=tm, mingpt=mingpt, quantize=quantize,
-                               upfirdn2d=upf, options=ref_options)
+                               upfirdn2d=upf, options=ref_options, stft_model=stft_model)
     _LOADED["ns"] = ns
     return ns
 
@@ -172,4 +177,11 @@ TINY_ARGV = [
     "--x_z_num", "32", "--x_z_len", "256", "--x_n_layer", "2", "--x_n_head", "2", "--x_n_embd", "32",
     "--x_z_chunk", "64", "--x_cond_len", "64", "--x_emb_mode", "temporal", "--x_num_blocks", "4",
     "--batch_size_vid", "2",
+]
+
+# tiny configuration with an ancillary (STFT) token stream: 2 STFT tokens + 64 frame tokens per frame, window of 4 frames
+TINY_STATE_ARGV = [a for a in TINY_ARGV] + [
+    "--x_stft", "--x_state_num", "24", "--x_state_size", "2", "--x_z_len", "256", "--x_z_chunk", "66",
+    "--x_top_k_state", "5", "--x_temperature_state", "0.8",
+    "--a_stft_num", "24", "--a_stft_size", "16", "--a_stft_hsize", "8", "--a_stft_shape", "2", "1",
 ]

@@ -266,3 +266,80 @@ def test_sliding_token_window_vs_oracle(tiny):
         b, t = (out != want).nonzero()[0].tolist()
         lg = trace[t - 64][b]
         assert (lg[out[b, t]] - lg[want[b, t]]).abs().item() < 1e-4
+
+
+TINY_STATE_ARGV = TINY_ARGV + [
+    "--x_stft", "--x_state_num", "24", "--x_state_size", "2", "--x_z_len", "256", "--x_z_chunk", "66",
+    "--x_top_k_state", "5", "--x_temperature_state", "0.8",
+    "--a_stft_num", "24", "--a_stft_size", "16", "--a_stft_hsize", "8", "--a_stft_shape", "2", "1",
+]
+
+
+@pytest.fixture(scope="module")
+def state_stream(golden_dir):
+    from ccvs_amd.tools.options import Options
+    from ccvs_amd.models.skip_vid_generator.models.transformer_model import Transformer
+    from ccvs_amd.models.skip_vid_generator.models.stft_model import StftModel
+    gold = np.load(os.path.join(golden_dir, "tiny_state.npz"))
+    opt = Options().parse(load_qvid_generator=True, load_transformer=True, load_stft_ae=True, argv=TINY_STATE_ARGV)
+    xopt, aopt = opt["transformer"], opt["stft_ae"]
+    tr = Transformer(xopt, is_train=False, is_main=True).eval()
+    sm = StftModel(aopt, is_train=False, is_main=True).eval()
+    _load(tr.net_t, _sd(gold, "t"))
+    _load(sm.net_e, _sd(gold, "ae"))
+    _load(sm.net_q, _sd(gold, "aq"))
+    nets = {"t": _sd(gold, "t"), "ae": _sd(gold, "ae"), "aq": _sd(gold, "aq")}
+    return dict(gold=gold, tr=tr, sm=sm, xopt=xopt, aopt=aopt, nets=nets)
+
+
+def test_stft_encode_golden(state_stream):
+    """StftModel.encode: spectrogram frames -> ancillary tokens, bit-exact."""
+    g, sm = state_stream["gold"], state_stream["sm"]
+    z = sm.net_e(torch.from_numpy(g["stft"]).cuda())
+    assert maxdiff(z, torch.from_numpy(g["stft_z"])) < 1e-4
+    got = sm({"stft": torch.from_numpy(g["stft"])}, mode="vid_encoder")["state_code"]
+    assert torch.equal(got.cpu(), torch.from_numpy(g["state_code"]))
+
+
+def test_gpt_state_interleave_logits_golden(state_stream):
+    """GPT.forward with the per-frame [state | frame] interleave (mingpt.py:246-282), teacher-forced."""
+    g, tr = state_stream["gold"], state_stream["tr"]
+    code, state = torch.from_numpy(g["tf_code"]).cuda(), torch.from_numpy(g["state_code"])[:, :8].cuda()
+    got = tr.net_t(code, state_idx=state)
+    want = torch.from_numpy(g["tf_logits"])
+    assert got.shape == want.shape
+    assert maxdiff(got, want) < 2e-4
+
+
+def _audit_pair(got_c, got_s, want_c, want_s):
+    assert got_c.shape == want_c.shape and got_s.shape == want_s.shape
+    assert torch.equal(got_c.cpu(), want_c) and torch.equal(got_s.cpu(), want_s)
+
+
+def test_generate_with_given_and_predicted_state_golden(state_stream):
+    """Transformer('inference') with an ancillary stream: STFT tokens given for every frame (graph replay for the frame
+    tokens, `extend` at frame boundaries), predicted along with the frames, and through the sliding window."""
+    g, tr, xopt = state_stream["gold"], state_stream["tr"], state_stream["xopt"]
+    xopt.sample, xopt.top_k, xopt.sample_state = False, 10, False
+    code, state = torch.from_numpy(g["tf_code"])[:, :64], torch.from_numpy(g["state_code"])
+    for use_graph in (True, False):
+        xopt.use_graph = use_graph
+        out = tr({"code": code.clone(), "state_code": state[:, :8].clone()}, mode="inference", total_len=264)
+        _audit_pair(out["code"], out["state_code"], torch.from_numpy(g["given_code"]), torch.from_numpy(g["given_state"]))
+        out = tr({"code": code.clone(), "state_code": state[:, :2].clone()}, mode="inference", total_len=264)
+        _audit_pair(out["code"], out["state_code"], torch.from_numpy(g["pred_code"]), torch.from_numpy(g["pred_state"]))
+        out = tr({"code": code.clone(), "state_code": state.clone()}, mode="inference", total_len=330)
+        _audit_pair(out["code"], out["state_code"], torch.from_numpy(g["slide_code"]), torch.from_numpy(g["slide_state"]))
+    xopt.use_graph = True
+
+
+def test_generate_sampled_state_stream_golden(state_stream):
+    """Both streams sampled: the reference's torch.multinomial stream reproduced from the same CPU generator state."""
+    g, tr, xopt = state_stream["gold"], state_stream["tr"], state_stream["xopt"]
+    xopt.sample, xopt.top_k, xopt.sample_state = True, 10, True
+    tr.sample_noise, tr.generator = "host", None
+    torch.manual_seed(7)
+    code, state = torch.from_numpy(g["tf_code"])[:, :64], torch.from_numpy(g["state_code"])
+    out = tr({"code": code.clone(), "state_code": state[:, :2].clone()}, mode="inference", total_len=64 + 2 + 2 + 6)
+    _audit_pair(out["code"], out["state_code"], torch.from_numpy(g["samp_code"]), torch.from_numpy(g["samp_state"]))
+    xopt.sample, xopt.sample_state = False, False
