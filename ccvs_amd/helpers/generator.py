@@ -38,15 +38,19 @@ class Generator:
         self.vid_model = None
         self.transformer_model = None
         self.timings = {}
-        for flag in ("state", "stft", "layout", "deblurring", "cat", "keep_state", "custom_state"):
+        self.stft_model = None
+        for flag in ("state", "layout", "deblurring", "cat", "custom_state"):
             if getattr(self.opt, flag, False):
-                raise NotImplementedError(f"--{flag}: ancillary token streams are not on the MI355X path yet (SURVEY 8f)")
+                raise NotImplementedError(f"--{flag} is not on the MI355X path (SURVEY 8f); --stft [--keep_state] is")
 
     # ------------------------------------------------------------------ models / data
     def build_models(self, is_main=True):
         self.vid_model = QVidModel(self.qvid_opt, is_train=False, is_main=is_main, logger=None).eval()
         if not self.opt.rec_only:
             self.transformer_model = Transformer(self.opt, is_train=False, is_main=is_main, logger=None).eval()
+        if self.opt.stft:  # generator.py:271-274
+            from ..models.skip_vid_generator.models.stft_model import StftModel
+            self.stft_model = StftModel(self.stft_ae_opt, is_train=False, is_main=is_main, logger=None).eval()
         return self
 
     def synthetic_batch(self, batch, seed=1, first_clip=0):
@@ -96,10 +100,17 @@ class Generator:
         encoded_data = self.vid_model(data, mode='vid_encoder')            # encode all frames
         ev[1].record()
 
+        if getattr(opt, "state", False) or getattr(opt, "layout", False) or getattr(opt, "deblurring", False):
+            raise NotImplementedError("state estimator / layout / deblurring conditioning is not on the MI355X path (SURVEY 8f)")
+        if opt.stft:                                                        # generator.py:78-80
+            encoded_data.update(self.stft_model(data, mode='vid_encoder'))
+
         size = int(torch.prod(torch.tensor(qopt.z_shape)))                  # generator.py:83-102
         cond_step, t_step = (1, opt.vid_len - 1) if opt.p2p else (0, opt.vid_len)
         total_len = (cond_step + t_step) * size
         cond_len = cond_step * size
+        if opt.stft:                                                        # generator.py:91-92
+            total_len += t_step * opt.state_size
         if opt.gen_from_img:
             crop_prop = opt.cond_len / size
         else:
@@ -115,6 +126,12 @@ class Generator:
             cropped["cond_inter"] = [feat[:, -1:].contiguous() for feat in encoded_data["inter"]]
             cropped["delta_length_cond"] = torch.tensor([opt.vid_len - 1]).repeat(cropped["code"].size(0))
 
+        if opt.stft:                                                        # generator.py:107-117
+            if opt.keep_state:
+                cropped["state_code"] = encoded_data["state_code"]
+            else:
+                cropped["state_code"] = encoded_data["state_code"][:, :int(crop_prop * encoded_data["state_code"].size(1))]
+
         fake_data, rec_data = None, None
         if not opt.rec_only:
             if opt.step_by_step:
@@ -126,6 +143,7 @@ class Generator:
                 cropped.update(fake_encoded)
                 fake_data = self.vid_model(cropped, mode='vid_decoder')
                 fake_data["code"] = fake_encoded["code"]
+                fake_data["state_code"] = fake_encoded.get("state_code")
             if opt.p2p:
                 fake_data["vid"] = torch.cat([fake_data["vid"], data["vid"][:, -1:]], dim=1)
         else:

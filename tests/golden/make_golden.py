@@ -203,6 +203,33 @@ def tiny_state_stream(ns):
     print("  wrote tiny_state.npz", sum(a.nbytes for a in arrays.values()) / 1e6, "MB raw")
 
 
+def tiny_keep_first(ns):
+    """Decoder context ring with `--q_keep_first --q_n_first 1` (quantized_video_model.py:896-898; the drums script uses
+    n_first 8): 6 frames through a 3-slot ring.  Same seed / construction order as tiny_end_to_end, so the weights are the
+    ones stored in tiny_e2e.npz."""
+    opt = rh.parse_reference_options(rh.TINY_ARGV + ["--q_keep_first", "--q_n_first", "1", "--vid_len", "6"])
+    qopt = opt["qvid_generator"]
+    torch.manual_seed(0)
+    qv = ns.qvm.QVidModel(qopt, is_train=False, is_main=True).eval()
+    ref = np.load(os.path.join(HERE, "tiny_e2e.npz"))
+    for k, v in qv.net_g.state_dict().items():
+        if not k.endswith(".kernel"):
+            assert np.array_equal(v.numpy(), ref["g/" + k]), k
+    with torch.no_grad():
+        qv.net_q.embedding.weight.copy_(torch.from_numpy(ref["q/embedding.weight"]))
+        torch.manual_seed(21)
+        vid = torch.rand(2, 6, 3, 32, 32) * 2 - 1
+        code = torch.randint(0, 32, (2, 6 * 64))
+        enc = qv({"vid": vid.clone()}, mode="vid_encoder")
+        inter = [f[:, :1].contiguous() for f in enc["inter"]]
+        with rh.patched_overlapping_shift():
+            fake = qv({"code": code.clone(), "inter": [f.clone() for f in inter]}, mode="vid_decoder")["vid"]
+        nets = {"e": qv.net_e.state_dict(), "q": qv.net_q.state_dict(), "g": qv.net_g.state_dict()}
+        report("keep_first/vid", O.qvid_decode(nets, qopt, code, [f.clone() for f in inter]), fake)
+    np.savez_compressed(os.path.join(HERE, "tiny_keepfirst.npz"), vid=vid.numpy(), code=code.numpy(), fake_vid=fake.numpy())
+    print("  wrote tiny_keepfirst.npz")
+
+
 def op_fixtures(ns):
     """Per-op vectors at a few real channel counts on small maps."""
     sae = ns.sae
@@ -347,7 +374,7 @@ def op_fixtures(ns):
 
 if __name__ == "__main__":
     ns = rh.load_reference()
-    which = sys.argv[1:] or ["ops", "tiny", "state"]
+    which = sys.argv[1:] or ["ops", "tiny", "state", "keepfirst"]
     if "ops" in which:
         print("== op fixtures")
         op_fixtures(ns)
@@ -357,3 +384,6 @@ if __name__ == "__main__":
     if "state" in which:
         print("== tiny ancillary-token stream")
         tiny_state_stream(ns)
+    if "keepfirst" in which:
+        print("== tiny keep_first ring")
+        tiny_keep_first(ns)

@@ -343,3 +343,46 @@ def test_generate_sampled_state_stream_golden(state_stream):
     out = tr({"code": code.clone(), "state_code": state[:, :2].clone()}, mode="inference", total_len=64 + 2 + 2 + 6)
     _audit_pair(out["code"], out["state_code"], torch.from_numpy(g["samp_code"]), torch.from_numpy(g["samp_state"]))
     xopt.sample, xopt.sample_state = False, False
+
+
+def test_keep_first_ring_golden(tiny, golden_dir):
+    """`--q_keep_first --q_n_first 1`: slot 0 of the context ring pinned once the ring is full (quantized_video_model.py:
+    896-898), 6 frames through 3 slots -- against the reference's own decode."""
+    g = np.load(os.path.join(golden_dir, "tiny_keepfirst.npz"))
+    qv, qopt = tiny["qv"], tiny["qopt"]
+    old = (qopt.vid_len, getattr(qopt, "keep_first", False), getattr(qopt, "n_first", 1))
+    qopt.vid_len, qopt.keep_first, qopt.n_first = 6, True, 1
+    try:
+        enc = qv({"vid": torch.from_numpy(g["vid"])}, mode="vid_encoder")
+        inter = [f[:, :1].contiguous() for f in enc["inter"]]
+        fake = qv({"code": torch.from_numpy(g["code"]), "inter": inter}, mode="vid_decoder")["vid"]
+        assert fake.shape == (2, 6, 3, 32, 32)
+        assert maxdiff(fake, torch.from_numpy(g["fake_vid"])) < PIX_TOL
+    finally:
+        qopt.vid_len, qopt.keep_first, qopt.n_first = old
+
+
+def test_audio_conditioned_generator_vs_oracle(tiny, state_stream):
+    """BASELINE config 5 in miniature: Generator.generate_vid with `--x_stft --keep_state` -- frames encoded, spectrogram
+    frames tokenised, frame tokens predicted around the given STFT tokens, clip decoded -- against the oracle."""
+    from ccvs_amd.helpers.generator import Generator
+    from ccvs_amd.tools.options import Options
+    opt = Options().parse(load_qvid_generator=True, load_transformer=True, load_stft_ae=True, argv=TINY_STATE_ARGV + ["--keep_state"])
+    xopt = opt["transformer"]
+    xopt.sample, xopt.top_k, xopt.sample_state = False, 10, False
+    gen = Generator(opt)
+    gen.vid_model, gen.transformer_model, gen.stft_model = tiny["qv"], state_stream["tr"], state_stream["sm"]
+    gen.transformer_model.opt = xopt
+    torch.manual_seed(31)
+    data = gen.synthetic_batch(2, seed=33)
+    stft = torch.rand(2, 4, 1, 16, 8) * 2 - 1
+    out = gen.generate_vid({"vid": data["vid"].clone(), "stft": stft.clone()})
+    nets = dict(tiny["nets"])
+    nets.update(state_stream["nets"])   # "t" is the state-stream transformer
+    trace = []
+    want = O.generate_vid(nets, tiny["qopt"], xopt, data["vid"], trace=trace, stft=stft, aopt=state_stream["aopt"])
+    assert torch.equal(out["enc_code"].cpu(), want["enc_code"])
+    assert torch.equal(out["fake"]["state_code"].cpu(), want["state_code"])
+    _audit_tokens(out["fake"]["code"], want["code"], lambda b, t: trace[t - 64][b])
+    if torch.equal(out["fake"]["code"].cpu(), want["code"]):
+        assert maxdiff(out["fake"]["vid"], want["vid"]) < PIX_TOL
