@@ -218,7 +218,6 @@ __global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4
 //   producer threads) with j % nt == a, which are stored during step (c-1, a) and loaded one
 //   step before that.
 // ---------------------------------------------------------------------------------------
-#define CB_XQ 1  // halo-tile pixel passes per producer thread per step (passes <= CB_XQ * nt)
 
 // VEC (stride-1 dense convolutions on 16-byte aligned rows): the halo tile is staged from ALIGNED float4 loads.
 // A staging thread owns one item = 4 consecutive pixels x 8 channels (8 x global_load_dwordx4, 8 x ds_write_b128
@@ -228,10 +227,12 @@ __global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4
 // NTY > 0 selects VEC with NTY tap rows per chunk (1 or 3) as a compile-time constant: the staging loop is then
 // unrolled over a chunk's steps, every load is unconditional (clamped at the tail), and hipcc can give each
 // s_waitcnt the exact vmcnt -- with run-time step structure it falls back to vmcnt(0) at every LDS store, which
-// drags the HBM latency of the activation loads into every step.  NTY == 0: scalar staging, any tap count.
+// drags the HBM latency of the activation loads into every step.  NTY == 0: scalar staging, any tap count;
+// NTY == -2: the same with two pixel passes per thread and step (stride-2 and transposed layers: larger halo tiles).
 template <int TW, int MB, int NTY>
 __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
     constexpr bool VEC = NTY > 0;
+    constexpr int CB_XQ = (NTY == -2) ? 2 : 1;  // scalar staging: halo-tile pixel passes per thread and step (passes <= CB_XQ * nt)
     constexpr int TH = 256 / TW;
     constexpr int NT = 32 * MB;
     constexpr int NP = 256;               // staging threads (waves 4-7)
@@ -692,6 +693,7 @@ static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int ha
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_kernel<TW, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, -2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
@@ -715,10 +717,16 @@ static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int ha
     const size_t smem_pc = (size_t)(2 * 4 * plane + 2 * ntx_max * 4 * NT) * 16;
     const int nt_min = (k.transposed ? 1 : k.kh);               // fewest tap rows of any parity class
     const int passes = (plane + 255) / 256;
-    const bool regs_ok = (ntx_max <= 3) && (passes <= CB_XQ * nt_min);
+    const bool regs_ok = (ntx_max <= 3) && (passes <= nt_min);
+    const bool regs_ok2 = (ntx_max <= 3) && (passes <= 2 * nt_min) && !(ablate & 32);
     // (8 staging waves for <= 64 output channels were measured slower: the steps are latency- not staging-bound)
     if (smem_pc <= 156 * 1024 && regs_ok) {  // double-buffered producer / consumer form, scalar staging
         hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 0>), grid, dim3(512), smem_pc, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
+        CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
+        return CCVS_OK;
+    }
+    if (smem_pc <= 156 * 1024 && regs_ok2) {
+        hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, -2>), grid, dim3(512), smem_pc, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
         CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
         return CCVS_OK;
     }
