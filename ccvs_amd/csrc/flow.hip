@@ -126,19 +126,42 @@ __device__ __forceinline__ float bilin_sample(const float* __restrict__ plane, c
 
 #define WARP_CCH 16  // channels per thread
 
-__global__ __launch_bounds__(256) void backwarp_kernel(const float* __restrict__ x, long x_sN, long x_sC,
+// The k context features of a decode step live in slots of the per-level context ring (and, point-to-point, in a
+// separate tensor): item n of the batch of N*k pairs reads source ctx.p[n % k] + (n / k) * ctx.sN[n % k], so the
+// reference's torch.stack / repeat of the contexts (skip_autoencoder.py:251) never has to be materialised.
+// A dense [N,C,H,W] source is the list {k = 1, p[0] = x, sN[0] = x_sN}.
+struct CtxList {
+    int k;
+    const float* p[CCVS_MAX_CTX];
+    long sN[CCVS_MAX_CTX];
+};
+
+__global__ __launch_bounds__(256) void backwarp_kernel(CtxList ctx, long x_sC,
                                                        const float* __restrict__ flow, long flow_sN, float mult,
                                                        float* __restrict__ y, long y_sN, long y_sC, int C, int H, int W) {
     const int HW = H * W;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= HW) return;
     const int n = blockIdx.z, c0 = blockIdx.y * WARP_CCH;
+    const int jn = n % ctx.k;
+    const float* x = ctx.p[jn] + (long)(n / ctx.k) * ctx.sN[jn];
     const int py = pix / W, px = pix - py * W;
     const float fx = flow[(long)n * flow_sN + pix] * mult, fy = flow[(long)n * flow_sN + HW + pix] * mult;
     const Bilin b = bilin_setup(px, py, fx, fy, H, W);
     const int cend = min(c0 + WARP_CCH, C);
     for (int c = c0; c < cend; ++c)
-        y[(long)n * y_sN + (long)c * y_sC + pix] = bilin_sample(x + (long)n * x_sN + (long)c * x_sC, b);
+        y[(long)n * y_sN + (long)c * y_sC + pix] = bilin_sample(x + (long)c * x_sC, b);
+}
+
+static int fill_ctx(CtxList& l, const ccvs_ctx_list* c, const char* name) {
+    if (!c || c->k < 1 || c->k > CCVS_MAX_CTX) { ccvs_set_error("%s: context list of 1..%d entries expected", name, CCVS_MAX_CTX); return CCVS_ERR_ARG; }
+    l.k = c->k;
+    for (int j = 0; j < c->k; ++j) {
+        if (!c->p[j]) { ccvs_set_error("%s: null context %d", name, j); return CCVS_ERR_ARG; }
+        l.p[j] = c->p[j];
+        l.sN[j] = (long)c->sN[j];
+    }
+    return CCVS_OK;
 }
 
 extern "C" int ccvs_backwarp(const float* x, int64_t x_sN, int64_t x_sC, const float* flow, int64_t flow_sN, float flow_mult, float* y,
@@ -146,9 +169,25 @@ extern "C" int ccvs_backwarp(const float* x, int64_t x_sN, int64_t x_sC, const f
     CCVS_REQUIRE(x && flow && y, "ccvs_backwarp: null pointer");
     CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535, "ccvs_backwarp: bad shape");
     dim3 grid(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
-    hipLaunchKernelGGL(backwarp_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (long)x_sN, (long)x_sC, flow, (long)flow_sN, flow_mult, y,
+    CtxList l = {};
+    l.k = 1; l.p[0] = x; l.sN[0] = (long)x_sN;
+    hipLaunchKernelGGL(backwarp_kernel, grid, dim3(256), 0, (hipStream_t)stream, l, (long)x_sC, flow, (long)flow_sN, flow_mult, y,
                        (long)y_sN, (long)y_sC, C, H, W);
     CCVS_CHECK_LAUNCH("ccvs_backwarp");
+    return CCVS_OK;
+}
+
+extern "C" int ccvs_backwarp_ctx(const ccvs_ctx_list* ctx, int64_t x_sC, const float* flow, int64_t flow_sN, float flow_mult, float* y,
+                                 int64_t y_sN, int64_t y_sC, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    CCVS_REQUIRE(flow && y, "ccvs_backwarp_ctx: null pointer");
+    CtxList l = {};
+    const int rc = fill_ctx(l, ctx, "ccvs_backwarp_ctx");
+    if (rc != CCVS_OK) return rc;
+    CCVS_REQUIRE(N > 0 && N % l.k == 0 && C > 0 && H > 0 && W > 0 && N <= 65535, "ccvs_backwarp_ctx: bad shape");
+    dim3 grid(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
+    hipLaunchKernelGGL(backwarp_kernel, grid, dim3(256), 0, (hipStream_t)stream, l, (long)x_sC, flow, (long)flow_sN, flow_mult, y,
+                       (long)y_sN, (long)y_sC, C, H, W);
+    CCVS_CHECK_LAUNCH("ccvs_backwarp_ctx");
     return CCVS_OK;
 }
 
@@ -161,7 +200,7 @@ extern "C" int ccvs_backwarp(const float* x, int64_t x_sN, int64_t x_sC, const f
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
 __global__ __launch_bounds__(256) void warp_fuse_blend_kernel(float* __restrict__ dec, long dec_sN, long dec_sC,
-                                                              const float* __restrict__ ctx, const float* __restrict__ flows,
+                                                              CtxList ctx, const float* __restrict__ flows,
                                                               long flows_sN, const float* __restrict__ occs, long occs_sN,
                                                               float mult, int k, int C, int H, int W) {
     const int HW = H * W;
@@ -182,7 +221,7 @@ __global__ __launch_bounds__(256) void warp_fuse_blend_kernel(float* __restrict_
         sum_conf += conf;
         sum_occ += oc * conf;
         const Bilin b = bilin_setup(px, py, fx, fy, H, W);
-        const float* base = ctx + (nk * C + c0) * HW;
+        const float* base = ctx.p[kk] + (long)n * ctx.sN[kk] + (long)c0 * HW;
 #pragma unroll
         for (int j = 0; j < WARP_CCH; ++j)
             if (j < cn) acc[j] += conf * bilin_sample(base + (long)j * HW, b);
@@ -205,9 +244,28 @@ extern "C" int ccvs_warp_fuse_blend(float* dec, int64_t dec_sN, int64_t dec_sC, 
     CCVS_REQUIRE(dec && ctx && flows && occs, "ccvs_warp_fuse_blend: null pointer");
     CCVS_REQUIRE(N > 0 && k > 0 && C > 0 && H > 0 && W > 0 && N <= 65535, "ccvs_warp_fuse_blend: bad shape");
     dim3 grid(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
-    hipLaunchKernelGGL(warp_fuse_blend_kernel, grid, dim3(256), 0, (hipStream_t)stream, dec, (long)dec_sN, (long)dec_sC, ctx, flows,
+    CCVS_REQUIRE(k <= CCVS_MAX_CTX, "ccvs_warp_fuse_blend: at most %d contexts", CCVS_MAX_CTX);
+    CtxList l = {};
+    l.k = k;
+    for (int j = 0; j < k; ++j) { l.p[j] = ctx + (long)j * C * H * W; l.sN[j] = (long)k * C * H * W; }
+    hipLaunchKernelGGL(warp_fuse_blend_kernel, grid, dim3(256), 0, (hipStream_t)stream, dec, (long)dec_sN, (long)dec_sC, l, flows,
                        (long)flows_sN, occs, (long)occs_sN, flow_mult, k, C, H, W);
     CCVS_CHECK_LAUNCH("ccvs_warp_fuse_blend");
+    return CCVS_OK;
+}
+
+extern "C" int ccvs_warp_fuse_blend_ctx(float* dec, int64_t dec_sN, int64_t dec_sC, const ccvs_ctx_list* ctx, const float* flows,
+                                        int64_t flows_sN, const float* occs, int64_t occs_sN, float flow_mult, int32_t N, int32_t C,
+                                        int32_t H, int32_t W, void* stream) {
+    CCVS_REQUIRE(dec && flows && occs, "ccvs_warp_fuse_blend_ctx: null pointer");
+    CtxList l = {};
+    const int rc = fill_ctx(l, ctx, "ccvs_warp_fuse_blend_ctx");
+    if (rc != CCVS_OK) return rc;
+    CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535, "ccvs_warp_fuse_blend_ctx: bad shape");
+    dim3 grid(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
+    hipLaunchKernelGGL(warp_fuse_blend_kernel, grid, dim3(256), 0, (hipStream_t)stream, dec, (long)dec_sN, (long)dec_sC, l, flows,
+                       (long)flows_sN, occs, (long)occs_sN, flow_mult, l.k, C, H, W);
+    CCVS_CHECK_LAUNCH("ccvs_warp_fuse_blend_ctx");
     return CCVS_OK;
 }
 

@@ -255,7 +255,7 @@ class InterBlock(nn.Module):
         n, s, h, w = dec.shape
         k = len(inters)
         m = self.matching
-        stacked = torch.stack([t.reshape(n, s, h, w) for t in inters], dim=1).view(n * k, s, h, w)
+        ctxs = [t.reshape(n, s, h, w) for t in inters]   # slot views of the context ring: read in place by the warp kernels
         # Subpixel input [dec | warped ctx | flow | occ] (skip_autoencoder.py:224): the `dec` block is the same
         # for the k contexts of a frame, so its share of the first Subpixel conv is computed ONCE per frame
         # (`pre`) and broadcast inside the conv epilogue; only [warped | flow | occ] is materialised per pair.
@@ -263,9 +263,9 @@ class InterBlock(nn.Module):
         fo = sp_in[:, s:]
         if fo_prev is not None:
             ops.dwconvT4x4s2(fo_prev, self._upsample_fo_weight(), out=fo)       # learned x2 of flow and occ
-            inter_w = ops.backwarp(stacked, fo[:, :2], self.flow_mult)
-        else:
-            inter_w = stacked
+            inter_w = ops.backwarp(ctxs, fo[:, :2], self.flow_mult)
+        else:  # coarsest level: the cost volume reads the contexts themselves
+            inter_w = torch.stack(ctxs, dim=1).view(n * k, s, h, w)
         if m.proj is not None:
             pa, pb = m.proj(dec), m.proj(inter_w)                                # input projected once per n, not k times
         else:
@@ -280,12 +280,12 @@ class InterBlock(nn.Module):
         w_dec, w_rest = self._sub0_split()
         conv0 = sp.convs[0].conv
         pre = ops.conv2d(dec, w_dec, None, conv0.out_channel, 3, pad=1)          # [N,128,H,W], before dec is blended
-        ops.backwarp(stacked, fo[:, :2], self.flow_mult, out=sp_in[:, :s])
+        ops.backwarp(ctxs, fo[:, :2], self.flow_mult, out=sp_in[:, :s])
         feat = ops.conv2d(sp_in, w_rest, conv0.bias, conv0.out_channel, 3, pad=1, act=True, pre=pre, pre_div=k)
         feat = sp.convs[2](sp.convs[1](feat))
         self._s_heads(feat, fo, accumulate=True)
         del feat, pre
-        ops.warp_fuse_blend(dec, stacked, fo[:, :2], fo[:, 2:3], self.flow_mult, k)
+        ops.warp_fuse_blend(dec, ctxs, fo[:, :2], fo[:, 2:3], self.flow_mult, k)
         return fo
 
     def _sub0_split(self):

@@ -225,32 +225,73 @@ def correlation7x7(first, second, stride, first_div=1, lrelu=False):
     return out
 
 
+def _ctx_list(ctxs):
+    """k context tensors [N,C,H,W] (channel planes dense, any batch stride) -> (`ccvs_ctx_list`, tensors kept alive)."""
+    assert 1 <= len(ctxs) <= _lib.MAX_CTX
+    cl = _lib.CtxList()
+    cl.k = len(ctxs)
+    keep = []
+    n, c, h, w = ctxs[0].shape
+    for j, t in enumerate(ctxs):
+        _need_gpu(t)
+        assert t.shape == (n, c, h, w) and t.dtype == torch.float32
+        if not (t.stride(3) == 1 and t.stride(2) == w and t.stride(1) == h * w):
+            t = t.contiguous()
+        keep.append(t)
+        cl.p[j] = t.data_ptr()
+        cl.sN[j] = t.stride(0)
+    return cl, keep
+
+
 def backwarp(x, flow, flow_mult=1.0, out=None):
-    _need_gpu(x, flow, out)
-    x = _as_rows_dense(x)
+    """x: a tensor [N,C,H,W], or a LIST of k context tensors [N/k,C,H,W] standing for the batch of N pairs in (frame, context)
+    order -- read in place, no stacked copy."""
+    _need_gpu(flow, out)
     if not _planes_dense(flow):
         flow = flow.contiguous()
+    L = _lib.load()
+    if isinstance(x, (list, tuple)):
+        cl, keep = _ctx_list(x)
+        nf, c, h, w = keep[0].shape
+        n = nf * cl.k
+        assert flow.shape == (n, 2, h, w)
+        if out is None:
+            out = torch.empty(n, c, h, w, dtype=torch.float32, device=flow.device)
+        assert _rows_dense(out)
+        _lib.check(L.ccvs_backwarp_ctx(C.byref(cl), h * w, _p(flow), flow.stride(0), flow_mult, _p(out), out.stride(0), out.stride(1),
+                                       n, c, h, w, _stream()), "ccvs_backwarp_ctx")
+        return out
+    _need_gpu(x)
+    x = _as_rows_dense(x)
     n, c, h, w = x.shape
     assert flow.shape == (n, 2, h, w)
     if out is None:
         out = torch.empty(n, c, h, w, dtype=torch.float32, device=x.device)
     assert _rows_dense(out)
-    L = _lib.load()
     _lib.check(L.ccvs_backwarp(_p(x), x.stride(0), x.stride(1), _p(flow), flow.stride(0), flow_mult, _p(out), out.stride(0),
                                out.stride(1), n, c, h, w, _stream()), "ccvs_backwarp")
     return out
 
 
 def warp_fuse_blend(dec, ctx, flows, occs, flow_mult, k):
-    """In place on `dec` (a channel-slice view [N,C,H,W] of the decoder feature)."""
-    _need_gpu(dec, ctx, flows, occs)
+    """In place on `dec` (a channel-slice view [N,C,H,W] of the decoder feature).  ctx: [N*k,C,H,W], or a list of k
+    context tensors [N,C,H,W] read in place."""
+    _need_gpu(dec, flows, occs)
     assert _rows_dense(dec)
-    ctx = ctx.contiguous()
     flows = flows if _planes_dense(flows) else flows.contiguous()
     occs = occs if _planes_dense(occs) else occs.contiguous()
     n, c, h, w = dec.shape
-    assert ctx.shape == (n * k, c, h, w) and flows.shape == (n * k, 2, h, w) and occs.shape == (n * k, 1, h, w)
+    assert flows.shape == (n * k, 2, h, w) and occs.shape == (n * k, 1, h, w)
     L = _lib.load()
+    if isinstance(ctx, (list, tuple)):
+        cl, keep = _ctx_list(ctx)
+        assert cl.k == k and keep[0].shape == (n, c, h, w)
+        _lib.check(L.ccvs_warp_fuse_blend_ctx(_p(dec), dec.stride(0), dec.stride(1), C.byref(cl), _p(flows), flows.stride(0), _p(occs),
+                                              occs.stride(0), flow_mult, n, c, h, w, _stream()), "ccvs_warp_fuse_blend_ctx")
+        return dec
+    _need_gpu(ctx)
+    ctx = ctx.contiguous()
+    assert ctx.shape == (n * k, c, h, w)
     _lib.check(L.ccvs_warp_fuse_blend(_p(dec), dec.stride(0), dec.stride(1), _p(ctx), _p(flows), flows.stride(0), _p(occs),
                                       occs.stride(0), flow_mult, n, k, c, h, w, _stream()), "ccvs_warp_fuse_blend")
     return dec

@@ -112,6 +112,22 @@ int ccvs_correlation7x7(const float* first, const float* second, float* out, int
 int ccvs_backwarp(const float* x, int64_t x_sN, int64_t x_sC, const float* flow, int64_t flow_sN, float flow_mult, float* y,
                   int64_t y_sN, int64_t y_sC, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
 
+/* The same two calls with the sources given as a list of k context tensors: pair b of the N (backwarp: N = pairs;
+ * warp_fuse_blend: N = frames) reads context j = b % k of frame b / k at p[j] + (b / k) * sN[j] (channel planes
+ * dense).  The k contexts of a decode step are slots of the per-level context ring (plus, point-to-point, one tensor
+ * outside it): this form reads them in place instead of the stacked copy of skip_autoencoder.py:251. */
+#define CCVS_MAX_CTX 16
+typedef struct ccvs_ctx_list {
+    int32_t k;
+    const float* p[CCVS_MAX_CTX];
+    int64_t sN[CCVS_MAX_CTX];
+} ccvs_ctx_list;
+int ccvs_backwarp_ctx(const ccvs_ctx_list* ctx, int64_t x_sC, const float* flow, int64_t flow_sN, float flow_mult, float* y,
+                      int64_t y_sN, int64_t y_sC, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+int ccvs_warp_fuse_blend_ctx(float* dec, int64_t dec_sN, int64_t dec_sC, const ccvs_ctx_list* ctx, const float* flows,
+                             int64_t flows_sN, const float* occs, int64_t occs_sN, float flow_mult, int32_t N, int32_t C,
+                             int32_t H, int32_t W, void* stream);
+
 /* Tail of InterBlock.forward (skip_autoencoder.py:254-264): final back-warp of the k
  * context features, confidence fusion over k (eps 1e-6) and occlusion blend, written in
  * place into the first C channels of the decoder feature.

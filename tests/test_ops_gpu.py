@@ -439,3 +439,23 @@ def test_attention_decode_long_cache(ops, D):
         close(got, want, 2e-5)
         pos_dev = torch.tensor([L - 1], dtype=torch.int32).cuda()  # device-resident position, as in the captured decode step
         close(ops.attention(q, kc, vc, 0, pos_dev), want, 2e-5)
+
+
+def test_warp_kernels_with_context_list(ops):
+    """ccvs_backwarp_ctx / ccvs_warp_fuse_blend_ctx read the k contexts in place (ring slots, any order, plus a tensor
+    outside the ring) and equal the stacked-copy forms bit for bit."""
+    torch.manual_seed(2)
+    n, k, c, h, w = 3, 4, 20, 12, 16
+    ring = torch.randn(n, 6, c, h, w).cuda()
+    extra = torch.randn(n, 1, c, h, w).cuda()
+    slots = [4, 1, 5]
+    ctxs = [ring[:, s_] for s_ in slots] + [extra[:, 0]]
+    stacked = torch.stack(ctxs, dim=1).reshape(n * k, c, h, w).contiguous()
+    flow = (torch.randn(n * k, 2, h, w) * 3).cuda()
+    occ = torch.randn(n * k, 1, h, w).cuda()
+    assert torch.equal(ops.backwarp(ctxs, flow, 0.5), ops.backwarp(stacked, flow, 0.5))
+    dec = torch.randn(n, c + 5, h, w).cuda()
+    a, b = dec.clone(), dec.clone()
+    ops.warp_fuse_blend(a[:, :c], ctxs, flow, occ, 0.5, k)
+    ops.warp_fuse_blend(b[:, :c], stacked, flow, occ, 0.5, k)
+    assert torch.equal(a, b)
