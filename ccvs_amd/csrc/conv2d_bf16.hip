@@ -238,7 +238,8 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
     constexpr int NP = 256;               // staging threads (waves 4-7)
     constexpr int NPW = 256;              // ... all of which stage weights
     constexpr int NPX = 256;              // ... and (VEC) one activation item each
-    constexpr int CB_WR = (3 * 4 * NT + NPW - 1) / NPW;  // uint4 of tap-row weights per weight-staging thread (3 taps per row)
+    constexpr int NTXM = (MB == 1) ? 9 : 3;              // most taps per row (1 x k head kernels run with MB = 1)
+    constexpr int CB_WR = (NTXM * 4 * NT + NPW - 1) / NPW;  // uint4 of tap-row weights per weight-staging thread
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -703,7 +704,7 @@ static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int ha
     // aligned float4 staging: dense stride-1 rows on 16-byte boundaries, one item per staging thread
     const int xsh = ((-k.pad % 4) + 4) % 4, nq = (xsh + halo_w + 3) / 4;
     const bool vec_ok = !k.transposed && k.stride == 1 && k.Win % 4 == 0 && k.in_sC % 4 == 0 && k.in_sN % 4 == 0 &&
-                        (reinterpret_cast<uintptr_t>(k.x) & 15) == 0 && TW >= 16 && halo_h * nq * 2 <= 256 && ntx_max <= 3 &&
+                        (reinterpret_cast<uintptr_t>(k.x) & 15) == 0 && TW >= 16 && halo_h * nq * 2 <= 256 && ntx_max <= (MB == 1 ? 9 : 3) &&
                         (k.kh == 1 || k.kh == 3) && !(ablate & 4);
     if (vec_ok) {
         const size_t smem_v = (size_t)(2 * 4 * halo_h * nq * 4 + 2 * ntx_max * 4 * NT) * 16;
@@ -717,8 +718,8 @@ static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int ha
     const size_t smem_pc = (size_t)(2 * 4 * plane + 2 * ntx_max * 4 * NT) * 16;
     const int nt_min = (k.transposed ? 1 : k.kh);               // fewest tap rows of any parity class
     const int passes = (plane + 255) / 256;
-    const bool regs_ok = (ntx_max <= 3) && (passes <= nt_min);
-    const bool regs_ok2 = (ntx_max <= 3) && (passes <= 2 * nt_min) && !(ablate & 32);
+    const bool regs_ok = (ntx_max <= (MB == 1 ? 9 : 3)) && (passes <= nt_min);
+    const bool regs_ok2 = (ntx_max <= (MB == 1 ? 9 : 3)) && (passes <= 2 * nt_min) && !(ablate & 32);
     // (8 staging waves for <= 64 output channels were measured slower: the steps are latency- not staging-bound)
     if (smem_pc <= 156 * 1024 && regs_ok) {  // double-buffered producer / consumer form, scalar staging
         hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 0>), grid, dim3(512), smem_pc, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
@@ -744,7 +745,8 @@ extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const flo
                                   const ccvs_conv_desc* d, void* stream) {
     CCVS_REQUIRE(x && w_split && y && d, "ccvs_conv2d_bf16x3: null pointer");
     CCVS_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->Hin > 0 && d->Win > 0, "ccvs_conv2d_bf16x3: empty tensor");
-    CCVS_REQUIRE((d->kh == d->kw || d->kw == 1) && d->kh >= 1 && d->kh <= 9, "ccvs_conv2d_bf16x3: kernel %dx%d unsupported", d->kh, d->kw);
+    CCVS_REQUIRE((d->kh == d->kw || d->kw == 1 || d->kh == 1) && d->kh >= 1 && d->kh <= 9 && d->kw >= 1 && d->kw <= 9,
+                 "ccvs_conv2d_bf16x3: kernel %dx%d unsupported", d->kh, d->kw);
     CCVS_REQUIRE(d->CoutPad % 32 == 0 && d->CoutPad >= d->Cout, "ccvs_conv2d_bf16x3: CoutPad %d invalid for Cout %d", d->CoutPad, d->Cout);
     int Hout, Wout;
     if (d->transposed) {

@@ -280,8 +280,10 @@ extern "C" int ccvs_warp_fuse_blend_ctx(float* dec, int64_t dec_sN, int64_t dec_
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tap_shift_add_kernel(const float* __restrict__ t, const float* __restrict__ bias,
                                                             float* __restrict__ y, long y_sN, long total, int k, int H, int W,
-                                                            int accumulate) {
-    const int Wt = W + k - 1;
+                                                            int accumulate, int vertical) {
+    // horizontal: T is [N,3k,H,W+k-1] and tap kx reads column x+kx; vertical: T is [N,3k,H+k-1,W], tap ky reads row yy+ky
+    const int Wt = vertical ? W : W + k - 1, Ht = vertical ? H + k - 1 : H;
+    const long tap = (long)3 * Ht * Wt + (vertical ? Wt : 1);  // next tap: 3 maps further, one row / column further
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int x = (int)(i % W);
         long r = i / W;
@@ -289,21 +291,22 @@ __global__ __launch_bounds__(256) void tap_shift_add_kernel(const float* __restr
         r /= H;
         const int co = (int)(r % 3);
         const long n = r / 3;
-        const float* tp = t + ((n * 3 * k + co) * H + yy) * (long)Wt + x;
+        const float* tp = t + ((n * 3 * k + co) * Ht + yy) * (long)Wt + x;
         float acc = bias ? bias[co] : 0.f;
-        for (int kx = 0; kx < k; ++kx) acc += tp[(long)kx * 3 * H * Wt + kx];
+        for (int kk = 0; kk < k; ++kk) acc += tp[kk * tap];
         float* dst = y + n * y_sN + ((long)co * H + yy) * W + x;
         *dst = accumulate ? *dst + acc : acc;
     }
 }
 
 extern "C" int ccvs_tap_shift_add(const float* t, const float* bias, float* y, int64_t y_sN, int32_t N, int32_t k, int32_t H, int32_t W,
-                                  int32_t accumulate, void* stream) {
+                                  int32_t accumulate, int32_t vertical, void* stream) {
     CCVS_REQUIRE(t && y, "ccvs_tap_shift_add: null pointer");
     CCVS_REQUIRE(N > 0 && k >= 1 && k <= 9 && H > 0 && W > 0, "ccvs_tap_shift_add: bad shape");
     const long total = (long)N * 3 * H * W;
     const int blocks = (int)(cdiv64(total, 256) < 65536 * 16 ? cdiv64(total, 256) : 65536 * 16);
-    hipLaunchKernelGGL(tap_shift_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, bias, y, (long)y_sN, total, k, H, W, accumulate);
+    hipLaunchKernelGGL(tap_shift_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, bias, y, (long)y_sN, total, k, H, W, accumulate,
+                       vertical ? 1 : 0);
     CCVS_CHECK_LAUNCH("ccvs_tap_shift_add");
     return CCVS_OK;
 }

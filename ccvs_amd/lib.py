@@ -94,7 +94,7 @@ def load():
         "ccvs_warp_fuse_blend": [vp, i64, i64, vp, vp, i64, vp, i64, f32, i32, i32, i32, i32, i32, vp],
         "ccvs_backwarp_ctx": [C.POINTER(CtxList), i64, vp, i64, f32, vp, i64, i64, i32, i32, i32, i32, vp],
         "ccvs_warp_fuse_blend_ctx": [vp, i64, i64, C.POINTER(CtxList), vp, i64, vp, i64, f32, i32, i32, i32, i32, vp],
-        "ccvs_tap_shift_add": [vp, vp, vp, i64, i32, i32, i32, i32, i32, vp],
+        "ccvs_tap_shift_add": [vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp],
         "ccvs_vq_argmin": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "ccvs_embed_gather": [vp, vp, vp, i32, i32, i32, i32, vp],
         "ccvs_gpt_embed": [vp, i64, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, vp],

@@ -155,24 +155,30 @@ def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=Fa
 
 
 def pack_head_weights(flow_w, occ_w, precision=None):
-    """flow_head [2,C,k,k] + occ_head [1,C,k,k] -> PackedConv of the equivalent k x 1 convolution with 3k
-    outputs (row kx*3+co = tap column kx of output co); see ccvs_tap_shift_add."""
-    w = torch.cat([flow_w.detach(), occ_w.detach()], dim=0).float()          # [3, C, k, k]
+    """flow_head [2,C,k,k] + occ_head [1,C,k,k] -> PackedConv of an equivalent convolution with 3k outputs whose second
+    half is ccvs_tap_shift_add: split-bf16: a 1 x k kernel (row ky*3+co = tap row ky of output co; all k taps of a row
+    in one step of the kernel); f32: a k x 1 kernel (row kx*3+co = tap column kx of output co)."""
+    precision = precision or CONV_PRECISION
+    w = torch.cat([flow_w.detach(), occ_w.detach()], dim=0).float()          # [3, C, k(y), k(x)]
     _, cin, k, _ = w.shape
-    wt = w.permute(3, 0, 1, 2).reshape(3 * k, cin, k, 1).contiguous()          # [(kx,co), C, ky, 1]
+    if precision == "bf16x3":
+        wt = w.permute(2, 0, 1, 3).reshape(3 * k, cin, 1, k).contiguous()      # [(ky,co), C, 1, kx]
+    else:
+        wt = w.permute(3, 0, 1, 2).reshape(3 * k, cin, k, 1).contiguous()      # [(kx,co), C, ky, 1]
     return pack_conv_weight(wt, precision, scale=1 / math.sqrt(cin * k * k))
 
 
 def conv_heads(feat, w_packed, bias3, out, accumulate, flops_cb=None):
-    """The fused flow/occ heads: k x 1 MFMA convolution to 3k maps, then the horizontal tap sum into
+    """The fused flow/occ heads: MFMA convolution to 3k maps, then the tap sum along the other axis into
     `out` ([N,3,H,W] view, batch stride free)."""
-    k = w_packed.k
+    vertical = w_packed.k == 1 and w_packed.kw > 1
+    k = w_packed.kw if vertical else w_packed.k
     n, _, h, w = feat.shape
-    t = conv2d(feat, w_packed, None, 3 * k, k, pad=k // 2)                      # [N, 3k, H, W+k-1]
+    t = conv2d(feat, w_packed, None, 3 * k, w_packed.k, pad=k // 2)             # [N,3k,H+k-1,W] or [N,3k,H,W+k-1]
     assert out.shape == (n, 3, h, w) and _planes_dense(out)
     L = _lib.load()
-    _lib.check(L.ccvs_tap_shift_add(_p(t), _p(bias3), _p(out), out.stride(0), n, k, h, w, 1 if accumulate else 0, _stream()),
-               "ccvs_tap_shift_add")
+    _lib.check(L.ccvs_tap_shift_add(_p(t), _p(bias3), _p(out), out.stride(0), n, k, h, w, 1 if accumulate else 0,
+                                    1 if vertical else 0, _stream()), "ccvs_tap_shift_add")
     return out
 
 

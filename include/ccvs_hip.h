@@ -137,13 +137,16 @@ int ccvs_warp_fuse_blend(float* dec, int64_t dec_sN, int64_t dec_sC, const float
                          const float* occs, int64_t occs_sN, float flow_mult, int32_t N, int32_t k, int32_t C, int32_t H,
                          int32_t W, void* stream);
 
-/* Horizontal half of the 3-output flow / occlusion heads (skip_autoencoder.py:176-177,204-205,225-226).
- * The k x k, 3-output convolution is run as ccvs_conv2d[_bf16x3] with a k x 1 kernel, 3k outputs
- * (row kx*3+co holds tap column kx of output co) and padding k/2 on both axes, giving
- * t [N,3k,H,W+k-1]; this call sums the k shifted rows:
- *   y[n][co][yy][x] (+)= bias[co] + sum_kx t[n][kx*3+co][yy][x+kx].   y batch stride y_sN, planes dense. */
+/* Second half of the 3-output flow / occlusion heads (skip_autoencoder.py:176-177,204-205,225-226).
+ * The k x k, 3-output convolution is run as ccvs_conv2d[_bf16x3] with 3k outputs and padding k/2 on both axes, either
+ *   vertical == 0: a k x 1 kernel (row kx*3+co holds tap column kx of output co), giving t [N,3k,H,W+k-1], and
+ *     y[n][co][yy][x] (+)= bias[co] + sum_kx t[n][kx*3+co][yy][x+kx]; or
+ *   vertical != 0: a 1 x k kernel (row ky*3+co holds tap row ky of output co), giving t [N,3k,H+k-1,W], and
+ *     y[n][co][yy][x] (+)= bias[co] + sum_ky t[n][ky*3+co][yy+ky][x]   (all k taps of a row in ONE step of the
+ *     convolution kernel: 9x fewer workgroup barriers than the k x 1 form for the 9 x 9 heads).
+ * y batch stride y_sN, planes dense. */
 int ccvs_tap_shift_add(const float* t, const float* bias, float* y, int64_t y_sN, int32_t N, int32_t k, int32_t H, int32_t W,
-                       int32_t accumulate, void* stream);
+                       int32_t accumulate, int32_t vertical, void* stream);
 
 /* ---- vector quantiser ----------------------------------------------------------------
  * ccvs_vq_argmin replaces VectorQuantizer.forward's distance + argmin

@@ -52,14 +52,21 @@ def main():
         x = torch.randn(n, cin, h, h, device="cuda")
         w = torch.randn(cout, cin, k, k, device="cuda")
         b = torch.randn(cout, device="cuda")
-        wp = ops.pack_conv_weight(w)
         pad = 0 if (tr or stride == 2) else k // 2
-        y = ops.conv2d(x, wp, b, cout, k, stride=stride, pad=pad, transposed=tr, act=True)
+        if name.startswith("heads"):   # the model's fused flow/occ heads: 3k-output MFMA convolution + tap sum (ops.conv_heads)
+            wp = ops.pack_head_weights(w[:2], w[2:3])
+            y = torch.zeros(n, 3, h, h, device="cuda")
+            run = lambda: ops.conv_heads(x, wp, b, y, accumulate=True)
+        else:
+            wp = ops.pack_conv_weight(w)
+            y = ops.conv2d(x, wp, b, cout, k, stride=stride, pad=pad, transposed=tr, act=True)
+            run = lambda: ops.conv2d(x, wp, b, cout, k, stride=stride, pad=pad, transposed=tr, act=True, out=y)
+        run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.reps):
-            ops.conv2d(x, wp, b, cout, k, stride=stride, pad=pad, transposed=tr, act=True, out=y)
+            run()
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps

@@ -54,7 +54,7 @@ def main():
     from ccvs_amd import lib
     L = lib.load()
     def tsa():
-        lib.check(L.ccvs_tap_shift_add(ctypes.c_void_p(t.data_ptr()), None, ctypes.c_void_p(fo.data_ptr()), fo.stride(0), n, 9, h, h, 1,
+        lib.check(L.ccvs_tap_shift_add(ctypes.c_void_p(t.data_ptr()), None, ctypes.c_void_p(fo.data_ptr()), fo.stride(0), n, 9, h, h, 1, 0,
                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "tsa")
     row("tap_shift_add k=9 120x27x256x264", timeit(tsa), t.numel() * 4 + 2 * fo.numel() * 4)
     src = [torch.randn(8, 1, c, h, h, device="cuda") for _ in range(15)]
