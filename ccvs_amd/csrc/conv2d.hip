@@ -200,6 +200,8 @@ extern "C" int ccvs_conv2d(const float* x, const float* w_packed, const float* b
     k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad; k.transposed = d->transposed ? 1 : 0;
     k.act = d->act; k.accumulate = d->accumulate; k.out_scale = d->out_scale;
     k.pre = d->pre; k.pre_sN = d->pre_sN; k.pre_sC = d->pre_sC; k.pre_div = d->pre_div > 0 ? d->pre_div : 1;
+    k.in_p8 = 0; k.out_p8 = 0;
+    CCVS_REQUIRE(!d->in_p8 && !d->out_p8, "ccvs_conv2d: packed activations are a split-bf16 format (use ccvs_conv2d_bf16x3)");
 
     // virtual grid (largest parity class for the transposed form)
     const int VH = d->transposed ? (Hout + 1) / 2 : Hout;

@@ -26,6 +26,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
+
+// source of halo pixels outside the image when a packed (P8) activation tile is staged by LDS-DMA
+__device__ uint4 g_conv_zero16 = {0u, 0u, 0u, 0u};
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // two floats -> two bf16 (round to nearest even) in one v_cvt_pk_bf16_f32; element 0 in the low half
@@ -232,6 +235,11 @@ __global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4
 template <int TW, int MB, int NTY>
 __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
     constexpr bool VEC = NTY > 0;
+    // NTY == -8: the input is a packed split-bf16 activation (P8: [N][C/8][hi|lo][H][W] x 8 bf16, written by the epilogue of
+    // the producing convolution): its halo tile is already in the LDS image's format, so the staging waves only issue
+    // LDS-DMA (global_load_lds_dwordx4, zero source outside the image) -- no registers, no conversion.
+    constexpr bool P8IN = NTY == -8;
+    constexpr bool DMAW = VEC || P8IN;   // weights by LDS-DMA from the MFMA waves
     constexpr int CB_XQ = (NTY == -2) ? 2 : 1;  // scalar staging: halo-tile pixel passes per thread and step (passes <= CB_XQ * nt)
     constexpr int TH = 256 / TW;
     constexpr int NT = 32 * MB;
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
     // get a whole chunk (NTY steps).  (Measured alternative: waves 4-5 activations / 6-7 weights was 10 % slower --
     // the conversion work then sits on two of the four SIMDs.)
     const bool xrole = VEC && producer;
-    const bool wrole = VEC ? !producer : producer;
+    const bool wrole = DMAW ? !producer : producer;
     const int rtw = rt;
     const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
     const int n0 = blockIdx.y * NT;
@@ -285,13 +293,13 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
     // ---- producer helpers -------------------------------------------------------------------
     // All per-lane address parts are computed ONCE; per step only wave-uniform (scalar) bases change,
     // so a load is `uniform base + 32-bit lane offset` with no vector address arithmetic.
-    constexpr int NE = VEC ? 1 : CB_MAX_E;
+    constexpr int NE = (VEC || P8IN) ? 1 : CB_MAX_E;
     int offs[NE];  // halo element -> plane offset; -2: no such element, -1: outside the image
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
         const int e = rt + NP * j;
         offs[j] = -2;
-        if (!VEC && producer && e < plane) {
+        if (!VEC && !P8IN && producer && e < plane) {
             const int r = e / IW, c = e - r * IW;
             const int gy = iy0 + r, gx = ix0 + c;
             offs[j] = (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) ? gy * p.Win + gx : -1;
@@ -353,6 +361,35 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
 #pragma unroll
         for (int i = 0; i < CB_WR; ++i)
             if (rtw + NPW * i < wunits) *reinterpret_cast<u32x4*>(dst + rtw + NPW * i) = wraw[i];
+    };
+    // P8 input: slot s = rt + 256 j of the 4-plane LDS image [half][hi|lo][pixel] <- one uint4 of the packed tensor
+    constexpr int NJ = P8IN ? 8 : 1;
+    int p8off[NJ], p8q[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        p8off[j] = -2;  // no such slot
+        p8q[j] = 0;
+        const int s_ = rt + 256 * j;
+        if (P8IN && producer && s_ < 4 * plane) {
+            const int q = s_ / plane, e = s_ - q * plane;
+            const int r = e / IW, c = e - r * IW;
+            const int gy = iy0 + r, gx = ix0 + c;
+            p8off[j] = (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) ? gy * p.Win + gx : -1;
+            p8q[j] = q;
+        }
+    }
+    const int gin = (p.Cin + 7) >> 3;
+    const long hw_in = (long)p.Hin * p.Win;
+    auto dma_x = [&](int c_, uint4* dst) {
+        const uint4* xb = reinterpret_cast<const uint4*>(p.x) + (long)n * gin * 2 * hw_in;  // uniform
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (p8off[j] != -2) {
+                const int g_ = 2 * c_ + (p8q[j] >> 1);
+                const uint4* src = (p8off[j] >= 0 && g_ < gin) ? xb + ((long)g_ * 2 + (p8q[j] & 1)) * hw_in + p8off[j] : &g_conv_zero16;
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + rw * 64 + 256 * j), 16, 0, 0);
+            }
+        }
     };
     // LDS-DMA of one tap row of weights: wave-instruction i of wave rw fills 64 consecutive uint4 of the row image
     auto dma_w = [&](int ci_, int a_, uint4* dst) {
@@ -460,7 +497,10 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
 
     if (producer) {
         // prologue: chunk 0's halo tile and step 0's weights, synchronously and straight into LDS
-        if (xrole) {
+        if (P8IN) {
+            dma_x(0, in_buf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (xrole) {
             load_xv(0);
             store_xv(in_buf);
         } else if (!VEC) {
@@ -469,7 +509,7 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
                 if (o != -2) stage_pixel(xn, p.in_sC, p.Cin, 0, o, in_buf, plane, rt + NP * j);
             }
         }
-        if (!VEC) {
+        if (!DMAW) {
             const uint4* base = wsplit + ((((long)ay_w0 * kw_ + ax_w0) * CinG) * 2) * cout_pad + n0;
 #pragma unroll
             for (int i = 0; i < CB_WR; ++i)
@@ -481,7 +521,19 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
     // steps 0 .. nsteps-1 are the real ones.  (ci, a) = (chunk, tap row) of step s.
     // The two roles run SEPARATE loops that meet at the same barrier once per step: in one shared loop the register
     // allocator keeps the staging bundle live across the MFMA code and the accumulators live across the staging code.
-    if (producer && VEC) {
+    if (producer && P8IN) {
+        // chunk c+1 is requested at step (c, 0) and must have landed when step (c, nt-1) ends; raw s_barrier: a
+        // __syncthreads() here would drain the DMA (vmcnt 0) at EVERY step
+        const bool work = !(ablate & 1);
+        __builtin_amdgcn_s_barrier();  // step -1
+        for (int ci = 0; ci < nchunks; ++ci) {
+            for (int a = 0; a < nt; ++a) {
+                if (work && a == 0 && ci + 1 < nchunks) dma_x(ci + 1, in_buf + ((ci + 1) & 1) * in_sz);
+                if (a == nt - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    } else if (producer && VEC) {
         // chunk c is requested at step (c-2, 0) and converted + stored at step (c-1, 0), a whole chunk later; these are
         // the wave's only outstanding loads.  Requests past the end re-read the last chunk (and are never stored).
         constexpr int NTYc = VEC ? NTY : 1;
@@ -524,7 +576,7 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
     } else {
       int ci = -1, a = nt - 1;
       for (int s = -1; s < nsteps; ++s) {
-        if (VEC && !(ablate & 1) && s + 1 < nsteps) {  // weights of step s+1 by LDS-DMA; hipcc drains them (vmcnt 0) at the barrier
+        if (DMAW && !(ablate & 1) && s + 1 < nsteps) {  // weights of step s+1 by LDS-DMA; hipcc drains them (vmcnt 0) at the barrier
             int a1 = a + 1, c1 = ci;
             if (a1 == nt) { a1 = 0; ++c1; }
             dma_w(c1, a1, w_buf + ((s + 1) & 1) * w_sz);
@@ -601,6 +653,40 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
                         stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * 256 + (rw * 2 + pp) * 32 + (lane & 31)] = acc[m][pp][r];
             }
             __syncthreads();
+            if (p.out_p8) {
+                // packed output: a thread takes one pixel x 8 output channels of the staged 32 x 256 block, applies the
+                // epilogue, splits to hi / lo and writes two 16-byte units (lanes = consecutive pixels: coalesced)
+                uint4* y4 = reinterpret_cast<uint4*>(p.y);
+                const int gout = (p.Cout + 7) >> 3;
+                const long hw_out = (long)p.Hout * p.Wout;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int item = tid + 512 * i;
+                    const int gq = item >> 8, px = item & 255;
+                    const int co0 = n0 + m * 32 + gq * 8;
+                    const int prow = px / TW, pcol = px - prow * TW;
+                    const int vy = ty * TH + prow, vx = tx * TW + pcol;
+                    if (co0 < p.Cout && vy < ay.V && vx < ax.V) {
+                        const long opix = (long)vy * p.Wout + vx;
+                        float v[8];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            float t = stage[(gq * 8 + c) * 256 + px];
+                            if (p.pre) t += p.pre[(long)(n / p.pre_div) * p.pre_sN + (long)(co0 + c) * p.pre_sC + opix];
+                            if (p.bias) t += p.bias[co0 + c];
+                            if (p.act == CCVS_ACT_LRELU) t = lrelu01(t);
+                            v[c] = t * p.out_scale;
+                        }
+                        uint4 hi, lo;
+                        split8(v, hi, lo);
+                        uint4* dst = y4 + ((long)n * gout + (co0 >> 3)) * 2 * hw_out + opix;
+                        dst[0] = hi;
+                        dst[hw_out] = lo;
+                    }
+                }
+                if (m + 1 < MB) __syncthreads();
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < (2048 + 255 + NP) / (256 + NP); ++i) {
                 const int idx4 = tid + (256 + NP) * i;
@@ -695,12 +781,23 @@ static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int ha
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_kernel<TW, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, -2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, -8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     static const int ablate = getenv("CCVS_CONV_ABLATE") ? atoi(getenv("CCVS_CONV_ABLATE")) : 0;  // timing experiments only (1: no staging, 2: no MFMA, 4: scalar staging)
     dim3 grid(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
+    if (k.in_p8) {  // packed input: LDS-DMA staging (validated by the caller: stride 1, not transposed, Cin % 8 == 0)
+        const size_t smem_p = (size_t)(2 * 4 * plane + 2 * ntx_max * 4 * NT) * 16;
+        if (4 * plane > 8 * 256 || ntx_max > (MB == 1 ? 9 : 3) || smem_p > 156 * 1024) {
+            ccvs_set_error("ccvs_conv2d_bf16x3: packed input with a %dx%d halo tile / %d taps per row is not supported", halo_h, halo_w, ntx_max);
+            return CCVS_ERR_ARG;
+        }
+        hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, -8>), grid, dim3(512), smem_p, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
+        CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
+        return CCVS_OK;
+    }
     // aligned float4 staging: dense stride-1 rows on 16-byte boundaries, one item per staging thread
     const int xsh = ((-k.pad % 4) + 4) % 4, nq = (xsh + halo_w + 3) / 4;
     const bool vec_ok = !k.transposed && k.stride == 1 && k.Win % 4 == 0 && k.in_sC % 4 == 0 && k.in_sN % 4 == 0 &&
@@ -730,6 +827,10 @@ static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int ha
         hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, -2>), grid, dim3(512), smem_pc, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
         CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
         return CCVS_OK;
+    }
+    if (k.out_p8) {
+        ccvs_set_error("ccvs_conv2d_bf16x3: packed output is not available for this shape (synchronous kernel)");
+        return CCVS_ERR_ARG;
     }
     const size_t smem = (size_t)(4 * plane + ntx_max * 4 * NT) * 16;
     if (smem > 160 * 1024) {
@@ -768,6 +869,9 @@ extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const flo
     k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad; k.transposed = d->transposed ? 1 : 0;
     k.act = d->act; k.accumulate = d->accumulate; k.out_scale = d->out_scale;
     k.pre = d->pre; k.pre_sN = d->pre_sN; k.pre_sC = d->pre_sC; k.pre_div = d->pre_div > 0 ? d->pre_div : 1;
+    k.in_p8 = d->in_p8 ? 1 : 0; k.out_p8 = d->out_p8 ? 1 : 0;
+    if (k.in_p8) CCVS_REQUIRE(!d->transposed && d->stride == 1 && d->Cin % 8 == 0, "ccvs_conv2d_bf16x3: packed input needs stride 1, Cin %% 8 == 0");
+    if (k.out_p8) CCVS_REQUIRE(!d->transposed && d->Cout % 8 == 0 && !d->accumulate && !residual, "ccvs_conv2d_bf16x3: packed output needs Cout %% 8 == 0, no residual / accumulate");
     const int CinG = 2 * ((d->Cin + 15) / 16);  // 8-channel groups, Cin padded to 16
 
     const int VH = d->transposed ? (Hout + 1) / 2 : Hout;

@@ -20,6 +20,7 @@ struct ConvK {
     long pre_sN, pre_sC;
     int pre_div;
     int tiles_x, tiles_y;
+    int in_p8, out_p8;  // split-bf16 packed activations (ccvs_hip.h: ccvs_conv_desc)
 };
 
 struct AxisTaps {

@@ -68,12 +68,12 @@ class EqualConv2d(nn.Module):
             self._packed = (key, ops.pack_conv_weight(w))
         return self._packed[1]
 
-    def forward(self, input, act=False, residual=None, out_scale=1.0, out=None, accumulate=False):
+    def forward(self, input, act=False, residual=None, out_scale=1.0, out=None, accumulate=False, out_p8=False):
         if self.transpose and self.kernel_size == 1:
             raise NotImplementedError("1x1 transposed conv is folded into ConvLayer's FIR up-sampling")
         return ops.conv2d(input, self.packed(), self.bias, self.out_channel, self.kernel_size, stride=self.stride,
                           pad=self.padding, transposed=self.transpose, act=act, residual=residual, out_scale=out_scale,
-                          out=out, accumulate=accumulate)
+                          out=out, accumulate=accumulate, out_p8=out_p8)
 
     def __repr__(self):
         return (f"{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]},"
@@ -111,8 +111,11 @@ class ConvLayer(nn.Module):
         self.__dict__["conv"] = layers[1] if downsample else layers[0]
         self.__dict__["blur"] = layers[0] if downsample else (layers[1] if upsample else None)
 
-    def forward(self, input, residual=None, out_scale=1.0, out=None, accumulate=False):
+    def forward(self, input, residual=None, out_scale=1.0, out=None, accumulate=False, out_p8=False):
+        """`input` may be an ops.P8Act and `out_p8` asks for one (plain stride-1 layers on the split-bf16 kernel): packed
+        intermediates of a conv -> conv chain, bit-identical to the fp32 chain."""
         conv, act = self.conv, self.activate
+        assert not out_p8 or not (self.downsample or self.upsample)
         if self.downsample:
             if self.kernel_size == 1:
                 # Blur(pad) then a stride-2 1x1 conv == decimating FIR then a dense 1x1 conv
@@ -132,7 +135,7 @@ class ConvLayer(nn.Module):
                 return ops.upfirdn2d(x, up=2, pad=(p0, p1 - 1), gain=self.blur.gain, act=act, residual=residual, out_scale=out_scale)
             x = conv(input)  # bias is added before the blur, like F.conv_transpose2d(bias=...)
             return self.blur(x, act=act, residual=residual, out_scale=out_scale)
-        return conv(input, act=act, residual=residual, out_scale=out_scale, out=out, accumulate=accumulate)
+        return conv(input, act=act, residual=residual, out_scale=out_scale, out=out, accumulate=accumulate, out_p8=out_p8)
 
 
 class ResBlock(nn.Module):
@@ -273,7 +276,8 @@ class InterBlock(nn.Module):
         corr = ops.correlation7x7(pa, pb, self.corr_stride, first_div=k, lrelu=True)
         if m.upsample_corr is not None:
             corr = ops.dwconvT4x4s2(corr, m.upsample_corr.weight.detach())
-        feat = m.convs[2](m.convs[1](m.convs[0](corr)))
+        p8 = ops.CONV_PRECISION == "bf16x3" and ops.CONV_P8   # conv -> conv intermediates stay in the kernel's packed split-bf16 form
+        feat = m.convs[2](m.convs[1](m.convs[0](corr, out_p8=p8), out_p8=p8), out_p8=p8)
         self._m_heads(feat, fo, accumulate=fo_prev is not None)
         del corr, feat, pa, pb, inter_w
         sp = self.subpixel
@@ -281,8 +285,8 @@ class InterBlock(nn.Module):
         conv0 = sp.convs[0].conv
         pre = ops.conv2d(dec, w_dec, None, conv0.out_channel, 3, pad=1)          # [N,128,H,W], before dec is blended
         ops.backwarp(ctxs, fo[:, :2], self.flow_mult, out=sp_in[:, :s])
-        feat = ops.conv2d(sp_in, w_rest, conv0.bias, conv0.out_channel, 3, pad=1, act=True, pre=pre, pre_div=k)
-        feat = sp.convs[2](sp.convs[1](feat))
+        feat = ops.conv2d(sp_in, w_rest, conv0.bias, conv0.out_channel, 3, pad=1, act=True, pre=pre, pre_div=k, out_p8=p8)
+        feat = sp.convs[2](sp.convs[1](feat, out_p8=p8), out_p8=p8)
         self._s_heads(feat, fo, accumulate=True)
         del feat, pre
         ops.warp_fuse_blend(dec, ctxs, fo[:, :2], fo[:, 2:3], self.flow_mult, k)

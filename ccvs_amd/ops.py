@@ -41,6 +41,10 @@ class KernelTimer:
 
 
 KERNEL_TIMER = None  # set to a KernelTimer() to time conv launches
+# Packed split-bf16 intermediates in the conv -> conv chains of the InterBlocks (P8Act).  Bit-identical, but OFF by default:
+# measured on a BAIR batch the consumers gain 41 ms (LDS-DMA staging, no conversion) while the 128-channel producers lose
+# 62 ms in their now serial split-and-store epilogue (tools/prof_p8_cmp.sh).
+CONV_P8 = __import__("os").environ.get("CCVS_CONV_P8", "0") == "1"
 
 
 def _stream():
@@ -81,6 +85,26 @@ class PackedConv:
         self.kw = k if kw is None else kw
 
 
+class P8Act:
+    """A split-bf16 packed activation (`ccvs_conv_desc.in_p8 / out_p8`): logical [n, c, h, w] fp32 values stored as
+    [n][c/8][hi|lo][h][w] units of 8 bf16 -- what the convolution kernel stages in LDS, so a conv -> conv chain moves its
+    intermediate tensors with no conversion work.  `data` is an opaque float32 buffer of n*c*h*w elements."""
+    __slots__ = ("data", "n", "c", "h", "w")
+
+    def __init__(self, data, n, c, h, w):
+        self.data, self.n, self.c, self.h, self.w = data, n, c, h, w
+
+    @property
+    def shape(self):
+        return (self.n, self.c, self.h, self.w)
+
+    def float(self):
+        """Decode to an fp32 [n,c,h,w] tensor (hi + lo) -- tests / debugging only."""
+        u = self.data.view(torch.bfloat16).view(self.n, self.c // 8, 2, self.h, self.w, 8).float()
+        v = u[:, :, 0] + u[:, :, 1]                                   # [n, g, h, w, 8]
+        return v.permute(0, 1, 4, 2, 3).reshape(self.n, self.c, self.h, self.w).contiguous()
+
+
 def pack_conv_weight(weight, precision=None, scale=None):
     """[Cout,Cin,k,k] parameter -> PackedConv, with the EqualConv2d scale 1/sqrt(Cin*k*k) multiplied in
     first (the same fp32 product as `weight * scale`, skip_autoencoder.py:44,55,58).
@@ -110,10 +134,16 @@ def pack_conv_weight(weight, precision=None, scale=None):
 
 
 def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=False, residual=None,
-           out_scale=1.0, out=None, accumulate=False, pre=None, pre_div=1):
-    """y = [y +] (act(conv(x) [+ pre[n // pre_div]] + bias) [+ residual]) * out_scale."""
-    _need_gpu(x, w_packed.data, bias, residual, out, pre)
-    x = _as_rows_dense(x)
+           out_scale=1.0, out=None, accumulate=False, pre=None, pre_div=1, out_p8=False):
+    """y = [y +] (act(conv(x) [+ pre[n // pre_div]] + bias) [+ residual]) * out_scale.
+    x may be a P8Act (packed split-bf16 input); out_p8=True returns one (split-bf16 kernel only)."""
+    in_p8 = isinstance(x, P8Act)
+    if in_p8:
+        _need_gpu(x.data, w_packed.data, bias, residual, out, pre)
+        assert w_packed.kind == "bf16x3" and stride == 1 and not transposed
+    else:
+        _need_gpu(x, w_packed.data, bias, residual, out, pre)
+        x = _as_rows_dense(x)
     n, cin, h, w = x.shape
     assert w_packed.k == k and w_packed.cin == cin and w_packed.cout == cout, (w_packed.k, w_packed.cin, w_packed.cout, k, cin, cout)
     kw = w_packed.kw
@@ -121,14 +151,22 @@ def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=Fa
         ho, wo = 2 * h + k - 2, 2 * w + k - 2
     else:
         ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - kw) // stride + 1
-    if out is None:
-        out = torch.empty(n, cout, ho, wo, dtype=torch.float32, device=x.device)
-    assert out.shape == (n, cout, ho, wo) and _rows_dense(out), (out.shape, (n, cout, ho, wo))
+    dev = x.data.device if in_p8 else x.device
+    if out_p8:
+        assert w_packed.kind == "bf16x3" and cout % 8 == 0 and out is None and residual is None and not accumulate
+        out = torch.empty(n * cout * ho * wo, dtype=torch.float32, device=dev)
+    elif out is None:
+        out = torch.empty(n, cout, ho, wo, dtype=torch.float32, device=dev)
+    if not out_p8:
+        assert out.shape == (n, cout, ho, wo) and _rows_dense(out), (out.shape, (n, cout, ho, wo))
     d = _lib.ConvDesc()
     d.N, d.Cin, d.Hin, d.Win = n, cin, h, w
-    d.in_sN, d.in_sC = x.stride(0), x.stride(1)
+    d.in_p8, d.out_p8 = (1 if in_p8 else 0), (1 if out_p8 else 0)
+    if not in_p8:
+        d.in_sN, d.in_sC = x.stride(0), x.stride(1)
     d.Cout, d.CoutPad, d.Hout, d.Wout = cout, w_packed.cout_pad, ho, wo
-    d.out_sN, d.out_sC = out.stride(0), out.stride(1)
+    if not out_p8:
+        d.out_sN, d.out_sC = out.stride(0), out.stride(1)
     if residual is not None:
         residual = _as_rows_dense(residual)
         assert residual.shape == out.shape
@@ -148,10 +186,11 @@ def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=Fa
         macs = n * cout * cin * k * kw * (h * w if transposed else ho * wo)
         prof.begin("conv2d_" + w_packed.kind, flops=2.0 * macs)
     fn = L.ccvs_conv2d if w_packed.kind == "f32" else L.ccvs_conv2d_bf16x3
-    _lib.check(fn(_p(x), _p(w_packed.data), _p(bias), _p(residual), _p(out), C.byref(d), _stream()), "ccvs_conv2d[" + w_packed.kind + "]")
+    _lib.check(fn(_p(x.data if in_p8 else x), _p(w_packed.data), _p(bias), _p(residual), _p(out), C.byref(d), _stream()),
+               "ccvs_conv2d[" + w_packed.kind + "]")
     if prof is not None:
         prof.end()
-    return out
+    return P8Act(out, n, cout, ho, wo) if out_p8 else out
 
 
 def pack_head_weights(flow_w, occ_w, precision=None):

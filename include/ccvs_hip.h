@@ -65,6 +65,12 @@ typedef struct ccvs_conv_desc {
     const float* pre;
     int64_t pre_sN, pre_sC;
     int32_t pre_div;
+    /* split-bf16 packed activations ("P8", ccvs_conv2d_bf16x3 only): [N][C/8][2 = hi,lo][H][W] units of 8 bf16 (16 bytes),
+     * v = hi + lo -- the same bytes per element as fp32, already in the layout the kernel stages in LDS.
+     * in_p8: x is such a tensor (dense; in_sN / in_sC ignored): staged by LDS-DMA with no conversion work.
+     * out_p8: y is written in that form (dense; out_sN / out_sC ignored) by the epilogue, for the next convolution.
+     * A chain conv -> conv run this way is bit-identical to the fp32-activation chain. */
+    int32_t in_p8, out_p8;
 } ccvs_conv_desc;
 
 int ccvs_conv2d(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,

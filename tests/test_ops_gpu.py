@@ -459,3 +459,33 @@ def test_warp_kernels_with_context_list(ops):
     ops.warp_fuse_blend(a[:, :c], ctxs, flow, occ, 0.5, k)
     ops.warp_fuse_blend(b[:, :c], stacked, flow, occ, 0.5, k)
     assert torch.equal(a, b)
+
+
+def test_conv_packed_activation_chain(ops):
+    """conv -> conv -> conv with split-bf16 packed (P8) intermediates == the same chain with fp32 intermediates, bit for bit
+    (3x3, 1x1 and 1xk kernels, ragged image edges, Cout 128 / 64 / 32 tiles, channel counts that are odd multiples of 8)."""
+    if ops.CONV_PRECISION != "bf16x3":
+        pytest.skip("packed activations are a split-bf16 format")
+    torch.manual_seed(5)
+    for n, h, w in ((3, 40, 36), (2, 8, 8), (1, 70, 33)):
+        x = torch.randn(n, 19, h, w).cuda()
+        specs = [(19, 128, 3, 3), (128, 72, 3, 3), (72, 40, 1, 1), (40, 24, 1, 5), (24, 32, 3, 3)]
+        ws = [torch.randn(co, ci, kh, kw).cuda() for ci, co, kh, kw in specs]
+        bs = [torch.randn(co).cuda() for _, co, _, _ in specs]
+        packs = [ops.pack_conv_weight(wt) for wt in ws]
+
+        def run2(packed):
+            t = x
+            outs = []
+            for i, (ci, co, kh, kw) in enumerate(specs):
+                last = i == len(specs) - 1
+                pad = kh // 2 if kh == kw else 2
+                t = ops.conv2d(t, packs[i], bs[i], co, kh, pad=pad, act=not last, out_p8=packed and not last)
+                outs.append(t)
+            return outs
+        a, b = run2(False), run2(True)
+        for i in range(len(specs) - 1):
+            # the packed tensor decodes to hi + lo of the fp32 value: equal to 2^-16 relative
+            assert b[i].shape == tuple(a[i].shape)
+            assert (b[i].float() - a[i]).abs().max().item() <= 2e-5 * a[i].abs().max().item() + 1e-6
+        assert torch.equal(a[-1], b[-1])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One convolution shape, a few launches -- the target of rocprofv3 --pmc runs.
-    python tools/conv_one.py Cin Cout k H N [precision]"""
+    python tools/conv_one.py Cin Cout k H N [precision] [p8]     (p8: packed split-bf16 input and output)"""
 import os
 import sys
 
@@ -10,19 +10,24 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ccvs_amd import ops  # noqa: E402
 
 cin, cout, k, h, n = [int(v) for v in sys.argv[1:6]]
-if len(sys.argv) > 6:
+p8 = "p8" in sys.argv[6:]
+if len(sys.argv) > 6 and sys.argv[6] != "p8":
     ops.CONV_PRECISION = sys.argv[6]
 torch.manual_seed(0)
 x = torch.randn(n, cin, h, h, device="cuda")
 w = torch.randn(cout, cin, k, k, device="cuda")
 b = torch.randn(cout, device="cuda")
 wp = ops.pack_conv_weight(w)
-y = ops.conv2d(x, wp, b, cout, k, pad=k // 2, act=True)
+if p8:   # a packed input: the output of an identity 1x1 convolution
+    eye = torch.eye(cin, device="cuda").view(cin, cin, 1, 1) * (cin ** 0.5)
+    x = ops.conv2d(x, ops.pack_conv_weight(eye), None, cin, 1, out_p8=True)
+kw = dict(out_p8=True) if p8 else {}
+y = ops.conv2d(x, wp, b, cout, k, pad=k // 2, act=True, **kw)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(3):
-    ops.conv2d(x, wp, b, cout, k, pad=k // 2, act=True, out=y)
+    ops.conv2d(x, wp, b, cout, k, pad=k // 2, act=True, **(kw if p8 else dict(out=y)))
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 3
