@@ -198,7 +198,8 @@ def main():
                            "predicted_frames_per_clip": predicted, "sampling": f"top-k {xopt.top_k}, T={xopt.temperature}, noise={args.sample_noise}",
                            "parallelism": f"dp{world} (batch sharded, one RCCL all-gather of uint8 clips)"},
                 "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
-                "roofline": {"kernel": "conv2d_bf16x3_kernel" if kind == "bf16x3" else "conv2d_mfma_kernel", "bound": "mfma",
+                "roofline": {"kernel": ("conv2d_bf16x3_pc_kernel<TW,MB,NTY> + conv2d_bf16x3_kernel<TW,MB> (every instantiation: all conv launches)"
+                                        if kind == "bf16x3" else "conv2d_mfma_kernel<TW,MB>"), "bound": "mfma",
                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                              "traffic": (conv_traffic(args, kind, n_conv) or {}).get("bytes_per_launch"),
                              "traffic_detail": conv_traffic(args, kind, n_conv),
@@ -206,6 +207,8 @@ def main():
                              "vs_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                              "launches": n_conv, "avg_launch_us": 1e3 * conv_ms / max(n_conv, 1),
                              "algorithmic_gflop_per_launch": conv_flops / max(n_conv, 1) / 1e9,
+                             "algorithmic_bytes_per_launch": timer.total_bytes("conv2d_" + kind) / max(n_conv, 1),
+                             "clock_note": "GRBM cycles / time = 2.0 GHz under this kernel (power-limited), i.e. a 2083 TF/s bf16 ceiling",
                              "share_of_step_time": conv_ms * 1e-3 / elapsed},
             }
             if not args.no_cpu_baseline and args.config == "bair":

@@ -23,21 +23,25 @@ class KernelTimer:
         self.records = []  # (name, algorithmic flops, start event, end event)
         self._open = None
 
-    def begin(self, name, flops=0.0):
+    def begin(self, name, flops=0.0, nbytes=0.0):
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        self._open = (name, flops, e0)
+        self._open = (name, flops, e0, nbytes)
 
     def end(self):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        name, flops, e0 = self._open
-        self.records.append((name, flops, e0, e1))
+        name, flops, e0, nbytes = self._open
+        self.records.append((name, flops, e0, e1, nbytes))
 
     def summary(self, name):
         """(launches, total algorithmic flops, total milliseconds) -- call after a device sync."""
         rec = [r for r in self.records if r[0] == name]
         return len(rec), sum(r[1] for r in rec), sum(r[2].elapsed_time(r[3]) for r in rec)
+
+    def total_bytes(self, name):
+        """Algorithmic bytes (inputs read once + outputs written once) of the launches called `name`."""
+        return sum(r[4] for r in self.records if r[0] == name)
 
 
 KERNEL_TIMER = None  # set to a KernelTimer() to time conv launches
@@ -184,7 +188,7 @@ def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=Fa
     prof = KERNEL_TIMER
     if prof is not None:
         macs = n * cout * cin * k * kw * (h * w if transposed else ho * wo)
-        prof.begin("conv2d_" + w_packed.kind, flops=2.0 * macs)
+        prof.begin("conv2d_" + w_packed.kind, flops=2.0 * macs, nbytes=4.0 * (n * cin * h * w + n * cout * ho * wo))
     fn = L.ccvs_conv2d if w_packed.kind == "f32" else L.ccvs_conv2d_bf16x3
     _lib.check(fn(_p(x.data if in_p8 else x), _p(w_packed.data), _p(bias), _p(residual), _p(out), C.byref(d), _stream()),
                "ccvs_conv2d[" + w_packed.kind + "]")
