@@ -278,7 +278,11 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
     // VEC: the LDS image starts at the 4-pixel boundary at or left of ix0 (xsh pixels earlier) and has NQ float4 columns
     const int xsh = VEC ? ((ax.lo % 4) + 4) % 4 : 0;
     const int NQ = (xsh + IW + 3) >> 2;
-    const int IWS = VEC ? 4 * NQ : IW;   // LDS row stride in pixels
+    // LDS row stride in pixels.  VEC: ODD, and consecutive staging lanes take consecutive ROWS of one float4 column: the 8
+    // lanes a ds_write_b128 services together then hit 8 different 16-byte slots modulo 128 B (banks of a store:
+    // (a/4) mod 32) -- with the rows 4*NQ slots apart and lanes along the row the same stores were 4-way conflicts
+    // (75 % of the staging waves' LDS cycles, SQ_LDS_BANK_CONFLICT).
+    const int IWS = VEC ? 4 * NQ + 1 : IW;
     const int plane = IH * IWS;
     const int in_sz = 4 * plane, w_sz = ntx_max * 4 * NT;
     uint4* in_buf = smem4;               // [2][half 2][part 2][plane]
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
             const int it = min(it0_, n_items - 1);
             vh[j] = it / (IH * NQ);
             const int rem = it - vh[j] * IH * NQ;
-            const int vr = rem / NQ, vq = rem - vr * NQ;
+            const int vq = rem / IH, vr = rem - vq * IH;  // rows fastest (see IWS)
             const int gy = iy0 + vr, gxa = ix0 - xsh + 4 * vq;
             vin[j] = gy >= 0 && gy < p.Hin && gxa >= 0 && gxa < p.Win;  // aligned and Win % 4 == 0: all 4 pixels in or out
             vptr[j] = xn + (long)(8 * vh[j]) * p.in_sC + (vin[j] ? gy * p.Win + gxa : 0);
@@ -804,7 +808,7 @@ static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int ha
                         (reinterpret_cast<uintptr_t>(k.x) & 15) == 0 && TW >= 16 && halo_h * nq * 2 <= 256 && ntx_max <= (MB == 1 ? 9 : 3) &&
                         (k.kh == 1 || k.kh == 3) && !(ablate & 4);
     if (vec_ok) {
-        const size_t smem_v = (size_t)(2 * 4 * halo_h * nq * 4 + 2 * ntx_max * 4 * NT) * 16;
+        const size_t smem_v = (size_t)(2 * 4 * halo_h * (nq * 4 + 1) + 2 * ntx_max * 4 * NT) * 16;
         if (smem_v <= 156 * 1024) {
             if (k.kh == 3) hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 3>), grid, dim3(512), smem_v, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
             else hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 1>), grid, dim3(512), smem_v, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
