@@ -445,7 +445,9 @@ class GPT(nn.Module):
             for k, v in state.items():
                 c[k].copy_(v)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: with torch.distributed initialised the RCCL watchdog thread issues HIP calls of its own, which the
+            # default 'global' capture mode would treat as capture violations
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 self._decode_body(sampler)
             for k, v in state.items():   # capture does not execute; kept for clarity
                 c[k].copy_(v)

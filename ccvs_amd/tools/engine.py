@@ -29,7 +29,8 @@ class Engine(object):
             if not dist.is_initialized():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29500")
-                dist.init_process_group(backend=self.backend, init_method="env://", rank=self.rank, world_size=self.world_size)
+                kw = {"device_id": torch.device("cuda", self.local_rank)} if self.backend == "nccl" else {}  # eager RCCL init
+                dist.init_process_group(backend=self.backend, init_method="env://", rank=self.rank, world_size=self.world_size, **kw)
                 self._own_group = True
             self.devices = list(range(self.world_size))
         self.is_main = self.rank == 0
