@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")
 torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))  # as Engine does
 from ccvs_amd import ops  # noqa: E402
 from ccvs_amd.tools.options import Options, BAIR_ARGV  # noqa: E402
 from ccvs_amd.helpers.generator import Generator  # noqa: E402
