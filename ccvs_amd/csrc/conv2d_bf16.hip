@@ -209,29 +209,25 @@ __global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4
 }
 
 // ---------------------------------------------------------------------------------------
-// Producer / consumer form (used whenever its LDS and register staging fit): a 512-thread
-// workgroup whose waves 0-3 only issue MFMAs and whose waves 4-7 only stage -- the matrix pipe and
-// the VALU / memory pipes of a SIMD run concurrently, so the fp32 -> split-bf16 conversion hides
-// under the MFMAs.  A step is one tap row of one 16-channel chunk; the halo tile and the tap-row
-// weights are double-buffered in LDS and handed over with ONE workgroup barrier per step.
-// The producers are software-pipelined one step deep in REGISTERS: during step s they first
-// convert + store what they loaded during step s-1 (needed at step s+1), then issue the global
-// loads for step s+2 -- so every load has a whole step of MFMA time to land before it is touched.
-//   bundle of step t:  W_row(t)   and, for chunk c, the halo-tile parts j (pixel pass j of the 256
-//   producer threads) with j % nt == a, which are stored during step (c-1, a) and loaded one
-//   step before that.
+// Producer / consumer form (used whenever its LDS and register staging fit): a 512-thread workgroup whose waves
+// 0-3 only issue MFMAs and whose waves 4-7 only stage -- each SIMD hosts one of each, the matrix pipe runs beside
+// the VALU / memory / LDS pipes, so the fp32 -> split-bf16 conversion sits under the MFMAs.  A step is one tap row
+// of one 16-channel chunk; the halo tile (per chunk) and the tap-row weights (per step) are double-buffered in LDS
+// and handed over with ONE workgroup barrier per step.  The two roles run separate loops that meet at that barrier.
+//
+// Staging mode, template parameter NTY:
+//   NTY = 1 | 3  "VEC", dense stride-1 layers on 16-byte aligned rows with 1 or 3 tap rows (the common case).
+//        Activations: the halo tile widened to 4-pixel boundaries, one item = 4 pixels x 8 channels per staging
+//        thread and chunk (8 x global_load_dwordx4 -> split -> 8 x ds_write_b128), requested a whole chunk before
+//        it is converted.  Weights (pre-split by the host, no conversion): LDS-DMA (global_load_lds_dwordx4) issued
+//        by the MFMA waves, so that the staging waves' in-order vmcnt queue holds activation loads only.
+//   NTY = -8     packed split-bf16 input (ccvs_conv_desc.in_p8): activations by LDS-DMA too, no conversion.
+//   NTY = 0      scalar staging, any tap count (k x 1 heads with odd padding, unaligned views): 16 dword loads per
+//        staging thread and step, software-pipelined one step deep in registers together with the weights
+//        (convert + store what was loaded during step s-1, then request the bundle of step s+2).
+//   NTY = -2     the same with two pixel passes per thread and step (transposed layers: larger halo tiles).
+// Stride-2 layers and halo tiles that do not fit the double buffer use the synchronous kernel above.
 // ---------------------------------------------------------------------------------------
-
-// VEC (stride-1 dense convolutions on 16-byte aligned rows): the halo tile is staged from ALIGNED float4 loads.
-// A staging thread owns one item = 4 consecutive pixels x 8 channels (8 x global_load_dwordx4, 8 x ds_write_b128
-// after the split) of the tile widened to 4-pixel boundaries; a whole chunk is one item per thread, requested a
-// full chunk (nt steps) before it is converted.  Against the scalar form (16 dword loads per thread and step)
-// that is 4.5x fewer load instructions and 1.6x the bytes in flight per CU -- the staging side was latency-bound.
-// NTY > 0 selects VEC with NTY tap rows per chunk (1 or 3) as a compile-time constant: the staging loop is then
-// unrolled over a chunk's steps, every load is unconditional (clamped at the tail), and hipcc can give each
-// s_waitcnt the exact vmcnt -- with run-time step structure it falls back to vmcnt(0) at every LDS store, which
-// drags the HBM latency of the activation loads into every step.  NTY == 0: scalar staging, any tap count;
-// NTY == -2: the same with two pixel passes per thread and step (stride-2 and transposed layers: larger halo tiles).
 template <int TW, int MB, int NTY>
 __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
     constexpr bool VEC = NTY > 0;

@@ -63,7 +63,7 @@ class EqualConv2d(nn.Module):
 
     def packed(self):
         w = self.weight
-        key = (w.data_ptr(), w._version, w.device)
+        key = (w.data_ptr(), w._version, w.device, ops.CONV_PRECISION)
         if self._packed is None or self._packed[0] != key:
             self._packed = (key, ops.pack_conv_weight(w))
         return self._packed[1]
