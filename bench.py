@@ -151,7 +151,8 @@ def main():
         def make_batch(step):
             return {"vid": gen.synthetic_batch(args.batch, seed=1 + step, first_clip=lo)["vid"].to(dev)}
 
-        calibrate_codebook(gen, make_batch(0))
+        # the same clips on every rank (global clips 0-1 of seed 1): the codebook scale, hence the replica, is identical everywhere
+        calibrate_codebook(gen, {"vid": gen.synthetic_batch(2, seed=1, first_clip=0)["vid"].to(dev)})
 
         def one_step(step, data):
             out = gen.generate_vid(data, step)
