@@ -87,6 +87,14 @@ extern "C" int ccvs_layernorm(const float* x, const float* gamma, const float* b
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 
+// row statistics of the folded LayerNorm: one definition, floating-point contraction off, so that the plain and the
+// row-blocked kernel (and any future variant) accumulate bit-identically
+__device__ __forceinline__ void ln_accum(const float4& v, float& sx, float& sxx) {
+#pragma clang fp contract(off)
+    sx += (v.x + v.y) + (v.z + v.w);
+    sxx += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+}
+
 struct Gemm16 {
     const float* x; long ldx;
     const float* w; const float* bias; const float* res; float* y; long ldy;
@@ -155,10 +163,7 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].y, wv[u].y, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].z, wv[u].z, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].w, wv[u].w, acc1, 0, 0, 0);
-                if (p.ln_s) {
-                    sx += (xv[u].x + xv[u].y) + (xv[u].z + xv[u].w);
-                    sxx += (xv[u].x * xv[u].x + xv[u].y * xv[u].y) + (xv[u].z * xv[u].z + xv[u].w * xv[u].w);
-                }
+                if (p.ln_s) ln_accum(xv[u], sx, sxx);
             }
         }
         for (; k0 < kper; k0 += 16) {  // remainder (small K only)
@@ -168,10 +173,7 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, w1.y, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, w1.z, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, w1.w, acc1, 0, 0, 0);
-            if (p.ln_s) {
-                sx += (x1.x + x1.y) + (x1.z + x1.w);
-                sxx += (x1.x * x1.x + x1.y * x1.y) + (x1.z * x1.z + x1.w * x1.w);
-            }
+            if (p.ln_s) ln_accum(x1, sx, sxx);
         }
     }
     f32x4 acc = acc0 + acc1;
@@ -249,8 +251,125 @@ __global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
     }
 }
 
+// Row-blocked form for M > 16 (prefill, batches beyond 16): one workgroup computes RB row blocks of 16 against the SAME
+// 16 output columns, so a weight tile is fetched once per 16*RB rows instead of once per 16 (the plain kernel re-reads
+// W from L2 for every row block).  Same K slicing over the 8 waves, same MFMA order per row block and the same
+// slab summation order (wave 0 first), hence bit-identical to the plain kernel.  No split-K here (kz = 1).
+template <int RB>
+__global__ __launch_bounds__(512) void gemm16_rb_kernel(Gemm16 p) {
+    __shared__ __attribute__((aligned(16))) float red[RB * 8 * 64 * 4];
+    __shared__ float stat[RB * 8 * 16 * 2];
+    __shared__ float fin[RB * 16 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * 16 * RB, ncol0 = blockIdx.x * 16;
+    const int nrow = min(ncol0 + li, p.N - 1);
+    const int kper = p.K / p.ks;
+    const bool active = wave < p.ks;
+    const float* wp = p.w + (long)nrow * p.K + (active ? wave : 0) * kper + 4 * g;
+    const float* xp[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) xp[rb] = p.x + (long)min(m0 + 16 * rb + li, p.M - 1) * p.ldx + (active ? wave : 0) * kper + 4 * g;
+    f32x4 acc0[RB], acc1[RB];
+    float sx[RB], sxx[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { acc0[rb] = {0.f, 0.f, 0.f, 0.f}; acc1[rb] = {0.f, 0.f, 0.f, 0.f}; sx[rb] = 0.f; sxx[rb] = 0.f; }
+    if (active) {
+        int k0 = 0;
+        for (; k0 + 16 * GEMM_U <= kper; k0 += 16 * GEMM_U) {
+            float4 wv[GEMM_U];
+#pragma unroll
+            for (int u = 0; u < GEMM_U; ++u) wv[u] = *reinterpret_cast<const float4*>(wp + k0 + 16 * u);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                float4 xv[GEMM_U];
+#pragma unroll
+                for (int u = 0; u < GEMM_U; ++u) xv[u] = *reinterpret_cast<const float4*>(xp[rb] + k0 + 16 * u);
+#pragma unroll
+                for (int u = 0; u < GEMM_U; ++u) {
+                    acc0[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].x, wv[u].x, acc0[rb], 0, 0, 0);
+                    acc1[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].y, wv[u].y, acc1[rb], 0, 0, 0);
+                    acc0[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].z, wv[u].z, acc0[rb], 0, 0, 0);
+                    acc1[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].w, wv[u].w, acc1[rb], 0, 0, 0);
+                    if (p.ln_s) ln_accum(xv[u], sx[rb], sxx[rb]);
+                }
+            }
+        }
+        for (; k0 < kper; k0 += 16) {
+            const float4 w1 = *reinterpret_cast<const float4*>(wp + k0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const float4 x1 = *reinterpret_cast<const float4*>(xp[rb] + k0);
+                acc0[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, w1.x, acc0[rb], 0, 0, 0);
+                acc1[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, w1.y, acc1[rb], 0, 0, 0);
+                acc0[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, w1.z, acc0[rb], 0, 0, 0);
+                acc1[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, w1.w, acc1[rb], 0, 0, 0);
+                if (p.ln_s) ln_accum(x1, sx[rb], sxx[rb]);
+            }
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const f32x4 acc = acc0[rb] + acc1[rb];
+        if (p.ln_s) {
+            float a = sx[rb], b = sxx[rb];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (g == 0) { stat[((rb * 8 + wave) * 16 + li) * 2] = a; stat[((rb * 8 + wave) * 16 + li) * 2 + 1] = b; }
+        }
+        *reinterpret_cast<f32x4*>(red + ((rb * 8 + wave) * 64 + lane) * 4) = acc;
+    }
+    __syncthreads();
+    if (p.ln_s && tid < 16 * RB) {
+        const int rb = tid >> 4, r = tid & 15;
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < 8; ++w) { a += stat[((rb * 8 + w) * 16 + r) * 2]; b += stat[((rb * 8 + w) * 16 + r) * 2 + 1]; }
+        const float mean = a / p.K;
+        const float var = fmaxf(b / p.K - mean * mean, 0.f);
+        fin[tid * 2] = mean;
+        fin[tid * 2 + 1] = rsqrtf(var + p.ln_eps);
+    }
+    __syncthreads();
+    if (wave >= RB) return;  // wave rb finishes row block rb
+    const int rb = wave;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(red + ((rb * 8) * 64 + lane) * 4);
+#pragma unroll
+    for (int s2 = 1; s2 < 8; ++s2) acc += *reinterpret_cast<const f32x4*>(red + ((rb * 8 + s2) * 64 + lane) * 4);
+    const int col = ncol0 + li;
+    if (col >= p.N) return;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+    const float sn = p.ln_s ? p.ln_s[col] : 0.f;
+    int pos0 = p.pos0;
+    if (p.kcache && p.pos_dev) pos0 += *p.pos_dev;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 16 * rb + 4 * g + r;
+        if (row >= p.M) continue;
+        float v = acc[r];
+        if (p.ln_s) v = fin[(rb * 16 + 4 * g + r) * 2 + 1] * (v - fin[(rb * 16 + 4 * g + r) * 2] * sn);
+        v += bv;
+        if (p.epi == 1) v = gelu_erf(v);
+        if (p.epi == 2) v += p.res[(long)row * p.ldy + col];
+        if (p.kcache && col >= p.C) {
+            const int cc = col - p.C;
+            float* cache = cc >= p.C ? p.vcache : p.kcache;
+            const int c2 = cc >= p.C ? cc - p.C : cc;
+            const int h = c2 / p.D, d = c2 - h * p.D;
+            const int b = row / p.Tq, t = row - b * p.Tq;
+            if (pos0 + t < p.Tmax) cache[(((long)b * p.H + h) * p.Tmax + pos0 + t) * p.D + d] = v;
+        } else {
+            p.y[(long)row * p.ldy + col] = v;
+        }
+    }
+}
+
 // K slices across workgroups (split-K): spreads GEMMs with few output columns over the chip.  Pays only for deep K:
 // the release/acquire hand-off costs ~3-4 us (measured).
+static int getenv_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 static int gemm_kz(const Gemm16& g) {
     static int kz_max = -1;
     if (kz_max < 0) { const char* e = getenv("CCVS_GEMM_KZ_MAX"); kz_max = e ? atoi(e) : 4; }
@@ -269,7 +388,12 @@ static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
     g.kz = gemm_kz(g);
     g.ks = 8;
     while (g.ks > 1 && g.K % (16 * g.ks * g.kz) != 0) g.ks >>= 1;
-    hipLaunchKernelGGL(gemm16_kernel, dim3(cdiv(g.N, 16), cdiv(g.M, 16), g.kz), dim3(512), 0, st, g);
+    static const int rb_max = getenv_int("CCVS_GEMM_RB", 4);
+    // row-blocked only from 128 rows up (prefill): at M = 64 it is slower for deep K (64 workgroups walk K = 4096 alone)
+    if (g.kz == 1 && g.M >= 128 && rb_max >= 4)
+        hipLaunchKernelGGL((gemm16_rb_kernel<4>), dim3(cdiv(g.N, 16), cdiv(g.M, 64), 1), dim3(512), 0, st, g);
+    else
+        hipLaunchKernelGGL(gemm16_kernel, dim3(cdiv(g.N, 16), cdiv(g.M, 16), g.kz), dim3(512), 0, st, g);
     CCVS_CHECK_LAUNCH(name);
     return CCVS_OK;
 }

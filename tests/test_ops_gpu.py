@@ -489,3 +489,25 @@ def test_conv_packed_activation_chain(ops):
             assert b[i].shape == tuple(a[i].shape)
             assert (b[i].float() - a[i]).abs().max().item() <= 2e-5 * a[i].abs().max().item() + 1e-6
         assert torch.equal(a[-1], b[-1])
+
+
+def test_gemm_row_blocked_matches_plain(ops):
+    """M >= 128 runs the row-blocked GEMM kernel (weight tile fetched once per 64 rows): every 16-row slice equals the
+    plain M = 16 launch bit for bit, with and without the folded LayerNorm, GELU / residual epilogues and ragged M, N."""
+    torch.manual_seed(9)
+    for m, n, k in ((128, 320, 256), (150, 200, 128), (260, 1024, 512), (64, 48, 64)):
+        x = torch.randn(m, k).cuda()
+        w = (torch.randn(n, k) * 0.05).cuda()
+        b = torch.randn(n).cuda()
+        res = torch.randn(m, n).cuda()
+        gam, bet = (1 + 0.1 * torch.randn(k)).cuda(), (0.1 * torch.randn(k)).cuda()
+        packed = ops.pack_ln_linear(w, b, gam, bet)
+        full = [ops.gemm_nt(x, w, b), ops.gemm_nt(x, w, b, ops.EPI_RESIDUAL, residual=res), ops.gemm_ln(x, *packed, epilogue=ops.EPI_GELU)]
+        for r0 in range(0, m, 16):
+            xs = x[r0:r0 + 16].contiguous()
+            part = [ops.gemm_nt(xs, w, b), ops.gemm_nt(xs, w, b, ops.EPI_RESIDUAL, residual=res[r0:r0 + 16].contiguous()),
+                    ops.gemm_ln(xs, *packed, epilogue=ops.EPI_GELU)]
+            for f, q in zip(full, part):
+                assert torch.equal(f[r0:r0 + 16], q)
+        want = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x, (k,), gam, bet) @ w.t() + b)
+        close(full[2], want, 5e-4)
