@@ -84,9 +84,11 @@ def cpu_baseline(gen, opt):
         t_enc = time.perf_counter() - t0
         z = enc["z"]
         ctx = [f for f in enc["inter"]]
-        t0 = time.perf_counter()
-        O.decoder_forward(nets["g"], qopt, z, [ctx])
-        t_dec1 = time.perf_counter() - t0
+        t_dec1 = float("inf")
+        for _ in range(2):  # the first decoder call also pays one-time allocator / thread-pool costs: keep the faster of two
+            t0 = time.perf_counter()
+            O.decoder_forward(nets["g"], qopt, z, [ctx])
+            t_dec1 = min(t_dec1, time.perf_counter() - t0)
         t0 = time.perf_counter()
         O.decoder_forward(nets["g"], qopt, z, [ctx, ctx, ctx])
         t_dec3 = time.perf_counter() - t0
