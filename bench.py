@@ -214,7 +214,7 @@ def main():
                              "clock_note": "GRBM cycles / time = 2.0 GHz under this kernel (power-limited), i.e. a 2083 TF/s bf16 ceiling",
                              "share_of_step_time": conv_ms * 1e-3 / elapsed},
             }
-            if not args.no_cpu_baseline and args.config == "bair":
+            if not args.no_cpu_baseline and args.config == "bair" and world == 1:   # rank 0 at N = 1 only
                 line["cpu_baseline"] = cpu_baseline(gen, opt)
             print(json.dumps(line))
 
