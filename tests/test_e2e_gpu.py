@@ -386,3 +386,28 @@ def test_audio_conditioned_generator_vs_oracle(tiny, state_stream):
     _audit_tokens(out["fake"]["code"], want["code"], lambda b, t: trace[t - 64][b])
     if torch.equal(out["fake"]["code"].cpu(), want["code"]):
         assert maxdiff(out["fake"]["vid"], want["vid"]) < PIX_TOL
+
+
+def test_bair_scale_batch_invariance():
+    """BAIR-size networks, greedy sampling: a clip generated inside a ragged batch of 5 equals the same clip generated alone,
+    bit for bit -- GEMM row tails, attention grids, conv batch strides and the context lists at full channel counts."""
+    from ccvs_amd.tools.options import Options, BAIR_ARGV
+    from ccvs_amd.helpers.generator import Generator
+    opt = Options().parse(load_qvid_generator=True, load_transformer=True, argv=list(BAIR_ARGV) + ["--batch_size_vid", "5"])
+    xopt, qopt = opt["transformer"], opt["qvid_generator"]
+    xopt.vid_len = qopt.vid_len = 3
+    xopt.sample = False
+    torch.manual_seed(0)
+    gen = Generator(opt).build_models()
+    with torch.no_grad():
+        t = gen.transformer_model.net_t
+        t.s_emb.normal_(0, 0.02)
+        t.t_emb.normal_(0, 0.02)
+        vid = gen.synthetic_batch(5, seed=3)["vid"][:, :3].cuda()
+        z_e, _ = gen.vid_model.net_e(vid[:2, :1])
+        cb = gen.vid_model.net_q.embedding.weight
+        cb.copy_(torch.randn_like(cb) * float(z_e.std()))
+        full = gen.generate_vid({"vid": vid.clone()})
+        one = gen.generate_vid({"vid": vid[3:4].clone()})
+    assert torch.equal(one["fake"]["code"][0], full["fake"]["code"][3])
+    assert torch.equal(one["fake"]["vid"][0], full["fake"]["vid"][3])

@@ -29,7 +29,7 @@ def main():
     torch.manual_seed(0)
     n, c, h = 120, 96, 256
     x = torch.randn(n, c, h, h, device="cuda")
-    flow = torch.randn(n, 2, h, h, device="cuda") * 0.1
+    flow = torch.randn(n, 2, h, h, device="cuda") * float(os.environ.get("FLOW_SCALE", "0.1"))
     occ = torch.randn(n, 1, h, h, device="cuda")
     out = torch.empty_like(x)
     row("backwarp 120x96x256^2", timeit(lambda: ops.backwarp(x, flow, 32.0, out=out)), 2 * x.numel() * 4)
