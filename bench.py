@@ -10,6 +10,7 @@ Weights are random-init (the reference's initialisers), frames are seeded synthe
 Rank 0 prints ONE JSON line; see DESIGN.md section "Measurement" for every field.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -45,7 +46,8 @@ def build_generator(args):
     argv += ["--batch_size_vid", str(args.batch), "--x_sample_noise", args.sample_noise]
     opt = Options().parse(load_qvid_generator=True, load_transformer=True, argv=argv)
     torch.manual_seed(0)  # reference initialisers under seed 0
-    gen = Generator(opt).build_models()
+    with contextlib.redirect_stdout(sys.stderr):   # "Loading untrained ... net": stdout carries the ONE JSON line only
+        gen = Generator(opt).build_models()
     return gen, opt
 
 
