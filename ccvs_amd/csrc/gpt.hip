@@ -703,8 +703,9 @@ struct Advance {       // decode-step bookkeeping folded into the sampling kerne
     long codes_sB;
     int32_t* widx;     // device-resident write index, +1 per step
     int32_t* len;      // device-resident cache length, +1 per step
-    int rng;           // draw the Exp(1) noise here: Philox keyed by state[4..5], counter (element, row, step = state[0])
-    int* state;        // int32[8]: [0] completed steps, [2] arrival ticket of this kernel's rows, [4..5] Philox key
+    int rng;           // draw the Exp(1) noise here: Philox keyed by state[4..5], counter (element, state[6] + row, step = state[0], call = state[3])
+    unsigned imm[5];   // rng == 2: immediate Philox words (key0, key1, global row of row 0, step, call) instead of `state`
+    int* state;        // int32[8]: [0] completed steps, [2] arrival ticket of this kernel's rows, [3] call index, [4..5] Philox key, [6] global index of row 0
 };
 
 // k-th largest key of xs[0..V) by a 4-pass radix-256 descent (LDS histogram + suffix scan per pass).
@@ -777,15 +778,22 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
     if (lane == 0) redf[wave] = lsum;
     __syncthreads();
     const float tot = ((redf[0] + redf[1]) + redf[2]) + redf[3];
-    unsigned k0 = 0u, k1 = 0u, step = 0u;
-    if (adv.rng) { k0 = (unsigned)adv.state[4]; k1 = (unsigned)adv.state[5]; step = (unsigned)adv.state[0]; }
+    // counter = (element, GLOBAL row = state[6] + b, step, call = state[3]): a clip's draws do not depend on which rank /
+    // batch slot it runs in, nor on how many other clips share the launch
+    unsigned k0 = 0u, k1 = 0u, step = 0u, row0 = 0u, call = 0u;
+    if (adv.rng == 2) {
+        k0 = adv.imm[0]; k1 = adv.imm[1]; row0 = adv.imm[2]; step = adv.imm[3]; call = adv.imm[4];
+    } else if (adv.rng) {
+        k0 = (unsigned)adv.state[4]; k1 = (unsigned)adv.state[5]; step = (unsigned)adv.state[0];
+        call = (unsigned)adv.state[3]; row0 = (unsigned)adv.state[6];
+    }
     float best = -1.f;
     int bi = 0x7fffffff;
     for (int j = tid; j < V; j += 256) {
         float p = xs[j] / tot;
         if (noise) p = p / noise[(long)b * V + j];
         else if (adv.rng) {
-            const float u = ((float)philox_first((unsigned)j, (unsigned)b, step, 0u, k0, k1) + 0.5f) * 2.3283064365386963e-10f;  // (0, 1]
+            const float u = ((float)philox_first((unsigned)j, row0 + (unsigned)b, step, call, k0, k1) + 0.5f) * 2.3283064365386963e-10f;  // (0, 1]
             p = p / fmaxf(-logf(u), 1e-30f);
         }
         if (p > best) { best = p; bi = j; }
@@ -836,6 +844,27 @@ extern "C" int ccvs_sample_topk(const float* logits, int64_t ld, const float* no
     hipLaunchKernelGGL(sample_topk_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, logits, (long)ld, noise, out, (long)out_stride, V,
                        top_k, temperature, Advance{});
     CCVS_CHECK_LAUNCH("ccvs_sample_topk");
+    return CCVS_OK;
+}
+
+extern "C" int ccvs_sample_topk_philox(const float* logits, int64_t ld, int64_t* out, int64_t out_stride, int32_t B, int32_t V, int32_t top_k,
+                                       float temperature, uint32_t key0, uint32_t key1, uint32_t row0, uint32_t step, uint32_t call,
+                                       void* stream) {
+    CCVS_REQUIRE(logits && out, "ccvs_sample_topk_philox: null pointer");
+    CCVS_REQUIRE(B > 0 && V > 0 && temperature > 0.f, "ccvs_sample_topk_philox: bad arguments");
+    const size_t smem = (size_t)PICK_SMEM_WORDS(V) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)sample_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    CCVS_REQUIRE(smem <= 160 * 1024, "ccvs_sample_topk_philox: vocabulary %d too large", V);
+    Advance adv = {};
+    adv.rng = 2;
+    adv.imm[0] = key0; adv.imm[1] = key1; adv.imm[2] = row0; adv.imm[3] = step; adv.imm[4] = call;
+    hipLaunchKernelGGL(sample_topk_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, logits, (long)ld, (const float*)nullptr, out,
+                       (long)out_stride, V, top_k, temperature, adv);
+    CCVS_CHECK_LAUNCH("ccvs_sample_topk_philox");
     return CCVS_OK;
 }
 
@@ -910,7 +939,9 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream) {
         if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(head)")) != CCVS_OK) return rc;
     }
     {   // pick + bookkeeping
-        Advance adv = {d->codes, (long)d->codes_sB, d->widx, d->len, (d->rng && !d->noise) ? 1 : 0, d->state};
+        Advance adv = {};
+        adv.codes = d->codes; adv.codes_sB = (long)d->codes_sB; adv.widx = d->widx; adv.len = d->len;
+        adv.rng = (d->rng && !d->noise) ? 1 : 0; adv.state = d->state;
         hipLaunchKernelGGL(sample_topk_kernel, dim3(d->B), dim3(256), smem_pick, st, d->logits, (long)d->V, d->noise, d->tok, 1L, d->V,
                            d->top_k, d->temperature, adv);
         CCVS_CHECK_LAUNCH("ccvs_gpt_decode_step(pick)");

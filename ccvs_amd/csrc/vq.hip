@@ -83,13 +83,39 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
     }
 }
 
+// e_dim = 1 (the state quantiser, VectorQuantizer(state_num, 1), state_model.py:55): one scalar per row, so the
+// reference's  sum(z^2) + sum(e^2) - 2 * (z @ e^T)  is  (z*z + e*e) - 2*(z*e)  with every operation rounded once
+// (clang's fp contraction off so no fma changes a rounding).  One thread per row walks the codes in index order.
+__global__ __launch_bounds__(256) void vq_argmin_scalar_kernel(const float* __restrict__ z, const float* __restrict__ cbt,
+                                                               const float* __restrict__ e_sq, int64_t* __restrict__ idx, long rows,
+                                                               int n_e) {
+#pragma clang fp contract(off)
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float v = z[r];
+    const float zz = v * v;
+    float best_d = INFINITY;
+    int best_i = 0;
+    for (int j = 0; j < n_e; ++j) {
+        const float d = (zz + e_sq[j]) - 2.f * (v * cbt[j]);
+        if (d < best_d) { best_d = d; best_i = j; }
+    }
+    idx[r] = (int64_t)best_i;
+}
+
 extern "C" int ccvs_vq_argmin(const float* z, const float* codebook_t, const float* e_sq, int64_t* idx, int32_t N, int32_t C, int32_t HW,
                               int32_t n_e, void* stream) {
     CCVS_REQUIRE(z && codebook_t && e_sq && idx, "ccvs_vq_argmin: null pointer");
     CCVS_REQUIRE(N > 0 && C > 0 && HW > 0 && n_e > 0, "ccvs_vq_argmin: empty tensor");
-    CCVS_REQUIRE(n_e % 32 == 0, "ccvs_vq_argmin: n_e=%d must be a multiple of 32", n_e);
-    CCVS_REQUIRE(C % 2 == 0 && C <= 1024, "ccvs_vq_argmin: C=%d must be even and <= 1024", C);
     const long rows = (long)N * HW;
+    if (C == 1) {
+        hipLaunchKernelGGL(vq_argmin_scalar_kernel, dim3((unsigned)cdiv64(rows, 256)), dim3(256), 0, (hipStream_t)stream, z, codebook_t, e_sq,
+                           idx, rows, n_e);
+        CCVS_CHECK_LAUNCH("ccvs_vq_argmin");
+        return CCVS_OK;
+    }
+    CCVS_REQUIRE(n_e % 32 == 0, "ccvs_vq_argmin: n_e=%d must be a multiple of 32", n_e);
+    CCVS_REQUIRE(C % 2 == 0 && C <= 1024, "ccvs_vq_argmin: C=%d must be 1 or even and <= 1024", C);
     const size_t smem = (size_t)(C * 32 + 32 + 128 + 128) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

@@ -20,11 +20,11 @@ from itertools import cycle
 import torch
 import torch.nn.functional as F
 
-from ..tools.options import Options
-from ..tools.engine import Engine
-from ..models.skip_vid_generator.models.quantized_video_model import QVidModel
-from ..models.skip_vid_generator.models.transformer_model import Transformer
-from .. import ops
+from ccvs_amd.tools.options import Options
+from ccvs_amd.tools.engine import Engine
+from ccvs_amd.models.skip_vid_generator.models.quantized_video_model import QVidModel
+from ccvs_amd.models.skip_vid_generator.models.transformer_model import Transformer
+from ccvs_amd import ops
 
 
 class Generator:
@@ -39,17 +39,21 @@ class Generator:
         self.transformer_model = None
         self.timings = {}
         self.stft_model = None
-        for flag in ("state", "layout", "deblurring", "cat", "custom_state"):
+        self.state_model = None
+        for flag in ("layout", "deblurring", "cat"):
             if getattr(self.opt, flag, False):
-                raise NotImplementedError(f"--{flag} is not on the MI355X path (SURVEY 8f); --stft [--keep_state] is")
+                raise NotImplementedError(f"--{flag} is not on the MI355X path (SURVEY 8f); --x_state / --x_stft [--keep_state] are")
 
     # ------------------------------------------------------------------ models / data
     def build_models(self, is_main=True):
         self.vid_model = QVidModel(self.qvid_opt, is_train=False, is_main=is_main, logger=None).eval()
         if not self.opt.rec_only:
             self.transformer_model = Transformer(self.opt, is_train=False, is_main=is_main, logger=None).eval()
+        if self.opt.state:  # generator.py:266-269
+            from ccvs_amd.models.skip_vid_generator.models.state_model import StateModel
+            self.state_model = StateModel(self.state_opt, is_train=False, is_main=is_main, logger=None).eval()
         if self.opt.stft:  # generator.py:271-274
-            from ..models.skip_vid_generator.models.stft_model import StftModel
+            from ccvs_amd.models.skip_vid_generator.models.stft_model import StftModel
             self.stft_model = StftModel(self.stft_ae_opt, is_train=False, is_main=is_main, logger=None).eval()
         return self
 
@@ -84,9 +88,27 @@ class Generator:
         return next(data_info["loader_iter"])
 
     # ------------------------------------------------------------------ the hot path
+    def noise_key(self, global_iter):
+        """Philox key of the in-kernel sampling noise for batch `global_iter`: splitmix64 of (seed, iteration), the same
+        on every rank.  With the rank's first global clip index as row offset (`first_clip`), a clip's token stream
+        depends on (seed, iteration, global clip index) only -- not on the world size."""
+        z = (int(getattr(self.opt, "seed", 0)) * 0x9E3779B97F4A7C15 + int(global_iter) + 0x632BE59BD9B4E019) & (2**64 - 1)
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+        z ^= z >> 31
+        return z & 0xffffffff, z >> 32
+
+    def first_clip(self, batch):
+        """Global index of this rank's clip 0 when every rank holds `batch` clips."""
+        return self.engine.rank * batch if self.engine is not None else 0
+
     @torch.no_grad()
     def generate_vid(self, data, global_iter=0, save=False):
         opt, qopt = self.opt, self.qvid_opt
+        if self.transformer_model is not None:
+            net_t = self.transformer_model.net_t
+            net_t.noise_key, net_t.noise_call = self.noise_key(global_iter), 0
+            net_t.row_offset = self.first_clip(data["vid"].shape[0])
         if opt.down_size is not None:  # generator.py:60-66
             vid = data["vid"].cuda()
             bs, t = vid.shape[:2]
@@ -100,8 +122,11 @@ class Generator:
         encoded_data = self.vid_model(data, mode='vid_encoder')            # encode all frames
         ev[1].record()
 
-        if getattr(opt, "state", False) or getattr(opt, "layout", False) or getattr(opt, "deblurring", False):
-            raise NotImplementedError("state estimator / layout / deblurring conditioning is not on the MI355X path (SURVEY 8f)")
+        if getattr(opt, "layout", False) or getattr(opt, "deblurring", False):
+            raise NotImplementedError("layout / deblurring conditioning is not on the MI355X path (SURVEY 8f)")
+        if opt.state:                                                       # generator.py:73-77: estimate + quantise the state
+            encoded_data.update(self.state_model(encoded_data, mode='vid_encoder'))
+            data.update(self.state_model(encoded_data, mode='vid_decoder'))
         if opt.stft:                                                        # generator.py:78-80
             encoded_data.update(self.stft_model(data, mode='vid_encoder'))
 
@@ -109,7 +134,7 @@ class Generator:
         cond_step, t_step = (1, opt.vid_len - 1) if opt.p2p else (0, opt.vid_len)
         total_len = (cond_step + t_step) * size
         cond_len = cond_step * size
-        if opt.stft:                                                        # generator.py:91-92
+        if opt.state or opt.stft:                                           # generator.py:91-92
             total_len += t_step * opt.state_size
         if opt.gen_from_img:
             crop_prop = opt.cond_len / size
@@ -126,9 +151,13 @@ class Generator:
             cropped["cond_inter"] = [feat[:, -1:].contiguous() for feat in encoded_data["inter"]]
             cropped["delta_length_cond"] = torch.tensor([opt.vid_len - 1]).repeat(cropped["code"].size(0))
 
-        if opt.stft:                                                        # generator.py:107-117
+        if opt.state or opt.stft:                                           # generator.py:107-117
             if opt.keep_state:
                 cropped["state_code"] = encoded_data["state_code"]
+            elif opt.custom_state:
+                init_state = self.state_model(encoded_data, mode='vid_decoder')["state"][:, [0]]
+                custom_state = square_trajectory(init_state, opt.vid_len)
+                cropped["state_code"] = self.state_model(custom_state, mode='vid_encoder')["state_code"]
             else:
                 cropped["state_code"] = encoded_data["state_code"][:, :int(crop_prop * encoded_data["state_code"].size(1))]
 
@@ -146,23 +175,31 @@ class Generator:
                 fake_data["state_code"] = fake_encoded.get("state_code")
             if opt.p2p:
                 fake_data["vid"] = torch.cat([fake_data["vid"], data["vid"][:, -1:]], dim=1)
+            if opt.state and fake_data.get("state_code") is not None:      # generator.py:168-169
+                fake_data.update(self.state_model({"state_code": fake_data["state_code"]}, mode='vid_decoder'))
         else:
             ev[2].record()
         ev[3].record()
 
-        if not opt.gen_from_img and getattr(opt, "rec_pass", False):   # teacher-forced "rec" decode (generator.py:172-189)
+        if not opt.gen_from_img and (getattr(opt, "rec_pass", True) or opt.rec_only):   # teacher-forced "rec" decode (generator.py:172-189)
             rec = {"inter": cropped["inter"]}
             if opt.p2p:
                 rec["code"] = encoded_data["code"][:, :-opt.z_chunk].contiguous()
+                rec["cond_code"] = cropped["cond_code"]
                 rec["cond_inter"] = cropped["cond_inter"]
             else:
                 rec["code"] = encoded_data["code"]
+            if opt.state or opt.stft:
+                rec["state_code"] = encoded_data["state_code"]
             rec_data = self.vid_model(rec, mode='vid_decoder')
             if opt.p2p:
                 rec_data["vid"] = torch.cat([rec_data["vid"], data["vid"][:, -1:]], dim=1)
+            if opt.state:
+                rec_data["state"] = data["state"]
 
         self._events = ev
-        out = {"real": data["vid"], "fake": fake_data, "rec": rec_data, "enc_code": encoded_data["code"]}
+        out = {"real": data["vid"], "fake": fake_data, "rec": rec_data, "enc_code": encoded_data["code"],
+               "real_state": data.get("state") if opt.state else None}
         if save:
             self.save_results(out, global_iter)
         return out
@@ -212,6 +249,10 @@ class Generator:
             vid = item["vid"] if isinstance(item, dict) else item
             save_video_batch(vid, bs, global_iter, os.path.join(self.opt.result_path, name), self.opt.fps, True,
                              self.opt.imagenet_norm, [-1, 1], self.opt.dataset)
+            state = out.get("real_state") if name == "real" else (item.get("state") if isinstance(item, dict) else None)
+            if self.opt.state and state is not None:                        # generator.py:213-223: clips with the state marker
+                save_video_batch(vid, bs, global_iter, os.path.join(self.opt.result_path, name + "_state"), self.opt.fps, True,
+                                 self.opt.imagenet_norm, [-1, 1], self.opt.dataset, state=state)
 
     def run(self):
         with Engine(self.opt) as engine:
@@ -235,8 +276,8 @@ def save_video_batch(vid, bs, global_iter, path, fps, normalize, imagenet_norm, 
                      is_layout=False):
     """helpers/generator.py:285-333.  The clamp / rescale / uint8 / channels-last pack runs on the
     GPU; files are written as mp4 when torchvision is importable, else as .npy uint8 [T,H,W,3]."""
-    if is_layout or state is not None:
-        raise NotImplementedError("layout / state overlays are not on the MI355X path yet (SURVEY 8f)")
+    if is_layout:
+        raise NotImplementedError("layout colour maps are not on the MI355X path (SURVEY 8f)")
     if normalize and imagenet_norm:
         mean = torch.tensor([0.485, 0.456, 0.406], device=vid.device).view(1, 1, 3, 1, 1)
         std = torch.tensor([0.229, 0.224, 0.225], device=vid.device).view(1, 1, 3, 1, 1)
@@ -246,6 +287,14 @@ def save_video_batch(vid, bs, global_iter, path, fps, normalize, imagenet_norm, 
     else:
         u8 = (vid.permute(0, 1, 3, 4, 2) * 255).to(torch.uint8)
     u8 = u8.cpu()
+    if state is not None:  # generator.py:311-323: mark the (x, y) state on every frame
+        res = {"bair": 64, "bairhd": 256}.get(dataset)
+        if res is not None:
+            st = state.detach().cpu()
+            for i in range(u8.size(0)):
+                for j in range(u8.size(1)):
+                    x, y = st[i, j]
+                    u8[i, j] = draw_cross(u8[i, j], min(int(res * x), res - 1), min(int(res * y), res - 1))
     os.makedirs(path, exist_ok=True)
     try:
         from torchvision.io import write_video

@@ -15,7 +15,7 @@ with the residual add in its epilogue, LayerNorm, MLP GEMMs with GELU / residual
 import torch
 import torch.nn as nn
 
-from .... import ops
+from ccvs_amd import ops
 
 
 class GPTConfig:
@@ -143,6 +143,30 @@ class GPT(nn.Module):
         self.config = config
         self._cache = None
         self._graphs = {}
+        # in-kernel sampling noise (Philox): key words, global index of batch row 0 and a per-call counter.  `noise_key`
+        # None draws a fresh key from torch's generator per call (honours torch.manual_seed); the Generator sets a key
+        # derived from (seed, iteration) plus the rank's first clip, so sampled tokens do not depend on the world size.
+        self.noise_key = None
+        self.row_offset = 0
+        self.noise_call = 0
+
+    def _philox_words(self):
+        """(key0, key1, row0, call) of this generate() call."""
+        if self.noise_key is None:
+            k = torch.randint(0, 2**32, (2,), dtype=torch.int64).tolist()
+            return int(k[0]), int(k[1]), int(self.row_offset), 0
+        call = self.noise_call
+        self.noise_call += 1
+        return int(self.noise_key[0]) & 0xffffffff, int(self.noise_key[1]) & 0xffffffff, int(self.row_offset), call
+
+    def _set_decode_state(self, words):
+        """Device-resident `state` of ccvs_gpt_decode: counters zeroed, Philox words in place (one upload)."""
+        st = torch.zeros(8, dtype=torch.int64)
+        if words is not None:
+            k0, k1, row0, call = words
+            st[3], st[4], st[5], st[6] = call, k0, k1, row0
+        st = torch.where(st >= 2**31, st - 2**32, st).to(torch.int32)
+        self._cache["state"].copy_(st, non_blocking=True)
 
     def get_block_size(self):
         return self.block_size
@@ -409,12 +433,13 @@ class GPT(nn.Module):
                 noise=c["noise"] if (sampler["sample"] and not device_rng) else None, rng=device_rng,
                 top_k=sampler["top_k"], temperature=sampler["temperature"], state=c["state"])
             c["desc"] = (key, desc)
+            self._graphs = {}   # captured graphs replay the OLD descriptor's pointers (packed weights are freed with it)
         return c["desc"][1]
 
-    def _emit(self, logits, sampler, noise, col):
+    def _emit(self, logits, sampler, noise, col, philox=None):
         """Pick the next token from `logits` into c['tok'] and store it in column `col` of c['codes']."""
         c = self._cache
-        ops.sample_topk(logits, sampler["top_k"], sampler["temperature"], noise=noise, out=c["tok"])
+        ops.sample_topk(logits, sampler["top_k"], sampler["temperature"], noise=noise, out=c["tok"], philox=philox)
         c["codes"][:, col] = c["tok"][:, 0]
         c["widx"].fill_(col + 1)
 
@@ -434,6 +459,7 @@ class GPT(nn.Module):
         """The decode step of the current cache captured in a hipGraph (once per key).  Captured on live state: a warm-up
         step runs first (one-time attribute calls, descriptor), then the device-resident state is put back."""
         c = self._cache
+        self._decode_desc(sampler)   # a changed weight version / sampler rebuilds the descriptor and drops the graphs built on the old one
         graph = self._graphs.get(key)
         if graph is None:
             state = {k: c[k].clone() for k in ("len_dev", "widx", "tok", "codes", "state")}
@@ -498,22 +524,23 @@ class GPT(nn.Module):
         n_code, n_state = t0, ns0
         device_noise = sampler["sample"] and sampler["noise"] == "device"
         eager = trace is not None or (sampler["sample"] and not device_noise) or not use_graph
-        c["state"].zero_()
-        if device_noise:
-            c["state"][4:6] = torch.randint(-2**31, 2**31 - 1, (2,), dtype=torch.int64).to(torch.int32).to(dev)
+        words = self._philox_words() if device_noise else None
+        self._set_decode_state(words)
 
         def rows_of(lo, hi):  # merged-sequence rows [lo, hi) from the current buffers
             kinds = self.stream_kinds(n_code, n_state)[lo:hi]
             cols = [frame_codes[:, i:i + 1] if k == 0 else state_buf[:, i:i + 1] + cfg.vocab_size for k, i in kinds]
             return torch.cat(cols, dim=1)
 
-        def draw(kind, width):
+        def draw(kind, width, pick):
+            """(noise, philox) of eager pick number `pick`: in-kernel Philox with the call word's top bit set (the captured
+            steps use the plain call word and their own step counter), or host noise."""
             smp = state_sampler if kind else sampler
             if not smp["sample"]:
-                return None
-            if smp.get("noise", sampler["noise"]) == "device" and device_noise:
-                return torch.empty(b, width, dtype=torch.float32, device=dev).exponential_(1)
-            return host_noise(b, width).to(dev, non_blocking=True)
+                return None, None
+            if device_noise:
+                return None, (words[0], words[1], words[2], pick, words[3] | 0x80000000)
+            return host_noise(b, width).to(dev, non_blocking=True), None
 
         logits = self.prefill(self._stream_rows(code, state_code), cond_idx, delta_length_cond)
         fed = slen(n_code, n_state)
@@ -542,13 +569,15 @@ class GPT(nn.Module):
                 lg = logits[:, :state_sampler["vocab"]].contiguous()
                 if trace is not None:
                     trace.append(lg.clone())
-                tok = ops.sample_topk(lg, state_sampler["top_k"], state_sampler["temperature"], noise=draw(1, lg.shape[1]))
+                nz, ph = draw(1, lg.shape[1], i)
+                tok = ops.sample_topk(lg, state_sampler["top_k"], state_sampler["temperature"], noise=nz, philox=ph)
                 state_buf[:, n_state] = tok
                 n_state += 1
             else:
                 if trace is not None:
                     trace.append(logits.clone())
-                ops.sample_topk(logits, sampler["top_k"], sampler["temperature"], noise=draw(0, logits.shape[1]), out=c["tok"])
+                nz, ph = draw(0, logits.shape[1], i)
+                ops.sample_topk(logits, sampler["top_k"], sampler["temperature"], noise=nz, out=c["tok"], philox=ph)
                 frame_codes[:, n_code] = c["tok"][:, 0]
                 n_code += 1
             i += 1
@@ -580,22 +609,18 @@ class GPT(nn.Module):
         max_len = n_cond + t0 + add_len
         c = self.begin(b, max_len)
 
-        def draw(logits):
-            if not sample:
-                return None
-            if noise == "device":
-                return torch.empty_like(logits).exponential_(1)
-            return host_noise(b, logits.shape[1]).to(logits.device, non_blocking=True)
-
+        device_rng = sample and noise == "device"
+        words = self._philox_words() if device_rng else None
         logits = self.prefill(code, cond_idx if use_cond else None, delta_length_cond if use_cond else None)
         if trace is not None:
             trace.append(logits.clone())
         c["codes"][:, :t0] = code
         c["len_dev"].fill_(n_cond + t0)
-        c["state"].zero_()                # the step counter (= Philox counter word) restarts with the call
-        if sample and noise == "device":  # key of the in-kernel Philox draws, from torch's generator (honours torch.manual_seed)
-            c["state"][4:6] = torch.randint(-2**31, 2**31 - 1, (2,), dtype=torch.int64).to(torch.int32).to(c["state"].device)
-        self._emit(logits, sampler, draw(logits), t0)
+        self._set_decode_state(words)     # the step counter (a Philox counter word) restarts with the call
+        if device_rng:                    # first pick: step word 0xffffffff (the decode steps count 0, 1, ...)
+            self._emit(logits, sampler, None, t0, philox=(words[0], words[1], words[2], 0xffffffff, words[3]))
+        else:
+            self._emit(logits, sampler, host_noise(b, logits.shape[1]).to(logits.device, non_blocking=True) if sample else None, t0)
 
         graph = None if eager else self._decode_graph(sampler, (bool(sample), top_k, float(temperature), n_cond, b))
         for _ in range(add_len - 1):

@@ -17,8 +17,8 @@ import torch
 
 from .skip_autoencoder import SkipGANDecoder, SkipGANEncoder
 from ..modules.quantize import VectorQuantizer
-from ....tools.utils import to_cuda
-from ... import load_network, print_network
+from ccvs_amd.tools.utils import to_cuda
+from ccvs_amd.models import load_network, print_network
 
 _TRAIN_MODES = ("img_to_img_generator", "eval_img_to_img_generator", "vid_to_vid_generator", "img_discriminator",
                 "img_discriminator_reg", "vid_discriminator_reg", "vid_discriminator")

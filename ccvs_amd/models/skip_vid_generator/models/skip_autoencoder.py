@@ -16,8 +16,8 @@ import math
 import torch
 from torch import nn
 
-from .... import ops
-from ....tools.utils import flatten_vid, unflatten_vid
+from ccvs_amd import ops
+from ccvs_amd.tools.utils import flatten_vid, unflatten_vid
 
 INV_SQRT2 = 1.0 / math.sqrt(2.0)
 
@@ -419,6 +419,66 @@ class SkipGANDecoder(nn.Module):
         if return_all:
             return out1, out2, inter_flows, inter_occs, [unflatten_vid(f, vid_size) for f in inter_dec]
         return out1, out2
+
+
+class EqualLinear(nn.Module):
+    """skip_autoencoder.py:478-507 (no activation): y = x @ (W * scale)^T + bias * lr_mul on the nn.Linear GEMM kernel."""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        if activation:
+            raise NotImplementedError("EqualLinear (HIP): fused_leaky_relu activation is not on the hot path")
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init)) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+        self._packed = None
+
+    def packed(self):
+        src = (self.weight,) + ((self.bias,) if self.bias is not None else ())
+        key = tuple((t.data_ptr(), t._version) for t in src) + (self.weight.device,)
+        if self._packed is None or self._packed[0] != key:
+            w = self.weight.detach() * self.scale
+            w = torch.nn.functional.pad(w, (0, (-w.shape[1]) % 16)).contiguous()   # the GEMM kernel walks K in steps of 16
+            b = (self.bias.detach() * self.lr_mul).contiguous() if self.bias is not None else None
+            self._packed = (key, w, b)
+        return self._packed[1], self._packed[2]
+
+    def forward(self, input):
+        w, b = self.packed()
+        x = input.reshape(-1, input.shape[-1])
+        x = torch.nn.functional.pad(x, (0, w.shape[1] - x.shape[1])).contiguous()
+        return ops.gemm_nt(x, w, b).view(*input.shape[:-1], w.shape[0])
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})"
+
+
+class StateEstimator(nn.Module):
+    """skip_autoencoder.py:510-528: quantised latent map [z_size, h, w] -> state in (0, 1)^state_size: blur + stride-2
+    3x3 ConvLayers down to 1 x 1, EqualLinear, sigmoid."""
+
+    def __init__(self, opt):
+        super().__init__()
+        convs = []
+        h, w = opt.z_shape
+        in_size = opt.z_size
+        while h > 1 and w > 1:
+            convs.append(ConvLayer(in_size, opt.state_hsize, 3, downsample=True))
+            h //= 2
+            w //= 2
+            in_size = opt.state_hsize
+        self.convs = nn.Sequential(*convs)
+        self.fc = EqualLinear(opt.state_hsize * h * w, opt.state_size)
+
+    @torch.no_grad()
+    def forward(self, input):
+        x, vid_size = flatten_vid(input)
+        for conv in self.convs:
+            x = conv(x.contiguous())
+        out = torch.sigmoid(self.fc(x.reshape(x.size(0), -1)))
+        return unflatten_vid(out, vid_size)
 
 
 class StftEncoder(nn.Module):

@@ -9,8 +9,8 @@ import torch
 
 from ..models.skip_autoencoder import StftEncoder
 from ..modules.quantize import VectorQuantizer
-from ....tools.utils import to_cuda
-from ... import load_network
+from ccvs_amd.tools.utils import to_cuda
+from ccvs_amd.models import load_network
 
 
 class StftModel(torch.nn.Module):

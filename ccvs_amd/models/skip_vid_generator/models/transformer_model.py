@@ -16,9 +16,9 @@ same CPU generator stream the reference's CPU path would consume and uploaded; w
 import torch
 
 from .mingpt import GPT
-from ....tools.utils import to_cuda
-from ... import load_network, print_network
-from .... import ops
+from ccvs_amd.tools.utils import to_cuda
+from ccvs_amd.models import load_network, print_network
+from ccvs_amd import ops
 
 
 class Transformer(torch.nn.Module):

@@ -1,6 +1,6 @@
 """`FunctionCorrelation(first, second, stride)` with the reference's signature
 (modules/correlation.py:405-406), forward only, on the HIP cost-volume kernel."""
-from .... import ops
+from ccvs_amd import ops
 
 
 def FunctionCorrelation(tenFirst, tenSecond, stride):

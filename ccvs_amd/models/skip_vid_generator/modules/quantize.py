@@ -3,7 +3,7 @@ only -- nearest-codebook indices, quantised features, `embed_code`."""
 import torch
 import torch.nn as nn
 
-from .... import ops
+from ccvs_amd import ops
 
 
 class VectorQuantizer(nn.Module):
@@ -33,27 +33,35 @@ class VectorQuantizer(nn.Module):
             self._packed = (key, cbt, esq)
         return self._packed[1], self._packed[2]
 
+    def _as_nchw(self, z):
+        """quantize.py:41-45: a [b, (t,) c, h, w] map is quantised per position; anything with fewer than 4 dims is a flat
+        list of e_dim-vectors (the state stream: [b, t, state_size] with e_dim = 1)."""
+        if z.ndim >= 4:
+            return z.reshape(-1, *z.shape[-3:])
+        return z.reshape(-1, self.e_dim, 1, 1)
+
     @torch.no_grad()
     def indices(self, z):
         """z [..., C, H, W] -> int64 [N*H*W] in (n, h, w) raster order (quantize.py:40-50)."""
-        z4 = z.reshape(-1, *z.shape[-3:])
         cbt, esq = self._tables()
-        return ops.vq_argmin(z4, cbt, esq)
+        return ops.vq_argmin(self._as_nchw(z), cbt, esq)
 
     @torch.no_grad()
     def forward(self, z):
         """Returns (z_q, None, (None, None, indices[N,1])) -- the training-only loss /
         perplexity / one-hot outputs of quantize.py:51-68 are not produced."""
         idx = self.indices(z)
-        z4 = z.reshape(-1, *z.shape[-3:])
+        z4 = self._as_nchw(z)
         hw = z4.shape[2] * z4.shape[3]
         zq = ops.embed_gather(idx, self.embedding.weight.detach(), z4.shape[0], hw).view(z.shape)
         return zq, None, (None, None, idx.unsqueeze(1))
 
     @torch.no_grad()
     def embed_code(self, code):
-        """[..., h, w] int64 -> [..., h, w, C] (quantize.py:76-83)."""
+        """[..., h, w] int64 -> [..., h, w, C] (quantize.py:76-83); any other shape s -> [*s, C]."""
         w = self.embedding.weight.detach()
+        if code.ndim < 3:
+            return ops.embed_gather(code.reshape(-1), w, code.numel(), 1).view(*code.shape, w.shape[1])
         n = code.numel() // (code.shape[-1] * code.shape[-2])
         hw = code.shape[-1] * code.shape[-2]
         z = ops.embed_gather(code.reshape(-1), w, n, hw)  # [n, C, hw]

@@ -7,7 +7,7 @@ kernel is rejected loudly rather than silently approximated.
 """
 import torch
 
-from .... import ops
+from ccvs_amd import ops
 
 _BASE = torch.tensor([1.0, 3.0, 3.0, 1.0])
 _BASE2D = (_BASE[None, :] * _BASE[:, None]) / 64.0

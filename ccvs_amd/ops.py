@@ -486,13 +486,21 @@ def attention(q, kcache, vcache, pos0, pos_dev=None):
     return out
 
 
-def sample_topk(logits, top_k, temperature, noise=None, out=None):
-    """logits [B,V] -> int64 [B]; noise None = greedy, else argmax(p / noise)."""
+def sample_topk(logits, top_k, temperature, noise=None, out=None, philox=None):
+    """logits [B,V] -> int64 [B]; noise None = greedy, else argmax(p / noise).  philox = (key0, key1, row0, step, call):
+    draw the Exp(1) noise in the kernel, keyed by the global clip index row0 + b (ccvs_sample_topk_philox)."""
     _need_gpu(logits, noise, out)
     b, v = logits.shape
     assert logits.stride(1) == 1
     if out is None:
         out = torch.empty(b, dtype=torch.int64, device=logits.device)
+    if philox is not None:
+        assert noise is None
+        k0, k1, row0, step, call = (int(t) & 0xffffffff for t in philox)
+        L = _lib.load()
+        _lib.check(L.ccvs_sample_topk_philox(_p(logits), logits.stride(0), _p(out), out.stride(0), b, v, 0 if top_k is None else int(top_k),
+                                             float(temperature), k0, k1, row0, step, call, _stream()), "ccvs_sample_topk_philox")
+        return out
     if noise is not None:
         assert noise.shape == (b, v) and noise.is_contiguous()
     L = _lib.load()

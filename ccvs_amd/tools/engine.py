@@ -13,6 +13,19 @@ import torch
 import torch.distributed as dist
 
 
+class _Gathered:
+    """Result of `Engine.all_gather_clips_async`."""
+
+    def __init__(self, tensor, event):
+        self.tensor, self.event = tensor, event
+
+    def wait(self):
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
+            self.event = None
+        return self.tensor
+
+
 class Engine(object):
     def __init__(self, opt=None, backend=None):
         self.opt = opt
@@ -23,6 +36,7 @@ class Engine(object):
         self.backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         self.devices = None
         self._own_group = False
+        self._gather_stream = None
         if self.backend == "nccl":
             torch.cuda.set_device(self.local_rank)
         if self.distributed:
@@ -48,12 +62,30 @@ class Engine(object):
 
     def all_gather_clips(self, clips):
         """RCCL all-gather of the decoded clips [B_loc, ...] -> [world*B_loc, ...] (rank order)."""
+        return self.all_gather_clips_async(clips).wait()
+
+    def all_gather_clips_async(self, clips):
+        """The same collective issued on a SIDE stream: it starts when the work already queued on the current
+        stream (the uint8 pack) is done and the current stream carries on with the next batch meanwhile.  Returns a
+        handle; `handle.wait()` orders the current stream after the gather and returns the gathered tensor."""
         if not self.distributed:
-            return clips
+            return _Gathered(clips, None)
         clips = clips.contiguous()
         out = torch.empty(self.world_size * clips.shape[0], *clips.shape[1:], dtype=clips.dtype, device=clips.device)
-        dist.all_gather_into_tensor(out, clips)
-        return out
+        if self.backend != "nccl":
+            dist.all_gather_into_tensor(out, clips)
+            return _Gathered(out, None)
+        if self._gather_stream is None:
+            self._gather_stream = torch.cuda.Stream()
+        side = self._gather_stream
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dist.all_gather_into_tensor(out, clips)
+            done = torch.cuda.Event()
+            done.record(side)
+        clips.record_stream(side)   # the allocator must not hand `clips` out again before the gather has read it
+        out.record_stream(side)
+        return _Gathered(out, done)
 
     def all_reduce_max(self, value):
         """max over ranks of a python float (benchmark timing)."""

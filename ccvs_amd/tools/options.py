@@ -67,6 +67,10 @@ class Options:
         for f in ("rec_only", "step_by_step", "gen_from_img", "keep_state", "custom_state", "layout", "include_id"):
             _flag(p, "--" + f)
         p.add_argument("--down_size", type=int, nargs="+", default=None)
+        # (ccvs_amd) the teacher-forced "rec" decode of the real codes, which the reference always runs unless gen_from_img
+        # (helpers/generator.py:172-189); on by default like the reference, switchable because it is not part of the
+        # synthesized-frames metric
+        _flag(p, "--rec_pass", default=True)
         # ---- q_: quantised video model (tools/options.py:159-264)
         p.add_argument("--q_enc_model", type=str, default="taming")
         p.add_argument("--q_dec_model", type=str, default="stylegan2")
@@ -121,6 +125,11 @@ class Options:
         p.add_argument("--s_state_num", type=int, default=0)
         p.add_argument("--s_z_shape", type=int, nargs="+", default=None)
         p.add_argument("--s_z_size", type=int, default=None)
+        p.add_argument("--s_state_hsize", type=int, default=128)
+        _flag(p, "--s_quantize_only")
+        p.add_argument("--s_load_path", type=str, default=None)
+        p.add_argument("--s_which_iter", type=str, default=0)
+        _flag(p, "--s_not_strict")
         p.add_argument("--a_stft_size", type=int, default=None)
         p.add_argument("--a_stft_shape", type=int, nargs="+", default=None)
         p.add_argument("--a_stft_num", type=int, default=None)

@@ -1,5 +1,7 @@
 """The three tensor helpers of the reference's tools/utils.py that sit on the hot path
-(tools/utils.py:40-62)."""
+(tools/utils.py:40-62), plus the small host helpers helpers/generator.py imports."""
+import os
+
 import torch
 
 
@@ -37,3 +39,29 @@ def unflatten_vid(x, vid_size):
         b, t = vid_size
         return x.view(b, t, *x.shape[1:])
     return x
+
+
+def mkdir(path):
+    """tools/utils.py:19-21."""
+    os.makedirs(path, exist_ok=True)
+
+
+def mkdirs(paths):
+    """tools/utils.py:12-17."""
+    for path in ([paths] if isinstance(paths, str) else list(paths)):
+        mkdir(path)
+
+
+class DummyOpt:
+    """tools/utils.py:128-136: a no-op optimiser stand-in."""
+
+    def zero_grad(self):
+        pass
+
+    def step(self):
+        pass
+
+
+def color_transfer(im, colormap):
+    """tools/utils.py:138-147 colours a semantic layout: layouts are outside the hot path."""
+    raise NotImplementedError("layout colour maps are outside the MI355X hot path")

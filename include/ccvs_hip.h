@@ -158,7 +158,8 @@ int ccvs_tap_shift_add(const float* t, const float* bias, float* y, int64_t y_sN
  * ccvs_vq_argmin replaces VectorQuantizer.forward's distance + argmin
  * (modules/quantize.py:40-50): idx[n*HW + p] = argmin_j (|z|^2 + |e_j|^2) - 2 z.e_j,
  * lowest index on ties.  z [N,C,HW] (NCHW), codebook_t [C][n_e] (transposed embedding),
- * e_sq [n_e]; idx int64 [N*HW]. */
+ * e_sq [n_e]; idx int64 [N*HW].  C even (n_e a multiple of 32: the MFMA stream), or C == 1 -- the scalar state
+ * quantiser VectorQuantizer(state_num, 1) of state_model.py:55, any n_e. */
 int ccvs_vq_argmin(const float* z, const float* codebook_t, const float* e_sq, int64_t* idx, int32_t N, int32_t C, int32_t HW,
                    int32_t n_e, void* stream);
 
@@ -224,14 +225,21 @@ int ccvs_kv_append(const float* k, const float* v, int64_t sB, int64_t ld, float
  * logits [B,V] row stride ld; out int64 [B] written at out[b*out_stride]. */
 int ccvs_sample_topk(const float* logits, int64_t ld, const float* noise, int64_t* out, int64_t out_stride, int32_t B, int32_t V,
                      int32_t top_k, float temperature, void* stream);
+/* The same pick with the Exp(1) noise drawn in the kernel: Philox4x32-10 keyed by (key0, key1), counter
+ * (element, row0 + b, step, call) -- the draw of a clip depends on its GLOBAL index row0 + b only, so a batch sharded
+ * over ranks samples the same tokens for any world size (same words as ccvs_gpt_decode.state, see below). */
+int ccvs_sample_topk_philox(const float* logits, int64_t ld, int64_t* out, int64_t out_stride, int32_t B, int32_t V, int32_t top_k,
+                            float temperature, uint32_t key0, uint32_t key1, uint32_t row0, uint32_t step, uint32_t call, void* stream);
 
 /* One whole KV-cached decode step of the sampling loop (transformer_model.py:395-409 calling
  * mingpt.py:219-305 for ONE new position): embed `tok` -> n_layer x [ln1+QKV+cache | attention |
  * proj+res | ln2+fc+GELU | fc2+res] -> ln_f+head -> get_icode pick -> codes[b][*widx] = tok[b] = pick;
  * ++*widx; ++*len; ++state[0].  5*n_layer+3 launches on `stream`.  All per-step state is device-resident,
  * so the call is hipGraph-capturable and a captured step replays unchanged.
- * `state`: int32[8] owned by the caller: [0] steps completed (also the Philox counter word), [2] internal
- * (zero between calls), [4..5] Philox key; the caller zeroes it and sets the key when a sequence starts. */
+ * `state`: int32[8] owned by the caller: [0] steps completed (also a Philox counter word), [2] internal
+ * (zero between calls), [3] call index (Philox counter word: successive token windows of one clip), [4..5] Philox key,
+ * [6] GLOBAL clip index of row 0 (rank r of a sharded batch passes its first clip, so a clip's noise does not depend on
+ * the world size); the caller zeroes [0] and [2] and sets the rest when a sequence starts. */
 typedef struct ccvs_gpt_layer {
     const float *qkv_w, *qkv_b, *qkv_s; /* ln1 folded into [q;k;v]: W*gamma [3C,C], b + W beta [3C], rowsum(W*gamma) [3C] */
     const float *proj_w, *proj_b;       /* [C,C], [C] */
@@ -253,7 +261,7 @@ typedef struct ccvs_gpt_decode {
     float *x, *q, *att, *h, *logits;    /* scratch [B,C] [B,C] [B,C] [B,F] [B,V] */
     const float* noise;                 /* [B,V] Exp(1) noise (host-reproducible sampling), or NULL */
     int32_t rng;                        /* noise == NULL: 0 greedy pick, 1 draw the Exp(1) noise in the kernel (Philox4x32-10,
-                                           key = state[4..5], counter = (element, row, step = state[0])) */
+                                           key = state[4..5], counter = (element, state[6] + row, step = state[0], call = state[3])) */
     int32_t top_k; float temperature;
     void* workspace;                    /* ccvs_gemm_workspace_bytes(), zeroed once */
     int32_t* state;

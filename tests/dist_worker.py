@@ -30,6 +30,21 @@ def main():
         assert gathered.shape == want.shape and torch.equal(gathered, want), "all-gather != concatenation of per-rank outputs"
         info = gen.get_data_info("valid", "vid")
         assert info["batch_size_per_gpu"] == 1  # batch_size_vid 2 split over 2 ranks
+        # sampling-noise derivation: one Philox key per iteration shared by all ranks, counter row = GLOBAL clip
+        # index -> identical to what a single rank running the whole batch would use (world-size invariance)
+        import torch.distributed as dist
+        key = torch.tensor(gen.noise_key(5), dtype=torch.int64)
+        keys = [torch.zeros_like(key) for _ in range(2)]
+        dist.all_gather(keys, key)
+        assert torch.equal(keys[0], keys[1]), "Philox key differs between ranks"
+        rows = gen.first_clip(2) + torch.arange(2)
+        allrows = [torch.zeros_like(rows) for _ in range(2)]
+        dist.all_gather(allrows, rows)
+        solo = Generator(Options().parse(True, True, argv=TINY_ARGV))          # the same job on one rank
+        assert solo.noise_key(5) == gen.noise_key(5) and solo.noise_key(6) != gen.noise_key(5)
+        assert torch.equal(torch.cat(allrows), solo.first_clip(4) + torch.arange(4)), "global clip rows differ from the 1-rank job"
+        h = eng.all_gather_clips_async(clips)          # the side-stream form degrades to the blocking call on gloo
+        assert torch.equal(h.wait(), want)
         t = eng.all_reduce_max(1.0 + eng.rank)
         assert t == 2.0
         eng.barrier()

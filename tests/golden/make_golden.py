@@ -203,6 +203,39 @@ def tiny_state_stream(ns):
     print("  wrote tiny_state.npz", sum(a.nbytes for a in arrays.values()) / 1e6, "MB raw")
 
 
+def tiny_state_model(ns):
+    """StateModel (state_model.py:109-124) in miniature: StateEstimator on a quantised latent map, the scalar (e_dim = 1)
+    quantiser, and the code -> state decode."""
+    opt = rh.parse_reference_options(rh.TINY_STATEMODEL_ARGV)
+    sopt = opt["state_estimator"]
+    torch.manual_seed(0)
+    sm = ns.state_model.StateModel(sopt, is_train=False, is_main=True).eval()
+    out = {}
+    with torch.no_grad():
+        torch.manual_seed(31)
+        z = torch.randn(2, 3, sopt.z_size, *sopt.z_shape)
+        sm.net_s.fc.bias.normal_(0, 0.3)
+        for conv in sm.net_s.convs:
+            conv[1].bias.normal_(0, 0.1)
+        state = sm.net_s(z)
+        enc = sm({"z": z.clone()}, mode="vid_encoder")["state_code"]
+        dec = sm({"state_code": enc.clone()}, mode="vid_decoder")["state"]
+        given = torch.rand(2, 3, 2)
+        enc_given = sm({"z": z.clone(), "state": given.clone()}, mode="vid_encoder")["state_code"]
+        out.update(z=z, state=state, state_code=enc, state_dec=dec, given=given, given_code=enc_given)
+    nets = {"s": sm.net_s.state_dict(), "sq": sm.net_q.state_dict()}
+    with torch.no_grad():
+        report("statemodel/state", O.state_estimator_forward(nets["s"], sopt, z), state)
+        report("statemodel/code (mismatches)", (O.state_encode(nets, sopt, z) != enc).float(), torch.zeros(1))
+        report("statemodel/given code (mismatches)", (O.state_encode(nets, sopt, z, given) != enc_given).float(), torch.zeros(1))
+        report("statemodel/decode", O.state_decode(nets, sopt, enc), dec)
+    arrays = {k: v.detach().cpu().numpy() for k, v in out.items()}
+    arrays.update(sd_np("s", sm.net_s))
+    arrays.update(sd_np("sq", sm.net_q))
+    np.savez_compressed(os.path.join(HERE, "tiny_statemodel.npz"), **arrays)
+    print("  wrote tiny_statemodel.npz", sum(a.nbytes for a in arrays.values()) / 1e6, "MB raw")
+
+
 def tiny_keep_first(ns):
     """Decoder context ring with `--q_keep_first --q_n_first 1` (quantized_video_model.py:896-898; the drums script uses
     n_first 8): 6 frames through a 3-slot ring.  Same seed / construction order as tiny_end_to_end, so the weights are the
@@ -374,7 +407,7 @@ def op_fixtures(ns):
 
 if __name__ == "__main__":
     ns = rh.load_reference()
-    which = sys.argv[1:] or ["ops", "tiny", "state", "keepfirst"]
+    which = sys.argv[1:] or ["ops", "tiny", "state", "keepfirst", "statemodel"]
     if "ops" in which:
         print("== op fixtures")
         op_fixtures(ns)
@@ -384,6 +417,9 @@ if __name__ == "__main__":
     if "state" in which:
         print("== tiny ancillary-token stream")
         tiny_state_stream(ns)
+    if "statemodel" in which:
+        print("== tiny state model")
+        tiny_state_model(ns)
     if "keepfirst" in which:
         print("== tiny keep_first ring")
         tiny_keep_first(ns)

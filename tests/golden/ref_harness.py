@@ -125,13 +125,18 @@ def load_reference():
     except Exception as exc:  # pragma: no cover
         stft_model = None
         print("[ref_harness] stft_model not importable:", exc)
+    try:
+        from models.skip_vid_generator.models import state_model
+    except Exception as exc:  # pragma: no cover
+        state_model = None
+        print("[ref_harness] state_model not importable:", exc)
     upf = sys.modules["models.skip_vid_generator.modules.upfirdn2d"]  # the package re-exports the function under the same name
     from tools import options as ref_options
 
     sae.FunctionCorrelation = correlation_bruteforce
 
     ns = types.SimpleNamespace(sae=sae, qvm=qvm, tm=tm, mingpt=mingpt, quantize=quantize,
-                               upfirdn2d=upf, options=ref_options, stft_model=stft_model)
+                               upfirdn2d=upf, options=ref_options, stft_model=stft_model, state_model=state_model)
     _LOADED["ns"] = ns
     return ns
 
@@ -184,4 +189,11 @@ TINY_STATE_ARGV = [a for a in TINY_ARGV] + [
     "--x_stft", "--x_state_num", "24", "--x_state_size", "2", "--x_z_len", "256", "--x_z_chunk", "66",
     "--x_top_k_state", "5", "--x_temperature_state", "0.8",
     "--a_stft_num", "24", "--a_stft_size", "16", "--a_stft_hsize", "8", "--a_stft_shape", "2", "1",
+]
+
+# tiny configuration of the state-conditioned scripts (scripts/bairhd/save_videos_state_*.sh): 2 state tokens per frame from a
+# StateEstimator + scalar quantiser with 24 levels
+TINY_STATEMODEL_ARGV = [a for a in TINY_ARGV] + [
+    "--x_state", "--x_z_len", "256", "--x_z_chunk", "66", "--x_top_k_state", "5",
+    "--s_state_size", "2", "--s_state_num", "24", "--s_state_hsize", "8",
 ]
