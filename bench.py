@@ -36,14 +36,42 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-noise", type=str, default="device", choices=["device", "host"])
     ap.add_argument("--conv-precision", type=str, default=None, choices=["bf16x3", "f32"])
+    ap.add_argument("--rec-pass", action="store_true", help="also run the reference's teacher-forced reconstruction decode (not counted)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` invoked bare (no torch.distributed environment): start N fresh rank processes -- children of
+    this process, which has not touched the GPU (torch.cuda.device_count() does not initialise it) -- relay rank 0's JSON
+    line and return their exit code.  Mirrors the reference's launch line (scripts/bairhd/save_videos_p2p.sh:6)."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if lines:
+        print(lines[-1])
+    else:
+        sys.stderr.write(res.stdout[-4000:])
+    return res.returncode if res.returncode != 0 or lines else 1
 
 
 def build_generator(args):
     from ccvs_amd.tools.options import Options, BAIR_ARGV, KINETICS_ARGV
     from ccvs_amd.helpers.generator import Generator
     argv = list(BAIR_ARGV if args.config == "bair" else KINETICS_ARGV)
-    argv += ["--batch_size_vid", str(args.batch), "--x_sample_noise", args.sample_noise]
+    # the teacher-forced "rec" decode of the REAL codes is not part of the metric (SURVEY 8d: synthesized frames only)
+    argv += ["--batch_size_vid", str(args.batch), "--x_sample_noise", args.sample_noise, "--rec_pass", "true" if args.rec_pass else "false"]
     opt = Options().parse(load_qvid_generator=True, load_transformer=True, argv=argv)
     torch.manual_seed(0)  # reference initialisers under seed 0 (SURVEY 8d)
     with contextlib.redirect_stdout(sys.stderr):   # "Loading untrained ... net": stdout carries the ONE JSON line only
@@ -135,8 +163,10 @@ def conv_traffic(args, kind, launches):
 
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     from ccvs_amd import lib, ops
     from ccvs_amd.tools.engine import Engine
@@ -200,7 +230,9 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": "BAIR 256x256 1->15 frames, batch 16 per GPU (BASELINE.json configs[1])" if args.config == "bair"
                            else "Kinetics-600 64x64 5->11 frames", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                           "predicted_frames_per_clip": predicted, "sampling": f"top-k {xopt.top_k}, T={xopt.temperature}, noise={args.sample_noise}",
+                           "predicted_frames_per_clip": predicted,
+                           "rec_pass": ("also run, not counted" if args.rec_pass else "off: the reference's extra teacher-forced reconstruction decode is not part of "
+                                        "the synthesized-frames metric (SURVEY 8d)"), "sampling": f"top-k {xopt.top_k}, T={xopt.temperature}, noise={args.sample_noise}",
                            "parallelism": f"dp{world} (batch sharded, one RCCL all-gather of uint8 clips)"},
                 "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
                 "roofline": {"kernel": ("conv2d_bf16x3_pc_kernel<TW,MB,NTY> + conv2d_bf16x3_kernel<TW,MB> (every instantiation: all conv launches)"

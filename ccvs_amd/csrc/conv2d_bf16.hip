@@ -89,9 +89,10 @@ __global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
-    const int n0 = blockIdx.y * NT;
-    int n = blockIdx.z, cls = 0;
+    CONV_TILE_COORDS(p, bx, by, bz)
+    const int ty = bx / p.tiles_x, tx = bx - ty * p.tiles_x;
+    const int n0 = by * NT;
+    int n = bz, cls = 0;
     if (p.transposed) { cls = n & 3; n >>= 2; }
     const AxisTaps ay = axis_taps(p.kh, p.stride, p.pad, p.transposed, cls >> 1, p.Hout);
     const AxisTaps ax = axis_taps(p.kw, p.stride, p.pad, p.transposed, cls & 1, p.Wout);
@@ -260,9 +261,10 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
     const bool xrole = VEC && producer;
     const bool wrole = DMAW ? !producer : producer;
     const int rtw = rt;
-    const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
-    const int n0 = blockIdx.y * NT;
-    int n = blockIdx.z, cls = 0;
+    CONV_TILE_COORDS(p, bx, by, bz)
+    const int ty = bx / p.tiles_x, tx = bx - ty * p.tiles_x;
+    const int n0 = by * NT;
+    int n = bz, cls = 0;
     if (p.transposed) { cls = n & 3; n >>= 2; }
     const AxisTaps ay = axis_taps(p.kh, p.stride, p.pad, p.transposed, cls >> 1, p.Hout);
     const AxisTaps ax = axis_taps(p.kw, p.stride, p.pad, p.transposed, cls & 1, p.Wout);
@@ -735,10 +737,7 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
             }
             if (m + 1 < MB) __syncthreads();
         }
-        return;
-    }
-    if (producer) return;
-
+    } else if (!producer) {
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
         const int pj = (rw * 2 + pp) * 32 + (lane & 31);
@@ -766,10 +765,26 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
             }
         }
     }
+    }
+}
+
+// workgroups of kernel `fn` that fit one CU (HIP occupancy query, cached per kernel and LDS size)
+static int conv_occupancy(const void* fn, int threads, size_t smem_bytes) {
+    struct Entry { const void* fn; size_t smem; int occ; };
+    static Entry cache[64];
+    static int n_cache = 0;
+    for (int i = 0; i < n_cache; ++i)
+        if (cache[i].fn == fn && cache[i].smem == smem_bytes) return cache[i].occ;
+    int occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, threads, smem_bytes) != hipSuccess || occ < 1) occ = 1;
+    static const int occ_max = getenv("CCVS_CONV_CHUNK_OCC") ? atoi(getenv("CCVS_CONV_CHUNK_OCC")) : 0;  // experiments: cap workgroups per CU
+    if (occ_max > 0 && occ > occ_max) occ = occ_max;
+    if (n_cache < 64) cache[n_cache++] = Entry{fn, smem_bytes, occ};
+    return occ;
 }
 
 template <int TW, int MB>
-static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int halo_h, int halo_w, int ntx_max, int gz, hipStream_t st) {
+static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, int CinG, int halo_h, int halo_w, int ntx_max, int gz, hipStream_t st) {
     constexpr int NT = 32 * MB;
     int plane = halo_h * halo_w;
     if (plane > 256 * CB_MAX_E) {
@@ -787,14 +802,42 @@ static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int ha
         attr_set = true;
     }
     static const int ablate = getenv("CCVS_CONV_ABLATE") ? atoi(getenv("CCVS_CONV_ABLATE")) : 0;  // timing experiments only (1: no staging, 2: no MFMA, 4: scalar staging)
-    dim3 grid(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
+    ConvK k = k_in;
+    const dim3 grid3(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
+    // cu_limit > 0: the tiles go out as consecutive 1-D chunks of cu_limit x (workgroups of this instantiation that fit one
+    // CU) workgroups -- launches on one stream run one after the other, so the convolution never holds more than cu_limit
+    // CUs and work on another stream (the token loop of the next batch) always finds the remaining ones free.
+    long n_chunk = 1, cap = 0;
+    const long total = (long)grid3.x * grid3.y * grid3.z;
+    auto plan = [&](const void* fn, int threads, size_t smem_bytes) {
+        k.nwork = 0; k.work0 = 0;
+        n_chunk = 1;
+        if (k.cu_limit <= 0) return;
+        cap = (long)k.cu_limit * conv_occupancy(fn, threads, smem_bytes);
+        if (total <= cap) return;  // fits as it is
+        k.nwork = (int)total; k.gx = (int)grid3.x; k.gy = (int)grid3.y;
+        n_chunk = (total + cap - 1) / cap;
+    };
+    auto chunk_grid = [&](long c) -> dim3 {
+        if (k.nwork == 0) return grid3;
+        k.work0 = (int)(c * cap);
+        return dim3((unsigned)((total - c * cap < cap) ? total - c * cap : cap));
+    };
+#define CB_LAUNCH(KERNEL, THREADS, SMEM, ...)                                                    \
+    do {                                                                                          \
+        plan((const void*)KERNEL, THREADS, SMEM);                                                 \
+        for (long c_ = 0; c_ < n_chunk; ++c_) {                                                   \
+            const dim3 g_ = chunk_grid(c_);                                                       \
+            hipLaunchKernelGGL((KERNEL), g_, dim3(THREADS), SMEM, st, k, __VA_ARGS__);            \
+        }                                                                                         \
+    } while (0)
     if (k.in_p8) {  // packed input: LDS-DMA staging (validated by the caller: stride 1, not transposed, Cin % 8 == 0)
         const size_t smem_p = (size_t)(2 * 4 * plane + 2 * ntx_max * 4 * NT) * 16;
         if (4 * plane > 8 * 256 || ntx_max > (MB == 1 ? 9 : 3) || smem_p > 156 * 1024) {
             ccvs_set_error("ccvs_conv2d_bf16x3: packed input with a %dx%d halo tile / %d taps per row is not supported", halo_h, halo_w, ntx_max);
             return CCVS_ERR_ARG;
         }
-        hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, -8>), grid, dim3(512), smem_p, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
+        CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, -8>), 512, smem_p, (const uint4*)wsplit, CinG, ntx_max, ablate);
         CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
         return CCVS_OK;
     }
@@ -806,8 +849,8 @@ static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int ha
     if (vec_ok) {
         const size_t smem_v = (size_t)(2 * 4 * halo_h * (nq * 4 + 1) + 2 * ntx_max * 4 * NT) * 16;
         if (smem_v <= 156 * 1024) {
-            if (k.kh == 3) hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 3>), grid, dim3(512), smem_v, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
-            else hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 1>), grid, dim3(512), smem_v, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
+            if (k.kh == 3) CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, 3>), 512, smem_v, (const uint4*)wsplit, CinG, ntx_max, ablate);
+            else CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, 1>), 512, smem_v, (const uint4*)wsplit, CinG, ntx_max, ablate);
             CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
             return CCVS_OK;
         }
@@ -819,12 +862,12 @@ static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int ha
     const bool regs_ok2 = (ntx_max <= (MB == 1 ? 9 : 3)) && (passes <= 2 * nt_min) && !(ablate & 32);
     // (8 staging waves for <= 64 output channels were measured slower: the steps are latency- not staging-bound)
     if (smem_pc <= 156 * 1024 && regs_ok) {  // double-buffered producer / consumer form, scalar staging
-        hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 0>), grid, dim3(512), smem_pc, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
+        CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, 0>), 512, smem_pc, (const uint4*)wsplit, CinG, ntx_max, ablate);
         CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
         return CCVS_OK;
     }
     if (smem_pc <= 156 * 1024 && regs_ok2) {
-        hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, -2>), grid, dim3(512), smem_pc, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
+        CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, -2>), 512, smem_pc, (const uint4*)wsplit, CinG, ntx_max, ablate);
         CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
         return CCVS_OK;
     }
@@ -837,7 +880,7 @@ static int launch_conv_bf16(const ConvK& k, const void* wsplit, int CinG, int ha
         ccvs_set_error("ccvs_conv2d_bf16x3: %zu bytes of LDS needed", smem);
         return CCVS_ERR_ARG;
     }
-    hipLaunchKernelGGL((conv2d_bf16x3_kernel<TW, MB>), grid, dim3(256), smem, st, k, (const uint4*)wsplit, CinG);
+    CB_LAUNCH((conv2d_bf16x3_kernel<TW, MB>), 256, smem, (const uint4*)wsplit, CinG);
     CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
     return CCVS_OK;
 }
@@ -870,6 +913,7 @@ extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const flo
     k.act = d->act; k.accumulate = d->accumulate; k.out_scale = d->out_scale;
     k.pre = d->pre; k.pre_sN = d->pre_sN; k.pre_sC = d->pre_sC; k.pre_div = d->pre_div > 0 ? d->pre_div : 1;
     k.in_p8 = d->in_p8 ? 1 : 0; k.out_p8 = d->out_p8 ? 1 : 0;
+    k.nwork = 0; k.gx = k.gy = 1; k.work0 = 0; k.cu_limit = d->cu_limit > 0 ? d->cu_limit : 0;
     if (k.in_p8) CCVS_REQUIRE(!d->transposed && d->stride == 1 && d->Cin % 8 == 0, "ccvs_conv2d_bf16x3: packed input needs stride 1, Cin %% 8 == 0");
     if (k.out_p8) CCVS_REQUIRE(!d->transposed && d->Cout % 8 == 0 && !d->accumulate && !residual, "ccvs_conv2d_bf16x3: packed output needs Cout %% 8 == 0, no residual / accumulate");
     const int CinG = 2 * ((d->Cin + 15) / 16);  // 8-channel groups, Cin padded to 16

@@ -21,7 +21,24 @@ struct ConvK {
     int pre_div;
     int tiles_x, tiles_y;
     int in_p8, out_p8;  // split-bf16 packed activations (ccvs_hip.h: ccvs_conv_desc)
+    // CU-limited form (ccvs_conv_desc.cu_limit > 0): the nwork = gx * gy * gz tiles (x fastest, like the 3-D grid's dispatch
+    // order) are launched as consecutive 1-D chunks of at most cu_limit x occupancy workgroups; a chunk starts at tile work0
+    int nwork, gx, gy, work0;
+    int cu_limit;  // host side only: CUs this launch may occupy (0 = classic 3-D grid over all of them)
 };
+
+// tile coordinates of a workgroup: the 3-D grid (nwork == 0) or tile work0 + blockIdx.x of a chunk
+#define CONV_TILE_COORDS(p, bx, by, bz)                                         \
+    int bx, by, bz;                                                             \
+    if ((p).nwork > 0) {                                                        \
+        const int w_ = (p).work0 + (int)blockIdx.x;                             \
+        bx = w_ % (p).gx;                                                       \
+        const int r_ = w_ / (p).gx;                                             \
+        by = r_ % (p).gy;                                                       \
+        bz = r_ / (p).gy;                                                       \
+    } else {                                                                    \
+        bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;                      \
+    }
 
 struct AxisTaps {
     int nt;       // number of taps along this axis

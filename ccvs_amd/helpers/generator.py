@@ -102,13 +102,20 @@ class Generator:
         """Global index of this rank's clip 0 when every rank holds `batch` clips."""
         return self.engine.rank * batch if self.engine is not None else 0
 
-    @torch.no_grad()
-    def generate_vid(self, data, global_iter=0, save=False):
-        opt, qopt = self.opt, self.qvid_opt
+    def _seed_sampler(self, batch, global_iter):
         if self.transformer_model is not None:
             net_t = self.transformer_model.net_t
             net_t.noise_key, net_t.noise_call = self.noise_key(global_iter), 0
-            net_t.row_offset = self.first_clip(data["vid"].shape[0])
+            net_t.row_offset = self.first_clip(batch)
+
+    @torch.no_grad()
+    def condition(self, data):
+        """First half of generate_vid (generator.py:57-130): encode every frame, tokenise the ancillary streams, crop to the
+        conditioning window.  Returns the working set of one batch as a dict: `encoded`, `cropped`, `total_len`,
+        `cond_len`, `crop_prop`."""
+        opt, qopt = self.opt, self.qvid_opt
+        if getattr(opt, "layout", False) or getattr(opt, "deblurring", False):
+            raise NotImplementedError("layout / deblurring conditioning is not on the MI355X path (SURVEY 8f)")
         if opt.down_size is not None:  # generator.py:60-66
             vid = data["vid"].cuda()
             bs, t = vid.shape[:2]
@@ -116,14 +123,7 @@ class Generator:
             img = F.interpolate(img, size=opt.down_size, mode='bilinear')
             img = F.interpolate(img, size=vid.shape[-2:], mode='bilinear')
             data["vid"] = img.view(bs, t, *vid.shape[2:])
-
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        ev[0].record()
         encoded_data = self.vid_model(data, mode='vid_encoder')            # encode all frames
-        ev[1].record()
-
-        if getattr(opt, "layout", False) or getattr(opt, "deblurring", False):
-            raise NotImplementedError("layout / deblurring conditioning is not on the MI355X path (SURVEY 8f)")
         if opt.state:                                                       # generator.py:73-77: estimate + quantise the state
             encoded_data.update(self.state_model(encoded_data, mode='vid_encoder'))
             data.update(self.state_model(encoded_data, mode='vid_decoder'))
@@ -160,42 +160,77 @@ class Generator:
                 cropped["state_code"] = self.state_model(custom_state, mode='vid_encoder')["state_code"]
             else:
                 cropped["state_code"] = encoded_data["state_code"][:, :int(crop_prop * encoded_data["state_code"].size(1))]
+        return {"data": data, "encoded": encoded_data, "cropped": cropped, "total_len": total_len, "cond_len": cond_len,
+                "crop_prop": crop_prop}
+
+    @torch.no_grad()
+    def decode_codes(self, ws, code, state_code=None):
+        """Flow-guided decode of a full token sequence `code` for the working set `ws` of `condition()`
+        (generator.py:161-169): the second half of the synthesis, also used teacher-forced by the tests."""
+        opt = self.opt
+        dec_in = dict(ws["cropped"])
+        dec_in["code"] = code
+        if state_code is not None:
+            dec_in["state_code"] = state_code
+        fake_data = self.vid_model(dec_in, mode='vid_decoder')
+        fake_data["code"], fake_data["state_code"] = code, state_code
+        if opt.p2p:
+            fake_data["vid"] = torch.cat([fake_data["vid"], ws["data"]["vid"][:, -1:]], dim=1)
+        if opt.state and state_code is not None:                            # generator.py:168-169
+            fake_data.update(self.state_model({"state_code": state_code}, mode='vid_decoder'))
+        return fake_data
+
+    @torch.no_grad()
+    def reconstruct(self, ws):
+        """The teacher-forced "rec" decode of the clip's own codes (generator.py:172-189)."""
+        opt = self.opt
+        encoded_data, cropped, data = ws["encoded"], ws["cropped"], ws["data"]
+        rec = {"inter": cropped["inter"]}
+        if opt.p2p:
+            rec["code"] = encoded_data["code"][:, :-opt.z_chunk].contiguous()
+            rec["cond_code"] = cropped["cond_code"]
+            rec["cond_inter"] = cropped["cond_inter"]
+        else:
+            rec["code"] = encoded_data["code"]
+        if opt.state or opt.stft:
+            rec["state_code"] = encoded_data["state_code"]
+        rec_data = self.vid_model(rec, mode='vid_decoder')
+        if opt.p2p:
+            rec_data["vid"] = torch.cat([rec_data["vid"], data["vid"][:, -1:]], dim=1)
+        if opt.state:
+            rec_data["state"] = data["state"]
+        return rec_data
+
+    @torch.no_grad()
+    def generate_vid(self, data, global_iter=0, save=False):
+        opt = self.opt
+        self._seed_sampler(data["vid"].shape[0], global_iter)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        ws = self.condition(data)
+        ev[1].record()
+        encoded_data, cropped = ws["encoded"], ws["cropped"]
 
         fake_data, rec_data = None, None
         if not opt.rec_only:
             if opt.step_by_step:
-                fake_data = self._step_by_step(data, cropped, crop_prop, total_len, cond_len)
+                fake_data = self._step_by_step(data, cropped, ws["crop_prop"], ws["total_len"], ws["cond_len"])
                 ev[2].record()
+                if opt.p2p:
+                    fake_data["vid"] = torch.cat([fake_data["vid"], data["vid"][:, -1:]], dim=1)
             else:
-                fake_encoded = self.transformer_model(cropped, mode='inference', total_len=total_len, show_progress=False)
+                fake_encoded = self.transformer_model(cropped, mode='inference', total_len=ws["total_len"], show_progress=False)
                 ev[2].record()
-                cropped.update(fake_encoded)
-                fake_data = self.vid_model(cropped, mode='vid_decoder')
-                fake_data["code"] = fake_encoded["code"]
-                fake_data["state_code"] = fake_encoded.get("state_code")
-            if opt.p2p:
-                fake_data["vid"] = torch.cat([fake_data["vid"], data["vid"][:, -1:]], dim=1)
-            if opt.state and fake_data.get("state_code") is not None:      # generator.py:168-169
-                fake_data.update(self.state_model({"state_code": fake_data["state_code"]}, mode='vid_decoder'))
+                state_code = fake_encoded.get("state_code")
+                if state_code is not None and 0 in state_code.size():
+                    state_code = None
+                fake_data = self.decode_codes(ws, fake_encoded["code"], state_code)
         else:
             ev[2].record()
         ev[3].record()
 
-        if not opt.gen_from_img and (getattr(opt, "rec_pass", True) or opt.rec_only):   # teacher-forced "rec" decode (generator.py:172-189)
-            rec = {"inter": cropped["inter"]}
-            if opt.p2p:
-                rec["code"] = encoded_data["code"][:, :-opt.z_chunk].contiguous()
-                rec["cond_code"] = cropped["cond_code"]
-                rec["cond_inter"] = cropped["cond_inter"]
-            else:
-                rec["code"] = encoded_data["code"]
-            if opt.state or opt.stft:
-                rec["state_code"] = encoded_data["state_code"]
-            rec_data = self.vid_model(rec, mode='vid_decoder')
-            if opt.p2p:
-                rec_data["vid"] = torch.cat([rec_data["vid"], data["vid"][:, -1:]], dim=1)
-            if opt.state:
-                rec_data["state"] = data["state"]
+        if not opt.gen_from_img and (getattr(opt, "rec_pass", True) or opt.rec_only):
+            rec_data = self.reconstruct(ws)
 
         self._events = ev
         out = {"real": data["vid"], "fake": fake_data, "rec": rec_data, "enc_code": encoded_data["code"],

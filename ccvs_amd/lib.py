@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
         ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("transposed", C.c_int32),
         ("act", C.c_int32), ("accumulate", C.c_int32), ("out_scale", C.c_float),
         ("pre", C.c_void_p), ("pre_sN", C.c_int64), ("pre_sC", C.c_int64), ("pre_div", C.c_int32),
-        ("in_p8", C.c_int32), ("out_p8", C.c_int32),
+        ("in_p8", C.c_int32), ("out_p8", C.c_int32), ("cu_limit", C.c_int32),
     ]
 
 

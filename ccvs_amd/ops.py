@@ -78,6 +78,9 @@ def _as_rows_dense(t):
 #   "bf16x3": split-bf16, 3 products per fp32 product on v_mfma_f32_32x32x16_bf16 (default)
 #   "f32"   : exact fp32 on v_mfma_f32_32x32x2_f32
 CONV_PRECISION = "bf16x3"
+# CUs a convolution launch may occupy (`ccvs_conv_desc.cu_limit`; 0 = all).  The pipelined Generator sets it for the decoder's
+# stream so that the token loop of the next batch, running concurrently on a high-priority stream, always finds free CUs.
+CONV_CU_LIMIT = 0
 
 
 class PackedConv:
@@ -184,6 +187,7 @@ def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=Fa
     d.act = ACT_LRELU if act else ACT_NONE
     d.accumulate = 1 if accumulate else 0
     d.out_scale = out_scale
+    d.cu_limit = CONV_CU_LIMIT
     L = _lib.load()
     prof = KERNEL_TIMER
     if prof is not None:

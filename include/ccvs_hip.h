@@ -71,6 +71,12 @@ typedef struct ccvs_conv_desc {
      * out_p8: y is written in that form (dense; out_sN / out_sC ignored) by the epilogue, for the next convolution.
      * A chain conv -> conv run this way is bit-identical to the fp32-activation chain. */
     int32_t in_p8, out_p8;
+    /* cu_limit > 0 (ccvs_conv2d_bf16x3): never occupy more than cu_limit compute units -- the tiles are launched as
+     * consecutive chunks of cu_limit x (workgroups per CU of the chosen kernel) workgroups on `stream` -- so that work on
+     * another stream (the latency-bound token loop of the next batch, a few hundred small workgroups per launch) always
+     * finds free CUs beside the decoder's convolutions.  0: one launch, one workgroup per tile over the whole chip.
+     * Results are identical either way. */
+    int32_t cu_limit;
 } ccvs_conv_desc;
 
 int ccvs_conv2d(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
