@@ -36,6 +36,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-noise", type=str, default="device", choices=["device", "host"])
     ap.add_argument("--conv-precision", type=str, default=None, choices=["bf16x3", "f32"])
+    ap.add_argument("--schedule", type=str, default=os.environ.get("CCVS_BENCH_SCHEDULE", "pipelined"), choices=["serial", "pipelined"],
+                    help="serial: batches one after the other; pipelined: token loop of batch i+1 beside the decoder of batch i")
+    ap.add_argument("--cu-limit", type=int, default=None, help="pipelined: CUs the convolutions may occupy while a token loop is in flight")
     ap.add_argument("--rec-pass", action="store_true", help="also run the reference's teacher-forced reconstruction decode (not counted)")
     return ap.parse_args()
 
@@ -188,25 +191,39 @@ def main():
         # the same clips on every rank (global clips 0-1 of seed 1): the codebook scale, hence the replica, is identical everywhere
         calibrate_codebook(gen, {"vid": gen.synthetic_batch(2, seed=1, first_clip=0)["vid"].to(dev)})
 
-        def one_step(step, data):
-            out = gen.generate_vid(data, step)
-            packed = ops.pack_u8(out["fake"]["vid"])
-            return engine.all_gather_clips(packed)
+        def finish(step, fake):
+            """uint8 pack on the decode stream, then the RCCL all-gather on a side stream (it overlaps the next batch)."""
+            return engine.all_gather_clips_async(ops.pack_u8(fake["vid"]))
 
-        for w in range(args.warmup):
-            one_step(-1 - w, make_batch(1000 + w))
+        def run(first, batches):
+            """K batches from resident inputs to all-gathered uint8 clips; returns the gathered clips of the last one."""
+            if args.schedule == "pipelined":
+                res = gen.run_pipelined(iter(batches), first_iter=first, cu_limit=args.cu_limit, finish=finish)
+                handles = [r["finished"] for r in res]
+                stages = gen.pipeline_stage_ms() if engine.is_main else {}
+            else:
+                ops.CONV_CU_LIMIT = args.cu_limit or 0     # (experiments: the cost of capping the convolutions, in isolation)
+                handles, stages = [], {"encode": 0.0, "transformer": 0.0, "decode": 0.0}
+                for i, data in enumerate(batches):
+                    out = gen.generate_vid(data, first + i)
+                    handles.append(finish(first + i, out["fake"]))
+                    if engine.is_main:
+                        for k, v in gen.stage_ms().items():
+                            stages[k] += v
+            clips = None
+            for h in handles:
+                clips = h.wait()
+            return clips, stages
+
+        if args.warmup > 0:
+            run(-args.warmup, [make_batch(1000 + w) for w in range(args.warmup)])
         batches = [make_batch(i) for i in range(args.steps)]   # inputs resident in HBM before the clock starts
         timer = ops.KernelTimer()
-        stage = {"encode": 0.0, "transformer": 0.0, "decode": 0.0}
         torch.cuda.synchronize()
         engine.barrier()
         ops.KERNEL_TIMER = timer
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            clips = one_step(i, batches[i])
-            if engine.is_main:
-                for k, v in gen.stage_ms().items():
-                    stage[k] += v
+        clips, stage = run(0, batches)
         torch.cuda.synchronize()
         engine.barrier()
         elapsed = engine.all_reduce_max(time.perf_counter() - t0)
@@ -214,6 +231,7 @@ def main():
         assert clips.shape[0] == args.batch * world
 
         if engine.is_main:
+            n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
             frames = predicted * args.batch * world * args.steps
             kind = ops.CONV_PRECISION
             n_conv, conv_flops, conv_ms = timer.summary("conv2d_" + kind)
@@ -233,11 +251,19 @@ def main():
                            "predicted_frames_per_clip": predicted,
                            "rec_pass": ("also run, not counted" if args.rec_pass else "off: the reference's extra teacher-forced reconstruction decode is not part of "
                                         "the synthesized-frames metric (SURVEY 8d)"), "sampling": f"top-k {xopt.top_k}, T={xopt.temperature}, noise={args.sample_noise}",
-                           "parallelism": f"dp{world} (batch sharded, one RCCL all-gather of uint8 clips)"},
+                           "schedule": ("pipelined: two batches in flight per GPU -- token loop of batch i+1 on a high-priority stream beside the "
+                                        f"encoder/decoder of batch i, whose convolutions are capped to {gen.last_cu_limit} of {n_cu} CUs; K batches timed "
+                                        "from resident inputs to gathered clips, fill and drain included") if args.schedule == "pipelined"
+                                       else "serial: one batch at a time",
+                           "parallelism": f"dp{world} (batch sharded, one RCCL all-gather of uint8 clips on a side stream)"},
                 "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
+                "stage_note": "per-batch stage durations from HIP events on the stage's own stream" +
+                              ("; in the pipelined schedule encode+decode (stream D) and transformer (stream T) overlap" if args.schedule == "pipelined" else ""),
                 "roofline": {"kernel": ("conv2d_bf16x3_pc_kernel<TW,MB,NTY> + conv2d_bf16x3_kernel<TW,MB> (every instantiation: all conv launches)"
                                         if kind == "bf16x3" else "conv2d_mfma_kernel<TW,MB>"), "bound": "mfma",
                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                             "cu_share": (f"launches capped to {gen.last_cu_limit} of {n_cu} CUs while a token loop is in flight: against that share of the "
+                                          f"peak the fraction is {achieved / (peak * gen.last_cu_limit / n_cu):.4f}") if args.schedule == "pipelined" and gen.last_cu_limit else None,
                              "traffic": (conv_traffic(args, kind, n_conv) or {}).get("bytes_per_launch"),
                              "traffic_detail": conv_traffic(args, kind, n_conv),
                              "mfma_products_per_flop": products, "mfma_issue_frac": products * achieved / peak,

@@ -363,6 +363,204 @@ __global__ __launch_bounds__(512) void gemm16_rb_kernel(Gemm16 p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Compact forms of the decode GEMM (M <= 16 rows) for a SMALL grid: the same arithmetic as gemm16_kernel, in the same
+// order (bit-identical results), on N / (16 T) workgroups instead of N / 16 (x kz).
+//
+// Why: the decode step is a latency chain, not a bandwidth stream -- a launch that spreads 4-16 MB of weights over 256
+// workgroups keeps every CU of the chip busy for ~8 us with 64 KB each.  When the token loop of the next batch runs BESIDE
+// the frame decoder (Generator.run_pipelined) those launches and the decoder's convolutions evict each other from the
+// CUs all the time.  Here a workgroup takes T column tiles (gemm16t) or the whole K depth of one tile (gemm16d: what the
+// split-K form spreads over kz workgroups), with every weight load of the wave in flight before the first MFMA -- up to
+// 40 KB per wave, 320 KB per CU -- so that 64 workgroups stream the layer about as fast as 256 did and the other CUs stay
+// with the decoder.  The activations are fetched once per workgroup instead of once per tile, and the barrier / LDS
+// reduction is paid once per T tiles.
+//   gemm16t<T>: K = 8 x 128 (one 128-deep slice per wave), T tiles of 16 columns per workgroup; wave t finishes tile t.
+//   gemm16d<KB>: one tile, K = KB x 8 x 128; slice (kb, wave) starts at kb * K / KB + wave * 128, exactly the slice that
+//                workgroup z = kb, wave `wave` of the split-K form owns; partial sums are added in the same order.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void gemm16_finish(const Gemm16& p, f32x4 acc, int col, int g, float bv, float sn, const float (&rv)[4],
+                                              const float* fin, int pos0) {
+    // D[row = 4*g + r][col]
+    if (col >= p.N) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        if (row >= p.M) continue;
+        float v = acc[r];
+        if (p.ln_s) v = fin[row * 2 + 1] * (v - fin[row * 2] * sn);
+        v += bv;
+        if (p.epi == 1) v = gelu_erf(v);
+        if (p.epi == 2) v += rv[r];
+        if (p.kcache && col >= p.C) {
+            const int cc = col - p.C;
+            float* cache = cc >= p.C ? p.vcache : p.kcache;
+            const int c2 = cc >= p.C ? cc - p.C : cc;
+            const int h = c2 / p.D, d = c2 - h * p.D;
+            const int b = row / p.Tq, t = row - b * p.Tq;
+            if (pos0 + t < p.Tmax) cache[(((long)b * p.H + h) * p.Tmax + pos0 + t) * p.D + d] = v;
+        } else {
+            p.y[(long)row * p.ldy + col] = v;
+        }
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(512) void gemm16t_kernel(Gemm16 p) {
+    __shared__ __attribute__((aligned(16))) float red[T * 8 * 64 * 4];   // [tile][wave][lane][4]
+    __shared__ float stat[8 * 16 * 2];
+    __shared__ float fin[16 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int ncol0 = blockIdx.x * 16 * T;
+    const int mrow = min(li, p.M - 1);
+    const float* xp = p.x + (long)mrow * p.ldx + wave * 128 + 4 * g;
+    float4 wv[T][GEMM_U], xv[GEMM_U];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const float* wp = p.w + (long)min(ncol0 + 16 * t + li, p.N - 1) * p.K + wave * 128 + 4 * g;
+#pragma unroll
+        for (int u = 0; u < GEMM_U; ++u) wv[t][u] = *reinterpret_cast<const float4*>(wp + 16 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < GEMM_U; ++u) xv[u] = *reinterpret_cast<const float4*>(xp + 16 * u);
+    // wave t finishes tile t: its epilogue operands are requested now
+    const int col = ncol0 + 16 * min(wave, T - 1) + li;
+    float bv = 0.f, sn = 0.f, rv[4] = {0.f, 0.f, 0.f, 0.f};
+    int pos0 = p.pos0;
+    if (p.kcache && p.pos_dev) pos0 += *p.pos_dev;
+    if (wave < T) {
+        const int colc = min(col, p.N - 1);
+        if (p.bias) bv = p.bias[colc];
+        if (p.ln_s) sn = p.ln_s[colc];
+        if (p.epi == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rv[r] = p.res[(long)min(4 * g + r, p.M - 1) * p.ldy + colc];
+        }
+    }
+    float sx = 0.f, sxx = 0.f;
+    if (p.ln_s) {
+#pragma unroll
+        for (int u = 0; u < GEMM_U; ++u) ln_accum(xv[u], sx, sxx);
+        sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
+        sxx += __shfl_xor(sxx, 16, 64); sxx += __shfl_xor(sxx, 32, 64);
+        if (g == 0) { stat[(wave * 16 + li) * 2] = sx; stat[(wave * 16 + li) * 2 + 1] = sxx; }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < GEMM_U; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].x, wv[t][u].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].y, wv[t][u].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].z, wv[t][u].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].w, wv[t][u].w, acc1, 0, 0, 0);
+        }
+        *reinterpret_cast<f32x4*>(red + ((t * 8 + wave) * 64 + lane) * 4) = acc0 + acc1;
+    }
+    __syncthreads();
+    if (p.ln_s && tid < 16) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < 8; ++w) { a += stat[(w * 16 + tid) * 2]; b += stat[(w * 16 + tid) * 2 + 1]; }
+        const float mean = a / p.K;
+        const float var = fmaxf(b / p.K - mean * mean, 0.f);
+        fin[tid * 2] = mean;
+        fin[tid * 2 + 1] = rsqrtf(var + p.ln_eps);
+    }
+    __syncthreads();
+    if (wave >= T) return;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(red + ((wave * 8) * 64 + lane) * 4);
+#pragma unroll
+    for (int s2 = 1; s2 < 8; ++s2) acc += *reinterpret_cast<const f32x4*>(red + ((wave * 8 + s2) * 64 + lane) * 4);
+    gemm16_finish(p, acc, col, g, bv, sn, rv, fin, pos0);
+}
+
+template <int KB>
+__global__ __launch_bounds__(512) void gemm16d_kernel(Gemm16 p) {
+    __shared__ __attribute__((aligned(16))) float red[KB * 8 * 64 * 4];   // [kb][wave][lane][4]
+    __shared__ float stat[8 * 16 * 2];
+    __shared__ float fin[16 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int ncol0 = blockIdx.x * 16;
+    const int mrow = min(li, p.M - 1);
+    const int kstride = p.K / KB;
+    const float* xp = p.x + (long)mrow * p.ldx + wave * 128 + 4 * g;
+    const float* wp = p.w + (long)min(ncol0 + li, p.N - 1) * p.K + wave * 128 + 4 * g;
+    // two 128-deep slices in flight; slice kb + 2 is requested as soon as slice kb has been consumed
+    float4 wv[2][GEMM_U], xv[2][GEMM_U];
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {
+        if (b2 < KB) {
+#pragma unroll
+            for (int u = 0; u < GEMM_U; ++u) {
+                wv[b2][u] = *reinterpret_cast<const float4*>(wp + b2 * kstride + 16 * u);
+                xv[b2][u] = *reinterpret_cast<const float4*>(xp + b2 * kstride + 16 * u);
+            }
+        }
+    }
+    const int col = ncol0 + li;
+    float bv = 0.f, sn = 0.f, rv[4] = {0.f, 0.f, 0.f, 0.f};
+    int pos0 = p.pos0;
+    if (p.kcache && p.pos_dev) pos0 += *p.pos_dev;
+    if (wave == 0) {
+        const int colc = min(col, p.N - 1);
+        if (p.bias) bv = p.bias[colc];
+        if (p.ln_s) sn = p.ln_s[colc];
+        if (p.epi == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rv[r] = p.res[(long)min(4 * g + r, p.M - 1) * p.ldy + colc];
+        }
+    }
+    float sx = 0.f, sxx = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int b2 = kb & 1;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < GEMM_U; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b2][u].x, wv[b2][u].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b2][u].y, wv[b2][u].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b2][u].z, wv[b2][u].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b2][u].w, wv[b2][u].w, acc1, 0, 0, 0);
+            if (p.ln_s) ln_accum(xv[b2][u], sx, sxx);
+        }
+        *reinterpret_cast<f32x4*>(red + ((kb * 8 + wave) * 64 + lane) * 4) = acc0 + acc1;
+        if (kb + 2 < KB) {
+#pragma unroll
+            for (int u = 0; u < GEMM_U; ++u) {
+                wv[b2][u] = *reinterpret_cast<const float4*>(wp + (kb + 2) * kstride + 16 * u);
+                xv[b2][u] = *reinterpret_cast<const float4*>(xp + (kb + 2) * kstride + 16 * u);
+            }
+        }
+    }
+    if (p.ln_s) {
+        sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
+        sxx += __shfl_xor(sxx, 16, 64); sxx += __shfl_xor(sxx, 32, 64);
+        if (g == 0) { stat[(wave * 16 + li) * 2] = sx; stat[(wave * 16 + li) * 2 + 1] = sxx; }
+    }
+    __syncthreads();
+    if (p.ln_s && tid < 16) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < 8; ++w) { a += stat[(w * 16 + tid) * 2]; b += stat[(w * 16 + tid) * 2 + 1]; }
+        const float mean = a / p.K;
+        const float var = fmaxf(b / p.K - mean * mean, 0.f);
+        fin[tid * 2] = mean;
+        fin[tid * 2 + 1] = rsqrtf(var + p.ln_eps);
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    f32x4 acc;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {   // slice sums in the split-K form's order: ((z0 + z1) + z2) + ..., each z = w0 + w1 + ... + w7
+        f32x4 part = *reinterpret_cast<const f32x4*>(red + ((kb * 8) * 64 + lane) * 4);
+#pragma unroll
+        for (int s2 = 1; s2 < 8; ++s2) part += *reinterpret_cast<const f32x4*>(red + ((kb * 8 + s2) * 64 + lane) * 4);
+        acc = kb == 0 ? part : acc + part;
+    }
+    gemm16_finish(p, acc, col, g, bv, sn, rv, fin, pos0);
+}
+
 // K slices across workgroups (split-K): spreads GEMMs with few output columns over the chip.  Pays only for deep K:
 // the release/acquire hand-off costs ~3-4 us (measured).
 static int getenv_int(const char* name, int dflt) {
@@ -380,11 +578,35 @@ static int gemm_kz(const Gemm16& g) {
     return kz;
 }
 
-static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
+static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name, int tiles = -1) {
     if (!(g.x && g.w && g.y)) { ccvs_set_error("%s: null pointer", name); return CCVS_ERR_ARG; }
     if (!(g.M > 0 && g.N > 0 && g.K > 0)) { ccvs_set_error("%s: empty tensor", name); return CCVS_ERR_ARG; }
     if (g.K % 16 != 0 || g.ldx % 4 != 0) { ccvs_set_error("%s: K=%d must be a multiple of 16 (ldx %% 4 == 0)", name, g.K); return CCVS_ERR_ARG; }
     if (g.epi < 0 || g.epi > 2 || (g.epi == 2 && !g.res)) { ccvs_set_error("%s: bad epilogue", name); return CCVS_ERR_ARG; }
+    // compact forms (small grid) for the decode regime: M <= 16 rows, K a multiple of 8 x 128
+    static const int compact_env = getenv_int("CCVS_GEMM_COMPACT", 0);   // experiments: default for callers that do not say
+    const int compact = tiles >= 0 ? tiles : compact_env;               // 0: classic grid; T_max >= 1: up to T_max tiles per workgroup
+    if (compact > 0 && g.M <= 16 && g.N % 16 == 0) {
+        if (g.K == 1024) {
+            int T = 1;
+            for (int t = compact < 4 ? compact : 4; t > 1; --t)
+                if ((g.N / 16) % t == 0 && g.N / 16 / t >= 64) { T = t; break; }   // keep at least 64 workgroups
+            const dim3 grid(g.N / 16 / T);
+            g.kz = 1; g.ks = 8;
+            if (T == 4) hipLaunchKernelGGL((gemm16t_kernel<4>), grid, dim3(512), 0, st, g);
+            else if (T == 3) hipLaunchKernelGGL((gemm16t_kernel<3>), grid, dim3(512), 0, st, g);
+            else if (T == 2) hipLaunchKernelGGL((gemm16t_kernel<2>), grid, dim3(512), 0, st, g);
+            else hipLaunchKernelGGL((gemm16t_kernel<1>), grid, dim3(512), 0, st, g);
+            CCVS_CHECK_LAUNCH(name);
+            return CCVS_OK;
+        }
+        if (g.K == 4096 && !g.ln_s && gemm_kz(g) == 4) {   // the shape the split-K form spreads over 4 workgroups per tile
+            g.kz = 1; g.ks = 8;
+            hipLaunchKernelGGL((gemm16d_kernel<4>), dim3(g.N / 16), dim3(512), 0, st, g);
+            CCVS_CHECK_LAUNCH(name);
+            return CCVS_OK;
+        }
+    }
     g.kz = gemm_kz(g);
     g.ks = 8;
     while (g.ks > 1 && g.K % (16 * g.ks * g.kz) != 0) g.ks >>= 1;
@@ -469,65 +691,169 @@ extern "C" int ccvs_kv_append(const float* k, const float* v, int64_t sB, int64_
     return CCVS_OK;
 }
 
-// Prefill form: one workgroup per (batch, head, query).  Scores: one key per thread (row of D
-// floats, q broadcast from LDS); softmax over the L = pos0+t+1 visible keys; PV: lane = head
-// dim (coalesced V rows), 4 waves take keys round-robin and are summed through LDS.
+// Prefill form (Tq > 1): flash-style attention on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), exact fp32 products.
+//
+// A workgroup = 4 waves = 4 blocks of 32 queries of one (batch, head); the K / V rows of the cache are walked in tiles of
+// 32 keys staged ONCE per workgroup in LDS (K transposed to [d][key], V as [key][d]) and shared by its 128 queries.
+// Per wave and key tile:
+//   S^T = K . Q^T   (A = K tile from LDS, B = the wave's Q block held in registers, pre-scaled by 1/sqrt(D)): the 32x32
+//         accumulator layout gives every lane ONE query (column lane%32) and 16 of the 32 keys, so the causal mask, the
+//         running max / sum of the online softmax and the exponentials are per-lane register work plus one xor-32 shuffle;
+//   O^T += V^T . P^T   the probabilities are used as the B operand straight from the S accumulator registers: MFMA step
+//         j contracts over the key that accumulator register j holds in each lane half (the contraction order over keys
+//         is free), and the A operand reads the matching V row from LDS -- P never moves;
+//   O is rescaled by exp(m_old - m_new) when the running max moves.
+// Query t (position pos0 + t) sees keys 0 .. pos0 + t; tiles beyond a wave's last query are skipped by that wave.  Two
+// tile buffers: tile i+1 is fetched into registers before tile i is consumed and stored after it, one barrier per tile.
+// The result goes through LDS so that it is written with lanes along the head dimension (coalesced rows of `out`).
+// Replaces the softmax(QK^T / sqrt(d) masked) V of mingpt.py:67-77 for whole sequences (prefill, teacher-forced forward,
+// the re-prefill of a slid token window).
 template <int D>
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, long q_sB, long ldq, const float* __restrict__ kc,
-                                                        const float* __restrict__ vc, float* __restrict__ out, int H, int Tq, int pos0,
-                                                        const int32_t* __restrict__ pos_dev, int Tmax, float scale) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* qs = smem;            // [64]
-    float* red = smem + 64;      // [8]
-    float* pv = smem + 80;       // [4][64]
-    float* ps = smem + 80 + 256; // [L]
+__global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __restrict__ q, long q_sB, long ldq, const float* __restrict__ kc,
+                                                                const float* __restrict__ vc, float* __restrict__ out, int H, int Tq, int pos0,
+                                                                const int32_t* __restrict__ pos_dev, int Tmax, float scale) {
+    constexpr int MT = (D + 31) / 32;   // 32-row tiles of the head dimension in O^T
+    constexpr int DP = MT * 32;         // head dimension padded to the tile (zero columns of V)
+    constexpr int DK = D / 2;           // MFMA steps of S (K = 2 per step)
+    constexpr int KS = 33;              // row stride of the transposed K tile
+    constexpr int F4 = D / 4;           // float4 per cache row
+    constexpr int NLD = (32 * F4 + 255) / 256;  // float4 per thread and tile
+    constexpr int TILE_WORDS = D * KS + 32 * DP;
+    constexpr int OUT_WORDS = 128 * (D + 1);
+    constexpr int SMEM_WORDS = 2 * TILE_WORDS > OUT_WORDS ? 2 * TILE_WORDS : OUT_WORDS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = blockIdx.x % Tq;
-    const int bh = blockIdx.x / Tq;
-    const int b = bh / H, h = bh - b * H;
+    const int qi = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     if (pos_dev) pos0 += *pos_dev;
-    const int L = min(pos0 + t + 1, Tmax);
+    const int q0 = blockIdx.x * 128;                       // first query of the workgroup
+    const int qw = q0 + wave * 32;                         // first query of the wave
+    const int qidx = qw + qi;                              // this lane's query
+    const int q_last_wg = min(q0 + 127, Tq - 1), q_last_w = min(qw + 31, Tq - 1);
+    const int ntiles = (min(pos0 + q_last_wg + 1, Tmax) + 31) >> 5;
     const float* kbase = kc + (long)bh * Tmax * D;
     const float* vbase = vc + (long)bh * Tmax * D;
-    if (tid < D) qs[tid] = q[(long)b * q_sB + (long)t * ldq + h * D + tid];
-    __syncthreads();
 
-    float lmax = -INFINITY;
-    for (int j = tid; j < L; j += 256) {
-        const float4* kr = reinterpret_cast<const float4*>(kbase + (long)j * D);
-        float s = 0.f;
+    // Q block of the wave: lane holds Q[qidx][2i + half], i = 0 .. DK-1 (B operand of step i)
+    float qreg[DK];
+    {
+        const float* qp = q + (long)b * q_sB + (long)min(qidx, Tq - 1) * ldq + h * D + half;
 #pragma unroll
-        for (int i = 0; i < D / 4; ++i) {
-            const float4 kv = kr[i];
-            const float4 qv = *reinterpret_cast<const float4*>(qs + 4 * i);
-            s += kv.x * qv.x + kv.y * qv.y + kv.z * qv.z + kv.w * qv.w;
+        for (int i = 0; i < DK; ++i) qreg[i] = (qidx < Tq) ? qp[2 * i] * scale : 0.f;
+    }
+    if (MT * 32 > D) {  // zero the padding columns of both V buffers once (D = 16)
+        for (int e = tid; e < 2 * 32 * (DP - D); e += 256) {
+            const int bsel = e / (32 * (DP - D)), r = e - bsel * 32 * (DP - D);
+            smem[bsel * TILE_WORDS + D * KS + (r / (DP - D)) * DP + D + r % (DP - D)] = 0.f;
         }
-        s *= scale;  // 1/sqrt(D)
-        ps[j] = s;
-        lmax = fmaxf(lmax, s);
     }
-    lmax = wave_max(lmax);
-    if (lane == 0) red[wave] = lmax;
+
+    float4 kreg[NLD], vreg[NLD];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) {
+            const int e = min(tid + 256 * r, 32 * F4 - 1);
+            const int key = e / F4, d4 = e - key * F4;
+            // cache rows >= pos0 + Tq have never been written: their scores are masked (select) but a 0 x NaN in the PV
+            // product would still poison the sum, so such rows are staged as zeros (and never read: the address is clamped)
+            const bool written = kt * 32 + key < pos0 + Tq;
+            const long row = min(kt * 32 + key, pos0 + Tq - 1);
+            const float4 kv = *reinterpret_cast<const float4*>(kbase + row * D + 4 * d4);
+            const float4 vv = *reinterpret_cast<const float4*>(vbase + row * D + 4 * d4);
+            kreg[r] = written ? kv : make_float4(0.f, 0.f, 0.f, 0.f);
+            vreg[r] = written ? vv : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int buf) {
+        float* kt_s = smem + buf * TILE_WORDS;
+        float* v_s = kt_s + D * KS;
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) {
+            const int e = tid + 256 * r;
+            if (e < 32 * F4) {
+                const int key = e / F4, d4 = e - key * F4;
+                kt_s[(4 * d4 + 0) * KS + key] = kreg[r].x;
+                kt_s[(4 * d4 + 1) * KS + key] = kreg[r].y;
+                kt_s[(4 * d4 + 2) * KS + key] = kreg[r].z;
+                kt_s[(4 * d4 + 3) * KS + key] = kreg[r].w;
+                *reinterpret_cast<float4*>(v_s + key * DP + 4 * d4) = vreg[r];
+            }
+        }
+    };
+
+    f32x16 acc_o[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[mt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    fetch(0);
+    __syncthreads();   // padding columns zeroed
+    stash(0);
     __syncthreads();
-    const float gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float lsum = 0.f;
-    for (int j = tid; j < L; j += 256) {
-        const float e = expf(ps[j] - gmax);
-        ps[j] = e;
-        lsum += e;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntiles) fetch(kt + 1);
+        const int key0 = kt * 32;
+        if (key0 <= pos0 + q_last_w && qw < Tq) {   // wave-uniform: this tile holds keys visible to the wave
+            const float* kt_s = smem + buf * TILE_WORDS;
+            const float* v_s = kt_s + D * KS;
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < DK; ++i) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kt_s[(2 * i + half) * KS + qi], qreg[i], s, 0, 0, 0);
+            // s[r] = S[query qidx][key key0 + 8*(r/4) + 4*half + r%4]
+            const int lim = pos0 + qidx - key0;   // keys with index <= lim are visible
+            float m_t = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = 8 * (r >> 2) + 4 * half + (r & 3);
+                s[r] = (kk <= lim && qidx < Tq) ? s[r] : -INFINITY;
+                m_t = fmaxf(m_t, s[r]);
+            }
+            m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
+            const float m_new = fmaxf(m_run, m_t);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;   // nothing visible yet: every p below is exp(-inf) = 0
+            const float alpha = expf(m_run - m_use);                   // m_run = -inf -> 0
+            float l_t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = expf(s[r] - m_use);
+                l_t += s[r];
+            }
+            l_t += __shfl_xor(l_t, 32, 64);
+            l_run = l_run * alpha + l_t;
+            m_run = m_new;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[mt][r] *= alpha;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int kk = 8 * (j >> 2) + 4 * half + (j & 3);
+                    acc_o[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v_s[kk * DP + mt * 32 + qi], s[j], acc_o[mt], 0, 0, 0);
+                }
+            }
+        }
+        if (kt + 1 < ntiles) stash(buf ^ 1);   // the other buffer: its last readers passed the barrier of the previous tile
+        __syncthreads();
     }
-    lsum = wave_sum(lsum);
-    if (lane == 0) red[4 + wave] = lsum;
+    // O[d][query] / l  ->  LDS [query][d]  ->  out rows (lanes along d)
+    float* o_s = smem;
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = mt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+            if (d < D) o_s[(wave * 32 + qi) * (D + 1) + d] = acc_o[mt][r] * inv;
+        }
     __syncthreads();
-    const float inv = 1.f / (((red[4] + red[5]) + red[6]) + red[7]);
-    float acc = 0.f;
-    if (lane < D)
-        for (int j = wave; j < L; j += 4) acc += ps[j] * vbase[(long)j * D + lane];
-    pv[wave * 64 + lane] = acc;
-    __syncthreads();
-    if (tid < D) {
-        const float o = ((pv[tid] + pv[64 + tid]) + pv[128 + tid]) + pv[192 + tid];
-        out[((long)b * Tq + t) * (H * D) + h * D + tid] = o * inv;
+    for (int e = tid; e < 128 * D; e += 256) {
+        const int ql = e / D, d = e - ql * D;
+        if (q0 + ql < Tq) out[((long)b * Tq + q0 + ql) * (H * D) + h * D + d] = o_s[ql * (D + 1) + d];
     }
 }
 
@@ -651,6 +977,7 @@ extern "C" int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const f
     CCVS_REQUIRE(q && kcache && vcache && out, "ccvs_attention: null pointer");
     CCVS_REQUIRE(D == 64 || D == 32 || D == 16, "ccvs_attention: head dim %d unsupported (16, 32, 64)", D);
     CCVS_REQUIRE(B > 0 && H > 0 && Tq > 0 && pos0 >= 0 && pos0 + Tq <= Tmax, "ccvs_attention: bad positions");
+    CCVS_REQUIRE((long)B * H <= 65535, "ccvs_attention: batch x heads %ld too large for one launch", (long)B * H);
     // with a device-side position the visible length is unknown to the host: size LDS for the whole cache
     const int maxL = pos_dev ? Tmax : pos0 + Tq;
     const float scale = 1.0f / sqrtf((float)D);
@@ -663,12 +990,10 @@ extern "C" int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const f
         else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
         else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
     } else {
-        const size_t smem = (size_t)(80 + 256 + maxL) * sizeof(float);
-        CCVS_REQUIRE(smem <= 64 * 1024, "ccvs_attention: sequence too long for the LDS score buffer");
-        const dim3 grid((unsigned)((long)B * H * Tq));
-        if (D == 64) hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(256), smem, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, pos_dev, Tmax, scale);
-        else if (D == 32) hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(256), smem, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, pos_dev, Tmax, scale);
-        else hipLaunchKernelGGL((attention_kernel<16>), grid, dim3(256), smem, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, pos_dev, Tmax, scale);
+        const dim3 grid((unsigned)cdiv(Tq, 128), (unsigned)(B * H));
+        if (D == 64) hipLaunchKernelGGL((attention_prefill_kernel<64>), grid, dim3(256), 0, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, pos_dev, Tmax, scale);
+        else if (D == 32) hipLaunchKernelGGL((attention_prefill_kernel<32>), grid, dim3(256), 0, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, pos_dev, Tmax, scale);
+        else hipLaunchKernelGGL((attention_prefill_kernel<16>), grid, dim3(256), 0, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, pos_dev, Tmax, scale);
     }
     CCVS_CHECK_LAUNCH("ccvs_attention");
     return CCVS_OK;
@@ -911,7 +1236,7 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream) {
         g.x = d->x; g.ldx = d->C; g.w = L.qkv_w; g.bias = L.qkv_b; g.y = d->q; g.ldy = d->C; g.M = d->B; g.N = 3 * d->C; g.K = d->C;
         g.ln_s = L.qkv_s; g.ln_eps = d->ln_eps;
         g.kcache = L.kcache; g.vcache = L.vcache; g.C = d->C; g.H = d->H; g.D = D; g.Tq = 1; g.Tmax = d->Tmax; g.pos0 = 0; g.pos_dev = d->len;
-        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(qkv)")) != CCVS_OK) return rc;
+        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(qkv)", d->gemm_tiles)) != CCVS_OK) return rc;
         {   // attention over the cache
             const dim3 grid((unsigned)(d->B * d->H));
             if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(512), smem_att, st, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, d->Tmax, scale);
@@ -922,21 +1247,21 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream) {
         g = Gemm16{};  // proj + residual (in place on x)
         g.x = d->att; g.ldx = d->C; g.w = L.proj_w; g.bias = L.proj_b; g.res = d->x; g.y = d->x; g.ldy = d->C; g.M = d->B; g.N = d->C; g.K = d->C; g.epi = 2;
         g.ws_slabs = ws_slabs; g.ws_count = ws_count;
-        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(proj)")) != CCVS_OK) return rc;
+        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(proj)", d->gemm_tiles)) != CCVS_OK) return rc;
         g = Gemm16{};  // ln2 + fc + GELU
         g.x = d->x; g.ldx = d->C; g.w = L.fc_w; g.bias = L.fc_b; g.y = d->h; g.ldy = d->F; g.M = d->B; g.N = d->F; g.K = d->C; g.epi = 1;
         g.ln_s = L.fc_s; g.ln_eps = d->ln_eps;
-        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(fc)")) != CCVS_OK) return rc;
+        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(fc)", d->gemm_tiles)) != CCVS_OK) return rc;
         g = Gemm16{};  // fc2 + residual (in place on x)
         g.x = d->h; g.ldx = d->F; g.w = L.fc2_w; g.bias = L.fc2_b; g.res = d->x; g.y = d->x; g.ldy = d->C; g.M = d->B; g.N = d->C; g.K = d->F; g.epi = 2;
         g.ws_slabs = ws_slabs; g.ws_count = ws_count;
-        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(fc2)")) != CCVS_OK) return rc;
+        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(fc2)", d->gemm_tiles)) != CCVS_OK) return rc;
     }
     {   // ln_f + head
         Gemm16 g = {};
         g.x = d->x; g.ldx = d->C; g.w = d->head_w; g.bias = d->head_b; g.y = d->logits; g.ldy = d->V; g.M = d->B; g.N = d->V; g.K = d->C;
         g.ln_s = d->head_s; g.ln_eps = d->ln_eps;
-        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(head)")) != CCVS_OK) return rc;
+        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(head)", d->gemm_tiles)) != CCVS_OK) return rc;
     }
     {   // pick + bookkeeping
         Advance adv = {};

@@ -16,7 +16,7 @@ same CPU generator stream the reference's CPU path would consume and uploaded; w
 import torch
 
 from .mingpt import GPT
-from ccvs_amd.tools.utils import to_cuda
+from ccvs_amd.tools.utils import to_cuda, drive
 from ccvs_amd.models import load_network, print_network
 from ccvs_amd import ops
 
@@ -42,6 +42,8 @@ class Transformer(torch.nn.Module):
         code, state_code, cond_code, delta_length_cond, vid_lbl = self.preprocess_input(data)
         if mode == 'inference':
             return self.generate_fake(code, state_code, cond_code, delta_length_cond, vid_lbl, total_len, show_progress)
+        if mode == 'inference_iter':   # (ccvs_amd) the same as a generator-style stage, see tools.utils.drive
+            return self.generate_fake_iter(code, state_code, cond_code, delta_length_cond, vid_lbl, total_len)
         if mode in ('transformer', 'eval_transformer'):
             raise NotImplementedError(f"mode '{mode}' (training loss) is outside the MI355X hot path")
         raise ValueError(f"mode '{mode}' is invalid")
@@ -76,23 +78,26 @@ class Transformer(torch.nn.Module):
         out[out < v[..., [-1]]] = -float('Inf')
         return out
 
-    @torch.no_grad()
     def generate_fake(self, code, state_code, cond_code, delta_length_cond, vid_lbl, total_len, show_progress=False):
+        return drive(self.generate_fake_iter(code, state_code, cond_code, delta_length_cond, vid_lbl, total_len))
+
+    @torch.no_grad()
+    def generate_fake_iter(self, code, state_code, cond_code, delta_length_cond, vid_lbl, total_len):
         """transformer_model.py:263-328, including the sliding token window for total_len > z_len (each slide restarts
         positions at 0, so the window is re-prefilled) and the ancillary (state / STFT) stream bookkeeping."""
         opt = self.opt
         use_state = 0 not in state_code.size()
         n_cond = cond_code.size(1) if 0 not in cond_code.size() else 0
         if total_len is None:
-            code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl)
+            code, state_code = yield from self.fill_code_iter(code, state_code, cond_code, delta_length_cond, vid_lbl)
             return {"code": code, "state_code": state_code}
         total_len = int(total_len)
         if total_len <= opt.z_len:
             add_len = total_len - code.size(1) - n_cond
             add_len -= min(state_code.size(1), opt.state_size * opt.num_blocks) if use_state else 0
-            code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl, add_len=add_len)
+            code, state_code = yield from self.fill_code_iter(code, state_code, cond_code, delta_length_cond, vid_lbl, add_len=add_len)
             return {"code": code, "state_code": state_code}
-        code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl)
+        code, state_code = yield from self.fill_code_iter(code, state_code, cond_code, delta_length_cond, vid_lbl)
         curr_len = opt.z_len
         i = 1
         while curr_len < total_len:
@@ -101,7 +106,8 @@ class Transformer(torch.nn.Module):
                 delta_length_cond = delta_length_cond - 1
             tmp_state_code = state_code[:, i * self.state_size:] if use_state else state_code
             tmp_code = code[:, i * self.size:]
-            pred_code, pred_state_code = self.fill_code(tmp_code, tmp_state_code, cond_code, delta_length_cond, vid_lbl, add_len=add_len)
+            pred_code, pred_state_code = yield from self.fill_code_iter(tmp_code, tmp_state_code, cond_code, delta_length_cond, vid_lbl,
+                                                                        add_len=add_len)
             delta_code = pred_code.size(1) - tmp_code.size(1)
             code = torch.cat([code, pred_code[:, -delta_code:]], dim=1)
             if use_state:
@@ -118,9 +124,12 @@ class Transformer(torch.nn.Module):
         q = torch.empty(b, v, dtype=torch.float32).exponential_(1, generator=self.generator)
         return q.to(device, non_blocking=True)
 
-    @torch.no_grad()
     def fill_code(self, code, state_code, cond_code, delta_length_cond, vid_lbl, add_len=None, show_progress=False):
-        """transformer_model.py:331-392 on the KV-cached engine."""
+        return drive(self.fill_code_iter(code, state_code, cond_code, delta_length_cond, vid_lbl, add_len))
+
+    @torch.no_grad()
+    def fill_code_iter(self, code, state_code, cond_code, delta_length_cond, vid_lbl, add_len=None):
+        """transformer_model.py:331-392 on the KV-cached engine (generator-style stage)."""
         opt = self.opt
         if getattr(opt, "beam_size", None) is not None:
             raise NotImplementedError("beam search is not on the MI355X path yet (SURVEY 8f)")
@@ -139,7 +148,7 @@ class Transformer(torch.nn.Module):
         if use_state:  # ancillary tokens: first state_num logits, their own sampling options (transformer_model.py:353-356)
             state_sampler = {"sample": bool(opt.sample_state), "top_k": opt.top_k_state, "temperature": float(opt.temperature_state),
                              "vocab": opt.state_num}
-        out = self.net_t.generate(code, add_len, cond_code if n_cond else None, delta_length_cond if n_cond else None,
+        out = yield from self.net_t.generate_iter(code, add_len, cond_code if n_cond else None, delta_length_cond if n_cond else None,
                                   sample=opt.sample, top_k=opt.top_k, temperature=opt.temperature, noise=self.sample_noise,
                                   host_noise=host_noise, trace=self.trace, use_graph=getattr(opt, "use_graph", True),
                                   state_code=state_code if use_state else None, state_sampler=state_sampler)

@@ -513,12 +513,16 @@ def sample_topk(logits, top_k, temperature, noise=None, out=None, philox=None):
     return out
 
 
+# `ccvs_gpt_decode.gemm_tiles` of the decode steps built from now on (0: whole-chip grids; 4: compact, ~64 CUs per launch).
+DECODE_GEMM_TILES = int(__import__("os").environ.get("CCVS_DECODE_GEMM_TILES", "0"))
+
+
 class GptDecodeStep:
     """A filled `ccvs_gpt_decode` descriptor (include/ccvs_hip.h) plus the tensors it points at.
     `launch()` enqueues one whole decode step on the current stream."""
 
     def __init__(self, layers, B, C, H, Tmax, ln_eps, tok_emb, pos_table, pos_off, head, tok, codes, widx, length,
-                 x, q, att, h, logits, noise, top_k, temperature, state, rng=False):
+                 x, q, att, h, logits, noise, top_k, temperature, state, rng=False, gemm_tiles=0):
         hw, hb, hs = head
         keep = [tok_emb, pos_table, hw, hb, hs, tok, codes, widx, length, x, q, att, h, logits, noise, state]
         for t in keep:
@@ -552,6 +556,7 @@ class GptDecodeStep:
         d.rng = 1 if (rng and noise is None) else 0
         d.top_k, d.temperature = 0 if top_k is None else int(top_k), float(temperature)
         d.workspace, d.state = _p(self.ws), _p(state)
+        d.gemm_tiles = int(gemm_tiles)
         self.desc, self._arr, self._keep = d, arr, keep
 
     def launch(self):

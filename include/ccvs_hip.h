@@ -271,6 +271,10 @@ typedef struct ccvs_gpt_decode {
     int32_t top_k; float temperature;
     void* workspace;                    /* ccvs_gemm_workspace_bytes(), zeroed once */
     int32_t* state;
+    int32_t gemm_tiles;                 /* 0: every GEMM as one 16-column tile per workgroup over the whole chip (fastest when the
+                                           step runs alone).  T >= 1: compact forms -- up to T tiles per workgroup (never fewer than
+                                           64 workgroups) and the split-K GEMM in one workgroup per tile: the step then needs ~64 CUs
+                                           and can run beside another stream's convolutions (ccvs_conv_desc.cu_limit).  Same bits. */
 } ccvs_gpt_decode;
 int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream);
 

@@ -511,3 +511,30 @@ def test_gemm_row_blocked_matches_plain(ops):
                 assert torch.equal(f[r0:r0 + 16], q)
         want = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x, (k,), gam, bet) @ w.t() + b)
         close(full[2], want, 5e-4)
+
+
+@pytest.mark.parametrize("D,B,H,Tq,pos0", [(64, 16, 16, 1024, 0), (64, 2, 3, 301, 0), (64, 2, 2, 97, 200), (32, 3, 2, 130, 5), (16, 2, 2, 33, 0),
+                                           (16, 1, 2, 2, 62)])
+def test_attention_prefill_mfma(ops, D, B, H, Tq, pos0):
+    """Flash-style prefill attention on the fp32 matrix cores (attention_prefill_kernel) against softmax(QK^T / sqrt(d)
+    masked) V of mingpt.py:67-77: the BAIR-size case T = 1024, D = 64, B = 16; ragged query counts (not multiples of the
+    32-query wave block / 128-query workgroup); queries that start at a cache offset (extend); the unwritten tail of the
+    cache filled with NaN must not leak into the result."""
+    torch.manual_seed(D + Tq)
+    Tmax = pos0 + Tq + 37
+    L = pos0 + Tq
+    kc = torch.full((B, H, Tmax, D), float("nan"))
+    vc = torch.full((B, H, Tmax, D), float("nan"))
+    kc[:, :, :L], vc[:, :, :L] = torch.randn(B, H, L, D), torch.randn(B, H, L, D)
+    qfull = torch.randn(B, Tq, 3 * H * D)          # q is a strided view, as in the fused QKV output
+    q = qfull[..., H * D:2 * H * D]
+    got = ops.attention(q.cuda(), kc.cuda(), vc.cuda(), pos0)
+    qh = q.reshape(B, Tq, H, D).transpose(1, 2).double()
+    att = (qh @ kc[:, :, :L].double().transpose(-2, -1)) / math.sqrt(D)
+    vis = torch.arange(L).view(1, L) <= (pos0 + torch.arange(Tq)).view(Tq, 1)
+    att = att.masked_fill(~vis, float("-inf")).softmax(-1)
+    want = (att @ vc[:, :, :L].double()).transpose(1, 2).reshape(B, Tq, H * D).float()
+    assert torch.isfinite(got).all()
+    close(got, want, 2e-5)
+    pos_dev = torch.tensor([pos0], dtype=torch.int32).cuda()      # device-resident offset
+    close(ops.attention(q.cuda(), kc.cuda(), vc.cuda(), 0, pos_dev), want, 2e-5)
