@@ -3,11 +3,19 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of Generator.generate_vid over one batch per GPU (BAIR 256x256, 1
-conditioning frame -> 15 synthesized frames, batch 16 per GPU: BASELINE.json configs[1]),
-frames already resident in HBM, ending with the RCCL all-gather of the uint8-packed clips.
+One "step" = one pass of the synthesis path over one batch per GPU (BAIR 256x256, 1
+conditioning frame -> 15 synthesized frames, batch 16 per GPU: BASELINE.json configs[1]):
+encode all frames, crop, token synthesis, flow-guided decode, uint8 pack, RCCL all-gather of
+the clips -- frames already resident in HBM when the clock starts.  K steps = K batches, timed
+from the first encode to the last gathered clip.  Two schedules of exactly that work:
+  pipelined (default)  two batches in flight per GPU: the token loop of batch i+1 on a
+                       high-priority stream beside the encoder / decoder of batch i
+                       (Generator.run_pipelined; bit-identical clips); fill and drain are inside
+                       the timed region;
+  serial               Generator.generate_vid batch after batch.
 Weights are random-init (the reference's initialisers), frames are seeded synthetic tensors.
 Rank 0 prints ONE JSON line; see DESIGN.md section "Measurement" for every field.
+`python bench.py --gpus N` without a torch.distributed environment starts the N ranks itself.
 """
 import argparse
 import contextlib
@@ -29,7 +37,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (de
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU (weak scaling)")
     ap.add_argument("--config", type=str, default="bair", choices=["bair", "kinetics"])
@@ -127,11 +135,12 @@ def cpu_baseline(gen, opt):
         t_dec3 = time.perf_counter() - t0
         t_dec2 = 0.5 * (t_dec1 + t_dec3)   # linear in the number of contexts
         ts = {}
-        for T in (64, 384, 768):
+        for T in (64, 384, 768, 576):      # 576 is NOT used by the fit below: it measures the fit's error
             idx = torch.randint(0, xopt.z_num, (1, T), generator=g)
             t0 = time.perf_counter()
             O.gpt_forward(nets["t"], xopt, idx)
             ts[T] = time.perf_counter() - t0
+        t_check = ts.pop(576)
     # decode: frame with k contexts costs a + b*k ; 1 cond frame (k=1) + 15 frames with k = 1..15
     b = max(t_dec2 - t_dec1, 0.0)
     a = max(t_dec1 - b, 0.0)
@@ -140,13 +149,69 @@ def cpu_baseline(gen, opt):
     import numpy as np
     coef = np.polyfit(np.array(list(ts.keys()), dtype=np.float64), np.array(list(ts.values())), 2)
     t_gpt = float(sum(np.polyval(coef, T) for T in range(64, 1024)))
+    fit_err = float(np.polyval(coef, 576)) / t_check - 1.0
     t_encode = 16 * t_enc
     total = t_encode + t_gpt + t_decode
     return {"value": 15.0 / total, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": (f"oracle on BAIR batch 1, extrapolated from {time.perf_counter() - t_all:.1f}s of CPU work: encoder 1 frame "
                        f"{t_enc:.2f}s, decoder 1 frame k=1 {t_dec1:.2f}s / k=3 {t_dec3:.2f}s, GPT forward T=64/384/768 "
-                       f"{ts[64]:.2f}/{ts[384]:.2f}/{ts[768]:.2f}s -> clip = encode {t_encode:.0f}s + no-cache token loop "
+                       f"{ts[64]:.2f}/{ts[384]:.2f}/{ts[768]:.2f}s (quadratic fit through these three; at the held-out T=576 the fit is "
+                       f"{100 * fit_err:+.1f}% off the measured {t_check:.2f}s) -> clip = encode {t_encode:.0f}s + no-cache token loop "
                        f"{t_gpt:.0f}s + decode {t_decode:.0f}s")}
+
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+@torch.no_grad()
+def decode_kernel_rooflines(gen, xopt, batch):
+    """HBM rooflines of the decode step's kernels (the token loop is a chain of weight / KV-cache streams): every GEMM
+    shape of a layer, the head and the cached attention at the mean cache length of the loop are captured `reps` times back
+    to back in a hipGraph and replayed between two HIP events (outside the timed region; the same weights are re-read by
+    every launch, so these are L2 / Infinity-Cache-warm figures for the small matrices -- the in-situ durations, where every
+    launch streams its own layer's weights from HBM, are in the rocprofv3 kernel stats under profiles/).  achieved = algorithmic bytes (weights, or keys + values) / average duration."""
+    from ccvs_amd import ops
+    net = gen.transformer_model.net_t
+    cfg = net.config
+    C, H, V = cfg.n_embd, cfg.n_head, net.head.weight.shape[0]
+    D = C // H
+    dev = net.head.weight.device
+    blk = net.blocks[len(net.blocks) // 2]
+    (qw, qb, qs), (fw, fb, fs) = blk.folded()
+    hw, hb, hs = net._head_packed()[1]
+    x = torch.randn(batch, C, device=dev)
+    h = torch.randn(batch, 4 * C, device=dev)
+    tmax = xopt.z_len
+    kc, vc = torch.randn(batch, H, tmax, D, device=dev), torch.randn(batch, H, tmax, D, device=dev)
+    t_mean = (xopt.cond_len + xopt.z_len) // 2
+    q3 = torch.randn(batch, 1, C, device=dev)
+    cases = [
+        ("gemm16 ln1+qkv (+KV scatter)", 4.0 * qw.numel(), lambda: ops.gemm_ln_qkv(x, qw, qb, qs, kc, vc, batch, 1, tmax - 1)),
+        ("gemm16 proj+residual", 4.0 * blk.attn.proj.weight.numel(), lambda: ops.gemm_nt(x, blk.attn.proj.weight, blk.attn.proj.bias, ops.EPI_RESIDUAL, residual=x)),
+        ("gemm16 ln2+fc+GELU", 4.0 * fw.numel(), lambda: ops.gemm_ln(x, fw, fb, fs, epilogue=ops.EPI_GELU)),
+        ("gemm16 fc2+residual (split-K)", 4.0 * blk.mlp[3].weight.numel(), lambda: ops.gemm_nt(h, blk.mlp[3].weight, blk.mlp[3].bias, ops.EPI_RESIDUAL, residual=x)),
+        ("gemm16 ln_f+head", 4.0 * hw.numel(), lambda: ops.gemm_ln(x, hw, hb, hs)),
+        (f"attention_decode_kernel<{D}> at cache length {t_mean}", 8.0 * batch * H * t_mean * D, lambda: ops.attention(q3, kc, vc, t_mean - 1)),
+    ]
+    out, reps = [], 100
+    for name, nbytes, fn in cases:
+        fn()
+        graph = torch.cuda.CUDAGraph()             # `reps` launches in one hipGraph: launch gaps as in the captured decode step
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            for _ in range(reps):
+                fn()
+        graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            graph.replay()
+        e1.record()
+        e1.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / (3 * reps)
+        gbps = nbytes / (us * 1e-6) / 1e9
+        out.append({"kernel": name, "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                    "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": us, "launches_timed": 3 * reps, "traffic": None})
+    return out
 
 
 def conv_traffic(args, kind, launches):
@@ -265,6 +330,8 @@ def main():
                              "cu_share": (f"launches capped to {gen.last_cu_limit} of {n_cu} CUs while a token loop is in flight: against that share of the "
                                           f"peak the fraction is {achieved / (peak * gen.last_cu_limit / n_cu):.4f}") if args.schedule == "pipelined" and gen.last_cu_limit else None,
                              "traffic": (conv_traffic(args, kind, n_conv) or {}).get("bytes_per_launch"),
+                             "traffic_note": "PMC counters cannot be read inside the timed run: FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc run of the "
+                                             "same convolutions (tools/pmc_conv_traffic.sh -> profiles/conv_traffic.json), not re-measured by this command",
                              "traffic_detail": conv_traffic(args, kind, n_conv),
                              "mfma_products_per_flop": products, "mfma_issue_frac": products * achieved / peak,
                              "vs_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
@@ -274,6 +341,19 @@ def main():
                              "clock_note": "GRBM cycles / time = 2.0 GHz under this kernel (power-limited), i.e. a 2083 TF/s bf16 ceiling",
                              "share_of_step_time": conv_ms * 1e-3 / elapsed},
             }
+            # the token loop as a whole, in situ: weights once per token + the keys and values of every layer, against the HBM peak
+            net_t = gen.transformer_model.net_t
+            n_tok = (xopt.vid_len * 64 - xopt.cond_len) if args.config == "bair" else (xopt.vid_len * 64 - xopt.cond_len)
+            w_bytes = 4.0 * sum(p_.numel() for n_, p_ in net_t.named_parameters() if n_.startswith("blocks.") and p_.dim() == 2) + 4.0 * net_t.head.weight.numel()
+            kv_bytes = 8.0 * args.batch * net_t.config.n_embd * len(net_t.blocks) * (xopt.cond_len + xopt.z_len) / 2
+            tok_ms = stage["transformer"] / args.steps / n_tok
+            line["roofline_token_loop"] = {
+                "kernel": "token loop (ccvs_gpt_decode_step replayed as a hipGraph: 5 x n_layer + 3 launches per token)", "bound": "hbm",
+                "achieved": (w_bytes + kv_bytes) / (tok_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": (w_bytes + kv_bytes) / (tok_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "ms_per_token": tok_ms, "tokens_per_clip": n_tok,
+                "algorithmic_bytes_per_token": w_bytes + kv_bytes, "weights_bytes": w_bytes, "mean_kv_bytes": kv_bytes,
+                "note": "HIP events on the token stream around the whole loop of the timed region (prefill of the conditioning frame included)"}
+            line["roofline_decode_kernels"] = decode_kernel_rooflines(gen, xopt, args.batch)
             if not args.no_cpu_baseline and args.config == "bair" and world == 1:   # rank 0 at N = 1 only
                 line["cpu_baseline"] = cpu_baseline(gen, opt)
             print(json.dumps(line))

@@ -29,6 +29,36 @@ void ccvs_set_error(const char* fmt, ...);
         }                                                                         \
     } while (0)
 
+// CU budget of a stream (ccvs_stream_cu_limit, misc.hip): 0 = the whole chip
+int ccvs_cu_limit_of(void* stream);
+
+// A 3-D grid of workgroups walked by a 1-D launch: workgroup w of the walk stands for block (w % nx, (w / nx) % ny,
+// w / (nx ny)) of the grid it replaces.  With a CU budget the launch is `cap` workgroups that stride over the `total`
+// blocks (a persistent grid); without one it is `total` workgroups that each take one block.
+struct GridWalk {
+    long total;
+    int nx, ny;
+};
+#define GRID_WALK_BEGIN(gw, bx, by, bz)                                              \
+    for (long w_ = blockIdx.x; w_ < (gw).total; w_ += gridDim.x) {                   \
+        const int bx = (int)(w_ % (gw).nx);                                          \
+        const long r_ = w_ / (gw).nx;                                                \
+        const int by = (int)(r_ % (gw).ny), bz = (int)(r_ / (gw).ny);
+#define GRID_WALK_END }
+
+static inline GridWalk grid_walk(long nx, long ny, long nz) {
+    GridWalk g;
+    g.total = nx * ny * nz; g.nx = (int)nx; g.ny = (int)ny;
+    return g;
+}
+// workgroups to launch for `blocks` blocks of work on `stream`: all of them, or cu_limit x per_cu persistent ones
+static inline unsigned limited_grid(long blocks, void* stream, int per_cu) {
+    const int lim = ccvs_cu_limit_of(stream);
+    const long cap = lim > 0 ? (long)lim * per_cu : blocks;
+    const long n = blocks < cap ? blocks : cap;
+    return (unsigned)(n < 1 ? 1 : (n > 0x7fffffffL ? 0x7fffffffL : n));
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -15,13 +15,15 @@
 template <int S>
 __global__ __launch_bounds__(256) void correlation7x7_kernel(const float* __restrict__ first, const float* __restrict__ second,
                                                              float* __restrict__ out, int C, int H, int W, int Ho, int Wo,
-                                                             int first_div, int lrelu, int tiles_x) {
+                                                             int first_div, int lrelu, int tiles_x, GridWalk gw) {
     constexpr int TH = 8, TW = 32;
     constexpr int IH = (TH - 1) * S + 6 * S + 1, IW = (TW - 1) * S + 6 * S + 1;
     __shared__ float bt[CORR_CC][IH * IW];
     const int tid = threadIdx.x;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int n = blockIdx.y;
+    GRID_WALK_BEGIN(gw, bx, by, bz)
+    (void)bz;
+    const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+    const int n = by;
     const int py = tid >> 5, px = tid & 31;
     const int oy = ty * TH + py, ox = tx * TW + px;
     const bool live = (oy < Ho && ox < Wo);
@@ -68,6 +70,7 @@ __global__ __launch_bounds__(256) void correlation7x7_kernel(const float* __rest
             o[(long)d * Ho * Wo] = v;
         }
     }
+    GRID_WALK_END   // (every channel chunk starts with a barrier: the next block's staging waits for this block's reads)
 }
 
 extern "C" int ccvs_correlation7x7(const float* first, const float* second, float* out, int32_t N, int32_t C, int32_t H, int32_t W,
@@ -75,15 +78,15 @@ extern "C" int ccvs_correlation7x7(const float* first, const float* second, floa
     CCVS_REQUIRE(first && second && out, "ccvs_correlation7x7: null pointer");
     CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && first_div >= 1, "ccvs_correlation7x7: bad shape");
     CCVS_REQUIRE(stride == 1 || stride == 2, "ccvs_correlation7x7: stride %d unsupported", stride);
-    CCVS_REQUIRE(N <= 65535, "ccvs_correlation7x7: batch too large");
     const int Ho = cdiv(H, stride), Wo = cdiv(W, stride);
     const int tiles_x = cdiv(Wo, 32), tiles_y = cdiv(Ho, 8);
-    dim3 grid(tiles_x * tiles_y, N);
+    const GridWalk gw = grid_walk((long)tiles_x * tiles_y, N, 1);
+    const dim3 grid(limited_grid(gw.total, stream, stride == 1 ? 8 : 4));
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1)
-        hipLaunchKernelGGL((correlation7x7_kernel<1>), grid, dim3(256), 0, st, first, second, out, C, H, W, Ho, Wo, first_div, lrelu, tiles_x);
+        hipLaunchKernelGGL((correlation7x7_kernel<1>), grid, dim3(256), 0, st, first, second, out, C, H, W, Ho, Wo, first_div, lrelu, tiles_x, gw);
     else
-        hipLaunchKernelGGL((correlation7x7_kernel<2>), grid, dim3(256), 0, st, first, second, out, C, H, W, Ho, Wo, first_div, lrelu, tiles_x);
+        hipLaunchKernelGGL((correlation7x7_kernel<2>), grid, dim3(256), 0, st, first, second, out, C, H, W, Ho, Wo, first_div, lrelu, tiles_x, gw);
     CCVS_CHECK_LAUNCH("ccvs_correlation7x7");
     return CCVS_OK;
 }
@@ -138,11 +141,12 @@ struct CtxList {
 
 __global__ __launch_bounds__(256) void backwarp_kernel(CtxList ctx, long x_sC,
                                                        const float* __restrict__ flow, long flow_sN, float mult,
-                                                       float* __restrict__ y, long y_sN, long y_sC, int C, int H, int W) {
+                                                       float* __restrict__ y, long y_sN, long y_sC, int C, int H, int W, GridWalk gw) {
     const int HW = H * W;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= HW) return;
-    const int n = blockIdx.z, c0 = blockIdx.y * WARP_CCH;
+    GRID_WALK_BEGIN(gw, bx, by, bz)
+    const int pix = bx * 256 + threadIdx.x;
+    if (pix >= HW) continue;
+    const int n = bz, c0 = by * WARP_CCH;
     const int jn = n % ctx.k;
     const float* x = ctx.p[jn] + (long)(n / ctx.k) * ctx.sN[jn];
     const int py = pix / W, px = pix - py * W;
@@ -151,6 +155,7 @@ __global__ __launch_bounds__(256) void backwarp_kernel(CtxList ctx, long x_sC,
     const int cend = min(c0 + WARP_CCH, C);
     for (int c = c0; c < cend; ++c)
         y[(long)n * y_sN + (long)c * y_sC + pix] = bilin_sample(x + (long)c * x_sC, b);
+    GRID_WALK_END
 }
 
 static int fill_ctx(CtxList& l, const ccvs_ctx_list* c, const char* name) {
@@ -167,12 +172,13 @@ static int fill_ctx(CtxList& l, const ccvs_ctx_list* c, const char* name) {
 extern "C" int ccvs_backwarp(const float* x, int64_t x_sN, int64_t x_sC, const float* flow, int64_t flow_sN, float flow_mult, float* y,
                              int64_t y_sN, int64_t y_sC, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
     CCVS_REQUIRE(x && flow && y, "ccvs_backwarp: null pointer");
-    CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535, "ccvs_backwarp: bad shape");
-    dim3 grid(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
+    CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "ccvs_backwarp: bad shape");
+    const GridWalk gw = grid_walk(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
+    const dim3 grid(limited_grid(gw.total, stream, 8));
     CtxList l = {};
     l.k = 1; l.p[0] = x; l.sN[0] = (long)x_sN;
     hipLaunchKernelGGL(backwarp_kernel, grid, dim3(256), 0, (hipStream_t)stream, l, (long)x_sC, flow, (long)flow_sN, flow_mult, y,
-                       (long)y_sN, (long)y_sC, C, H, W);
+                       (long)y_sN, (long)y_sC, C, H, W, gw);
     CCVS_CHECK_LAUNCH("ccvs_backwarp");
     return CCVS_OK;
 }
@@ -183,10 +189,11 @@ extern "C" int ccvs_backwarp_ctx(const ccvs_ctx_list* ctx, int64_t x_sC, const f
     CtxList l = {};
     const int rc = fill_ctx(l, ctx, "ccvs_backwarp_ctx");
     if (rc != CCVS_OK) return rc;
-    CCVS_REQUIRE(N > 0 && N % l.k == 0 && C > 0 && H > 0 && W > 0 && N <= 65535, "ccvs_backwarp_ctx: bad shape");
-    dim3 grid(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
+    CCVS_REQUIRE(N > 0 && N % l.k == 0 && C > 0 && H > 0 && W > 0, "ccvs_backwarp_ctx: bad shape");
+    const GridWalk gw = grid_walk(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
+    const dim3 grid(limited_grid(gw.total, stream, 8));
     hipLaunchKernelGGL(backwarp_kernel, grid, dim3(256), 0, (hipStream_t)stream, l, (long)x_sC, flow, (long)flow_sN, flow_mult, y,
-                       (long)y_sN, (long)y_sC, C, H, W);
+                       (long)y_sN, (long)y_sC, C, H, W, gw);
     CCVS_CHECK_LAUNCH("ccvs_backwarp_ctx");
     return CCVS_OK;
 }
@@ -202,11 +209,12 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 __global__ __launch_bounds__(256) void warp_fuse_blend_kernel(float* __restrict__ dec, long dec_sN, long dec_sC,
                                                               CtxList ctx, const float* __restrict__ flows,
                                                               long flows_sN, const float* __restrict__ occs, long occs_sN,
-                                                              float mult, int k, int C, int H, int W) {
+                                                              float mult, int k, int C, int H, int W, GridWalk gw) {
     const int HW = H * W;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= HW) return;
-    const int n = blockIdx.z, c0 = blockIdx.y * WARP_CCH;
+    GRID_WALK_BEGIN(gw, bx, by, bz)
+    const int pix = bx * 256 + threadIdx.x;
+    if (pix >= HW) continue;
+    const int n = bz, c0 = by * WARP_CCH;
     const int py = pix / W, px = pix - py * W;
     const int cn = min(WARP_CCH, C - c0);
     float acc[WARP_CCH];
@@ -236,20 +244,22 @@ __global__ __launch_bounds__(256) void warp_fuse_blend_kernel(float* __restrict_
             *d = m * (*d) + (1.f - m) * wv;
         }
     }
+    GRID_WALK_END
 }
 
 extern "C" int ccvs_warp_fuse_blend(float* dec, int64_t dec_sN, int64_t dec_sC, const float* ctx, const float* flows, int64_t flows_sN,
                                     const float* occs, int64_t occs_sN, float flow_mult, int32_t N, int32_t k, int32_t C, int32_t H,
                                     int32_t W, void* stream) {
     CCVS_REQUIRE(dec && ctx && flows && occs, "ccvs_warp_fuse_blend: null pointer");
-    CCVS_REQUIRE(N > 0 && k > 0 && C > 0 && H > 0 && W > 0 && N <= 65535, "ccvs_warp_fuse_blend: bad shape");
-    dim3 grid(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
+    CCVS_REQUIRE(N > 0 && k > 0 && C > 0 && H > 0 && W > 0, "ccvs_warp_fuse_blend: bad shape");
+    const GridWalk gw = grid_walk(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
+    const dim3 grid(limited_grid(gw.total, stream, 8));
     CCVS_REQUIRE(k <= CCVS_MAX_CTX, "ccvs_warp_fuse_blend: at most %d contexts", CCVS_MAX_CTX);
     CtxList l = {};
     l.k = k;
     for (int j = 0; j < k; ++j) { l.p[j] = ctx + (long)j * C * H * W; l.sN[j] = (long)k * C * H * W; }
     hipLaunchKernelGGL(warp_fuse_blend_kernel, grid, dim3(256), 0, (hipStream_t)stream, dec, (long)dec_sN, (long)dec_sC, l, flows,
-                       (long)flows_sN, occs, (long)occs_sN, flow_mult, k, C, H, W);
+                       (long)flows_sN, occs, (long)occs_sN, flow_mult, k, C, H, W, gw);
     CCVS_CHECK_LAUNCH("ccvs_warp_fuse_blend");
     return CCVS_OK;
 }
@@ -261,10 +271,11 @@ extern "C" int ccvs_warp_fuse_blend_ctx(float* dec, int64_t dec_sN, int64_t dec_
     CtxList l = {};
     const int rc = fill_ctx(l, ctx, "ccvs_warp_fuse_blend_ctx");
     if (rc != CCVS_OK) return rc;
-    CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535, "ccvs_warp_fuse_blend_ctx: bad shape");
-    dim3 grid(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
+    CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "ccvs_warp_fuse_blend_ctx: bad shape");
+    const GridWalk gw = grid_walk(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
+    const dim3 grid(limited_grid(gw.total, stream, 8));
     hipLaunchKernelGGL(warp_fuse_blend_kernel, grid, dim3(256), 0, (hipStream_t)stream, dec, (long)dec_sN, (long)dec_sC, l, flows,
-                       (long)flows_sN, occs, (long)occs_sN, flow_mult, l.k, C, H, W);
+                       (long)flows_sN, occs, (long)occs_sN, flow_mult, l.k, C, H, W, gw);
     CCVS_CHECK_LAUNCH("ccvs_warp_fuse_blend_ctx");
     return CCVS_OK;
 }
@@ -304,7 +315,7 @@ extern "C" int ccvs_tap_shift_add(const float* t, const float* bias, float* y, i
     CCVS_REQUIRE(t && y, "ccvs_tap_shift_add: null pointer");
     CCVS_REQUIRE(N > 0 && k >= 1 && k <= 9 && H > 0 && W > 0, "ccvs_tap_shift_add: bad shape");
     const long total = (long)N * 3 * H * W;
-    const int blocks = (int)(cdiv64(total, 256) < 65536 * 16 ? cdiv64(total, 256) : 65536 * 16);
+    const unsigned blocks = limited_grid(cdiv64(total, 256) < 65536 * 16 ? cdiv64(total, 256) : 65536 * 16, stream, 8);
     hipLaunchKernelGGL(tap_shift_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, bias, y, (long)y_sN, total, k, H, W, accumulate,
                        vertical ? 1 : 0);
     CCVS_CHECK_LAUNCH("ccvs_tap_shift_add");

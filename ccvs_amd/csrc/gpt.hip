@@ -109,19 +109,23 @@ struct Gemm16 {
 #define GEMM_U 8  // K steps (of 16) whose loads are issued together
 #define GEMM_WS_TILES 128  // output tiles a workspace covers (split-K is only used when tiles <= this)
 
-__global__ __launch_bounds__(512) void gemm16_kernel(Gemm16 p) {
+// The operands of the address arithmetic come first and as plain kernel arguments: with -mllvm
+// -amdgpu-kernarg-preload-count they are delivered in SGPRs when the wave starts (gfx950 kernarg preload), so the weight
+// and activation loads of this latency-bound kernel go out without first waiting for a scalar load of the argument block.
+__global__ __launch_bounds__(512) void gemm16_kernel(const float* __restrict__ x_, const float* __restrict__ w_, long ldx_, int K_, int N_,
+                                                     int M_, int ks_, int kz_, Gemm16 p) {
     __shared__ __attribute__((aligned(16))) float red[7 * 64 * 4];
     __shared__ float stat[8 * 16 * 2];
     __shared__ float fin[16 * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.y * 16, ncol0 = blockIdx.x * 16;
-    const int nrow = min(ncol0 + li, p.N - 1), mrow = min(m0 + li, p.M - 1);  // tails: computed on a valid row, dropped at the store
-    const int kper = p.K / (p.ks * p.kz);
-    const int kbase = blockIdx.z * (p.K / p.kz);
-    const bool active = wave < p.ks;
-    const float* wp = p.w + (long)nrow * p.K + kbase + (active ? wave : 0) * kper + 4 * g;
-    const float* xp = p.x + (long)mrow * p.ldx + kbase + (active ? wave : 0) * kper + 4 * g;
+    const int nrow = min(ncol0 + li, N_ - 1), mrow = min(m0 + li, M_ - 1);  // tails: computed on a valid row, dropped at the store
+    const int kper = K_ / (ks_ * kz_);
+    const int kbase = blockIdx.z * (K_ / kz_);
+    const bool active = wave < ks_;
+    const float* wp = w_ + (long)nrow * K_ + kbase + (active ? wave : 0) * kper + 4 * g;
+    const float* xp = x_ + (long)mrow * ldx_ + kbase + (active ? wave : 0) * kper + 4 * g;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float sx = 0.f, sxx = 0.f;
 
@@ -363,204 +367,6 @@ __global__ __launch_bounds__(512) void gemm16_rb_kernel(Gemm16 p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Compact forms of the decode GEMM (M <= 16 rows) for a SMALL grid: the same arithmetic as gemm16_kernel, in the same
-// order (bit-identical results), on N / (16 T) workgroups instead of N / 16 (x kz).
-//
-// Why: the decode step is a latency chain, not a bandwidth stream -- a launch that spreads 4-16 MB of weights over 256
-// workgroups keeps every CU of the chip busy for ~8 us with 64 KB each.  When the token loop of the next batch runs BESIDE
-// the frame decoder (Generator.run_pipelined) those launches and the decoder's convolutions evict each other from the
-// CUs all the time.  Here a workgroup takes T column tiles (gemm16t) or the whole K depth of one tile (gemm16d: what the
-// split-K form spreads over kz workgroups), with every weight load of the wave in flight before the first MFMA -- up to
-// 40 KB per wave, 320 KB per CU -- so that 64 workgroups stream the layer about as fast as 256 did and the other CUs stay
-// with the decoder.  The activations are fetched once per workgroup instead of once per tile, and the barrier / LDS
-// reduction is paid once per T tiles.
-//   gemm16t<T>: K = 8 x 128 (one 128-deep slice per wave), T tiles of 16 columns per workgroup; wave t finishes tile t.
-//   gemm16d<KB>: one tile, K = KB x 8 x 128; slice (kb, wave) starts at kb * K / KB + wave * 128, exactly the slice that
-//                workgroup z = kb, wave `wave` of the split-K form owns; partial sums are added in the same order.
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void gemm16_finish(const Gemm16& p, f32x4 acc, int col, int g, float bv, float sn, const float (&rv)[4],
-                                              const float* fin, int pos0) {
-    // D[row = 4*g + r][col]
-    if (col >= p.N) return;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 4 * g + r;
-        if (row >= p.M) continue;
-        float v = acc[r];
-        if (p.ln_s) v = fin[row * 2 + 1] * (v - fin[row * 2] * sn);
-        v += bv;
-        if (p.epi == 1) v = gelu_erf(v);
-        if (p.epi == 2) v += rv[r];
-        if (p.kcache && col >= p.C) {
-            const int cc = col - p.C;
-            float* cache = cc >= p.C ? p.vcache : p.kcache;
-            const int c2 = cc >= p.C ? cc - p.C : cc;
-            const int h = c2 / p.D, d = c2 - h * p.D;
-            const int b = row / p.Tq, t = row - b * p.Tq;
-            if (pos0 + t < p.Tmax) cache[(((long)b * p.H + h) * p.Tmax + pos0 + t) * p.D + d] = v;
-        } else {
-            p.y[(long)row * p.ldy + col] = v;
-        }
-    }
-}
-
-template <int T>
-__global__ __launch_bounds__(512) void gemm16t_kernel(Gemm16 p) {
-    __shared__ __attribute__((aligned(16))) float red[T * 8 * 64 * 4];   // [tile][wave][lane][4]
-    __shared__ float stat[8 * 16 * 2];
-    __shared__ float fin[16 * 2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, g = lane >> 4;
-    const int ncol0 = blockIdx.x * 16 * T;
-    const int mrow = min(li, p.M - 1);
-    const float* xp = p.x + (long)mrow * p.ldx + wave * 128 + 4 * g;
-    float4 wv[T][GEMM_U], xv[GEMM_U];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const float* wp = p.w + (long)min(ncol0 + 16 * t + li, p.N - 1) * p.K + wave * 128 + 4 * g;
-#pragma unroll
-        for (int u = 0; u < GEMM_U; ++u) wv[t][u] = *reinterpret_cast<const float4*>(wp + 16 * u);
-    }
-#pragma unroll
-    for (int u = 0; u < GEMM_U; ++u) xv[u] = *reinterpret_cast<const float4*>(xp + 16 * u);
-    // wave t finishes tile t: its epilogue operands are requested now
-    const int col = ncol0 + 16 * min(wave, T - 1) + li;
-    float bv = 0.f, sn = 0.f, rv[4] = {0.f, 0.f, 0.f, 0.f};
-    int pos0 = p.pos0;
-    if (p.kcache && p.pos_dev) pos0 += *p.pos_dev;
-    if (wave < T) {
-        const int colc = min(col, p.N - 1);
-        if (p.bias) bv = p.bias[colc];
-        if (p.ln_s) sn = p.ln_s[colc];
-        if (p.epi == 2) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rv[r] = p.res[(long)min(4 * g + r, p.M - 1) * p.ldy + colc];
-        }
-    }
-    float sx = 0.f, sxx = 0.f;
-    if (p.ln_s) {
-#pragma unroll
-        for (int u = 0; u < GEMM_U; ++u) ln_accum(xv[u], sx, sxx);
-        sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
-        sxx += __shfl_xor(sxx, 16, 64); sxx += __shfl_xor(sxx, 32, 64);
-        if (g == 0) { stat[(wave * 16 + li) * 2] = sx; stat[(wave * 16 + li) * 2 + 1] = sxx; }
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < GEMM_U; ++u) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].x, wv[t][u].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].y, wv[t][u].y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].z, wv[t][u].z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].w, wv[t][u].w, acc1, 0, 0, 0);
-        }
-        *reinterpret_cast<f32x4*>(red + ((t * 8 + wave) * 64 + lane) * 4) = acc0 + acc1;
-    }
-    __syncthreads();
-    if (p.ln_s && tid < 16) {
-        float a = 0.f, b = 0.f;
-        for (int w = 0; w < 8; ++w) { a += stat[(w * 16 + tid) * 2]; b += stat[(w * 16 + tid) * 2 + 1]; }
-        const float mean = a / p.K;
-        const float var = fmaxf(b / p.K - mean * mean, 0.f);
-        fin[tid * 2] = mean;
-        fin[tid * 2 + 1] = rsqrtf(var + p.ln_eps);
-    }
-    __syncthreads();
-    if (wave >= T) return;
-    f32x4 acc = *reinterpret_cast<const f32x4*>(red + ((wave * 8) * 64 + lane) * 4);
-#pragma unroll
-    for (int s2 = 1; s2 < 8; ++s2) acc += *reinterpret_cast<const f32x4*>(red + ((wave * 8 + s2) * 64 + lane) * 4);
-    gemm16_finish(p, acc, col, g, bv, sn, rv, fin, pos0);
-}
-
-template <int KB>
-__global__ __launch_bounds__(512) void gemm16d_kernel(Gemm16 p) {
-    __shared__ __attribute__((aligned(16))) float red[KB * 8 * 64 * 4];   // [kb][wave][lane][4]
-    __shared__ float stat[8 * 16 * 2];
-    __shared__ float fin[16 * 2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, g = lane >> 4;
-    const int ncol0 = blockIdx.x * 16;
-    const int mrow = min(li, p.M - 1);
-    const int kstride = p.K / KB;
-    const float* xp = p.x + (long)mrow * p.ldx + wave * 128 + 4 * g;
-    const float* wp = p.w + (long)min(ncol0 + li, p.N - 1) * p.K + wave * 128 + 4 * g;
-    // two 128-deep slices in flight; slice kb + 2 is requested as soon as slice kb has been consumed
-    float4 wv[2][GEMM_U], xv[2][GEMM_U];
-#pragma unroll
-    for (int b2 = 0; b2 < 2; ++b2) {
-        if (b2 < KB) {
-#pragma unroll
-            for (int u = 0; u < GEMM_U; ++u) {
-                wv[b2][u] = *reinterpret_cast<const float4*>(wp + b2 * kstride + 16 * u);
-                xv[b2][u] = *reinterpret_cast<const float4*>(xp + b2 * kstride + 16 * u);
-            }
-        }
-    }
-    const int col = ncol0 + li;
-    float bv = 0.f, sn = 0.f, rv[4] = {0.f, 0.f, 0.f, 0.f};
-    int pos0 = p.pos0;
-    if (p.kcache && p.pos_dev) pos0 += *p.pos_dev;
-    if (wave == 0) {
-        const int colc = min(col, p.N - 1);
-        if (p.bias) bv = p.bias[colc];
-        if (p.ln_s) sn = p.ln_s[colc];
-        if (p.epi == 2) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rv[r] = p.res[(long)min(4 * g + r, p.M - 1) * p.ldy + colc];
-        }
-    }
-    float sx = 0.f, sxx = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        const int b2 = kb & 1;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < GEMM_U; ++u) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b2][u].x, wv[b2][u].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b2][u].y, wv[b2][u].y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b2][u].z, wv[b2][u].z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b2][u].w, wv[b2][u].w, acc1, 0, 0, 0);
-            if (p.ln_s) ln_accum(xv[b2][u], sx, sxx);
-        }
-        *reinterpret_cast<f32x4*>(red + ((kb * 8 + wave) * 64 + lane) * 4) = acc0 + acc1;
-        if (kb + 2 < KB) {
-#pragma unroll
-            for (int u = 0; u < GEMM_U; ++u) {
-                wv[b2][u] = *reinterpret_cast<const float4*>(wp + (kb + 2) * kstride + 16 * u);
-                xv[b2][u] = *reinterpret_cast<const float4*>(xp + (kb + 2) * kstride + 16 * u);
-            }
-        }
-    }
-    if (p.ln_s) {
-        sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
-        sxx += __shfl_xor(sxx, 16, 64); sxx += __shfl_xor(sxx, 32, 64);
-        if (g == 0) { stat[(wave * 16 + li) * 2] = sx; stat[(wave * 16 + li) * 2 + 1] = sxx; }
-    }
-    __syncthreads();
-    if (p.ln_s && tid < 16) {
-        float a = 0.f, b = 0.f;
-        for (int w = 0; w < 8; ++w) { a += stat[(w * 16 + tid) * 2]; b += stat[(w * 16 + tid) * 2 + 1]; }
-        const float mean = a / p.K;
-        const float var = fmaxf(b / p.K - mean * mean, 0.f);
-        fin[tid * 2] = mean;
-        fin[tid * 2 + 1] = rsqrtf(var + p.ln_eps);
-    }
-    __syncthreads();
-    if (wave > 0) return;
-    f32x4 acc;
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {   // slice sums in the split-K form's order: ((z0 + z1) + z2) + ..., each z = w0 + w1 + ... + w7
-        f32x4 part = *reinterpret_cast<const f32x4*>(red + ((kb * 8) * 64 + lane) * 4);
-#pragma unroll
-        for (int s2 = 1; s2 < 8; ++s2) part += *reinterpret_cast<const f32x4*>(red + ((kb * 8 + s2) * 64 + lane) * 4);
-        acc = kb == 0 ? part : acc + part;
-    }
-    gemm16_finish(p, acc, col, g, bv, sn, rv, fin, pos0);
-}
-
 // K slices across workgroups (split-K): spreads GEMMs with few output columns over the chip.  Pays only for deep K:
 // the release/acquire hand-off costs ~3-4 us (measured).
 static int getenv_int(const char* name, int dflt) {
@@ -578,35 +384,11 @@ static int gemm_kz(const Gemm16& g) {
     return kz;
 }
 
-static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name, int tiles = -1) {
+static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
     if (!(g.x && g.w && g.y)) { ccvs_set_error("%s: null pointer", name); return CCVS_ERR_ARG; }
     if (!(g.M > 0 && g.N > 0 && g.K > 0)) { ccvs_set_error("%s: empty tensor", name); return CCVS_ERR_ARG; }
     if (g.K % 16 != 0 || g.ldx % 4 != 0) { ccvs_set_error("%s: K=%d must be a multiple of 16 (ldx %% 4 == 0)", name, g.K); return CCVS_ERR_ARG; }
     if (g.epi < 0 || g.epi > 2 || (g.epi == 2 && !g.res)) { ccvs_set_error("%s: bad epilogue", name); return CCVS_ERR_ARG; }
-    // compact forms (small grid) for the decode regime: M <= 16 rows, K a multiple of 8 x 128
-    static const int compact_env = getenv_int("CCVS_GEMM_COMPACT", 0);   // experiments: default for callers that do not say
-    const int compact = tiles >= 0 ? tiles : compact_env;               // 0: classic grid; T_max >= 1: up to T_max tiles per workgroup
-    if (compact > 0 && g.M <= 16 && g.N % 16 == 0) {
-        if (g.K == 1024) {
-            int T = 1;
-            for (int t = compact < 4 ? compact : 4; t > 1; --t)
-                if ((g.N / 16) % t == 0 && g.N / 16 / t >= 64) { T = t; break; }   // keep at least 64 workgroups
-            const dim3 grid(g.N / 16 / T);
-            g.kz = 1; g.ks = 8;
-            if (T == 4) hipLaunchKernelGGL((gemm16t_kernel<4>), grid, dim3(512), 0, st, g);
-            else if (T == 3) hipLaunchKernelGGL((gemm16t_kernel<3>), grid, dim3(512), 0, st, g);
-            else if (T == 2) hipLaunchKernelGGL((gemm16t_kernel<2>), grid, dim3(512), 0, st, g);
-            else hipLaunchKernelGGL((gemm16t_kernel<1>), grid, dim3(512), 0, st, g);
-            CCVS_CHECK_LAUNCH(name);
-            return CCVS_OK;
-        }
-        if (g.K == 4096 && !g.ln_s && gemm_kz(g) == 4) {   // the shape the split-K form spreads over 4 workgroups per tile
-            g.kz = 1; g.ks = 8;
-            hipLaunchKernelGGL((gemm16d_kernel<4>), dim3(g.N / 16), dim3(512), 0, st, g);
-            CCVS_CHECK_LAUNCH(name);
-            return CCVS_OK;
-        }
-    }
     g.kz = gemm_kz(g);
     g.ks = 8;
     while (g.ks > 1 && g.K % (16 * g.ks * g.kz) != 0) g.ks >>= 1;
@@ -615,7 +397,7 @@ static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name, int tiles 
     if (g.kz == 1 && g.M >= 128 && rb_max >= 4)
         hipLaunchKernelGGL((gemm16_rb_kernel<4>), dim3(cdiv(g.N, 16), cdiv(g.M, 64), 1), dim3(512), 0, st, g);
     else
-        hipLaunchKernelGGL(gemm16_kernel, dim3(cdiv(g.N, 16), cdiv(g.M, 16), g.kz), dim3(512), 0, st, g);
+        hipLaunchKernelGGL(gemm16_kernel, dim3(cdiv(g.N, 16), cdiv(g.M, 16), g.kz), dim3(512), 0, st, g.x, g.w, g.ldx, g.K, g.N, g.M, g.ks, g.kz, g);
     CCVS_CHECK_LAUNCH(name);
     return CCVS_OK;
 }
@@ -1236,7 +1018,7 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream) {
         g.x = d->x; g.ldx = d->C; g.w = L.qkv_w; g.bias = L.qkv_b; g.y = d->q; g.ldy = d->C; g.M = d->B; g.N = 3 * d->C; g.K = d->C;
         g.ln_s = L.qkv_s; g.ln_eps = d->ln_eps;
         g.kcache = L.kcache; g.vcache = L.vcache; g.C = d->C; g.H = d->H; g.D = D; g.Tq = 1; g.Tmax = d->Tmax; g.pos0 = 0; g.pos_dev = d->len;
-        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(qkv)", d->gemm_tiles)) != CCVS_OK) return rc;
+        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(qkv)")) != CCVS_OK) return rc;
         {   // attention over the cache
             const dim3 grid((unsigned)(d->B * d->H));
             if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(512), smem_att, st, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, d->Tmax, scale);
@@ -1247,21 +1029,21 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream) {
         g = Gemm16{};  // proj + residual (in place on x)
         g.x = d->att; g.ldx = d->C; g.w = L.proj_w; g.bias = L.proj_b; g.res = d->x; g.y = d->x; g.ldy = d->C; g.M = d->B; g.N = d->C; g.K = d->C; g.epi = 2;
         g.ws_slabs = ws_slabs; g.ws_count = ws_count;
-        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(proj)", d->gemm_tiles)) != CCVS_OK) return rc;
+        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(proj)")) != CCVS_OK) return rc;
         g = Gemm16{};  // ln2 + fc + GELU
         g.x = d->x; g.ldx = d->C; g.w = L.fc_w; g.bias = L.fc_b; g.y = d->h; g.ldy = d->F; g.M = d->B; g.N = d->F; g.K = d->C; g.epi = 1;
         g.ln_s = L.fc_s; g.ln_eps = d->ln_eps;
-        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(fc)", d->gemm_tiles)) != CCVS_OK) return rc;
+        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(fc)")) != CCVS_OK) return rc;
         g = Gemm16{};  // fc2 + residual (in place on x)
         g.x = d->h; g.ldx = d->F; g.w = L.fc2_w; g.bias = L.fc2_b; g.res = d->x; g.y = d->x; g.ldy = d->C; g.M = d->B; g.N = d->C; g.K = d->F; g.epi = 2;
         g.ws_slabs = ws_slabs; g.ws_count = ws_count;
-        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(fc2)", d->gemm_tiles)) != CCVS_OK) return rc;
+        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(fc2)")) != CCVS_OK) return rc;
     }
     {   // ln_f + head
         Gemm16 g = {};
         g.x = d->x; g.ldx = d->C; g.w = d->head_w; g.bias = d->head_b; g.y = d->logits; g.ldy = d->V; g.M = d->B; g.N = d->V; g.K = d->C;
         g.ln_s = d->head_s; g.ln_eps = d->ln_eps;
-        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(head)", d->gemm_tiles)) != CCVS_OK) return rc;
+        if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(head)")) != CCVS_OK) return rc;
     }
     {   // pick + bookkeeping
         Advance adv = {};

@@ -12,7 +12,27 @@ void ccvs_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ccvs_last_error(void) { return g_err; }
-extern "C" int ccvs_abi_version(void) { return 1; }
+extern "C" int ccvs_abi_version(void) { return 2; }
+
+// Per-stream CU budgets: a handful of (stream, limit) pairs, written by the one host thread that drives the device.
+static struct { void* stream; int limit; } g_cu_limits[16];
+static int g_n_cu_limits = 0;
+
+extern "C" int ccvs_stream_cu_limit(void* stream, int32_t cu_limit) {
+    CCVS_REQUIRE(cu_limit >= 0, "ccvs_stream_cu_limit: negative limit");
+    for (int i = 0; i < g_n_cu_limits; ++i)
+        if (g_cu_limits[i].stream == stream) { g_cu_limits[i].limit = cu_limit; return CCVS_OK; }
+    CCVS_REQUIRE(g_n_cu_limits < 16, "ccvs_stream_cu_limit: more than 16 streams with a budget");
+    g_cu_limits[g_n_cu_limits].stream = stream;
+    g_cu_limits[g_n_cu_limits++].limit = cu_limit;
+    return CCVS_OK;
+}
+
+int ccvs_cu_limit_of(void* stream) {
+    for (int i = 0; i < g_n_cu_limits; ++i)
+        if (g_cu_limits[i].stream == stream) return g_cu_limits[i].limit;
+    return 0;
+}
 
 // save_video_batch (helpers/generator.py:306-309): clamp to [lo,hi], rescale to [0,1],
 // x255, truncate to uint8, NCHW -> NHWC.
@@ -36,7 +56,7 @@ extern "C" int ccvs_pack_u8(const float* vid, uint8_t* out, int64_t N, int32_t H
     CCVS_REQUIRE(vid && out, "ccvs_pack_u8: null pointer");
     CCVS_REQUIRE(N > 0 && H > 0 && W > 0 && hi > lo, "ccvs_pack_u8: bad arguments");
     const long total = (long)N * H * W;
-    const int blocks = (int)(cdiv64(total, 256) < 1048576 ? cdiv64(total, 256) : 1048576);
+    const unsigned blocks = limited_grid(cdiv64(total, 256) < 1048576 ? cdiv64(total, 256) : 1048576, stream, 8);
     hipLaunchKernelGGL(pack_u8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, vid, out, (long)N, H * W, lo, hi);
     CCVS_CHECK_LAUNCH("ccvs_pack_u8");
     return CCVS_OK;

@@ -55,12 +55,15 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(FirK p) {
 // outputs of one row with the separable 1-3-3-1 passes and writes them as one 16-byte store.
 #define BLUR_TH 16
 #define BLUR_TW 64
-__global__ __launch_bounds__(256) void blur4x4_tile_kernel(FirK p, int tiles_x) {
+__global__ __launch_bounds__(256) void blur4x4_tile_kernel(FirK p, int tiles_x, GridWalk gw) {
     __shared__ float tile[(BLUR_TH + 3) * (BLUR_TW + 4)];
     constexpr int IWp = BLUR_TW + 4, IH = BLUR_TH + 3, IW = BLUR_TW + 3;
     const int tid = threadIdx.x;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const long nc = blockIdx.y;
+    GRID_WALK_BEGIN(gw, bx, by, bz)
+    (void)bz;
+    const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+    const long nc = by;
+    if (w_ != (long)blockIdx.x) __syncthreads();   // persistent walk: the tile of the previous block has been read by everyone
     const float* xp = p.x + nc * (long)p.H * p.W;
     const int iy0 = ty * BLUR_TH - p.pad0, ix0 = tx * BLUR_TW - p.pad0;
     for (int e = tid; e < IH * IW; e += 256) {
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void blur4x4_tile_kernel(FirK p, int tiles_x) 
     __syncthreads();
     const int row = tid >> 4, col = (tid & 15) * 4;
     const int oy = ty * BLUR_TH + row, ox0 = tx * BLUR_TW + col;
-    if (oy >= p.Ho || ox0 >= p.Wo) return;
+    if (oy < p.Ho && ox0 < p.Wo) {
     float h[4][4];
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
@@ -100,6 +103,8 @@ __global__ __launch_bounds__(256) void blur4x4_tile_kernel(FirK p, int tiles_x) 
     } else {
         for (int o = 0; o < nv; ++o) p.y[oi + o] = (v[o] + (p.res ? p.res[oi + o] : 0.f)) * p.out_scale;
     }
+    }
+    GRID_WALK_END
 }
 
 // up = 2, down = 1, pad (2,1): the decoder's skip up-sampling.  On the zero-inserted grid only every
@@ -154,16 +159,17 @@ extern "C" int ccvs_upfirdn2d(const float* x, float* y, const float* residual, i
     CCVS_REQUIRE(k.Ho > 0 && k.Wo > 0, "ccvs_upfirdn2d: empty output");
     k.gain = gain; k.act = act; k.out_scale = out_scale;
     hipStream_t st = (hipStream_t)stream;
-    if (up == 1 && down == 1 && NC <= 65535) {
+    if (up == 1 && down == 1) {
         const int tiles_x = cdiv(k.Wo, BLUR_TW), tiles_y = cdiv(k.Ho, BLUR_TH);
-        hipLaunchKernelGGL(blur4x4_tile_kernel, dim3(tiles_x * tiles_y, (unsigned)NC), dim3(256), 0, st, k, tiles_x);
+        const GridWalk gw = grid_walk((long)tiles_x * tiles_y, NC, 1);
+        hipLaunchKernelGGL(blur4x4_tile_kernel, dim3(limited_grid(gw.total, stream, 8)), dim3(256), 0, st, k, tiles_x, gw);
     } else if (up == 2 && down == 1 && pad0 == 2 && pad1 == 1) {
         const long work = NC * (long)H * W;
-        const int blocks = (int)(cdiv64(work, 256) < 65536 * 16 ? cdiv64(work, 256) : 65536 * 16);
+        const unsigned blocks = limited_grid(cdiv64(work, 256) < 65536 * 16 ? cdiv64(work, 256) : 65536 * 16, stream, 8);
         hipLaunchKernelGGL(upsample2_kernel, dim3(blocks), dim3(256), 0, st, k);
     } else {
         const long work = NC * k.Ho * k.Wo;
-        const int blocks = (int)(cdiv64(work, 256) < 65536 * 16 ? cdiv64(work, 256) : 65536 * 16);
+        const unsigned blocks = limited_grid(cdiv64(work, 256) < 65536 * 16 ? cdiv64(work, 256) : 65536 * 16, stream, 8);
         hipLaunchKernelGGL(upfirdn2d_generic_kernel, dim3(blocks), dim3(256), 0, st, k);
     }
     CCVS_CHECK_LAUNCH("ccvs_upfirdn2d");
@@ -219,7 +225,7 @@ extern "C" int ccvs_dwconvT4x4s2(const float* x, int64_t x_sN, const float* w, f
     CCVS_REQUIRE(x && w && y, "ccvs_dwconvT4x4s2: null pointer");
     CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "ccvs_dwconvT4x4s2: empty tensor");
     const long work = (long)N * C * H * W;
-    const int blocks = (int)(cdiv64(work, 256) < 65536 * 16 ? cdiv64(work, 256) : 65536 * 16);
+    const unsigned blocks = limited_grid(cdiv64(work, 256) < 65536 * 16 ? cdiv64(work, 256) : 65536 * 16, stream, 8);
     hipLaunchKernelGGL(dwconvT4x4s2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)x_sN, w, y, (long)y_sN, (long)N, C, H, W);
     CCVS_CHECK_LAUNCH("ccvs_dwconvT4x4s2");
     return CCVS_OK;

@@ -25,7 +25,6 @@ from ccvs_amd.tools.engine import Engine
 from ccvs_amd.models.skip_vid_generator.models.quantized_video_model import QVidModel
 from ccvs_amd.models.skip_vid_generator.models.transformer_model import Transformer
 from ccvs_amd import ops
-from ccvs_amd.tools.utils import drive
 
 
 class Generator:
@@ -183,21 +182,6 @@ class Generator:
             fake_data.update(self.state_model({"state_code": state_code}, mode='vid_decoder'))
         return fake_data
 
-    def decode_codes_iter(self, ws, code, state_code=None):
-        """`decode_codes` as a generator-style stage (yields after every frame)."""
-        opt = self.opt
-        dec_in = dict(ws["cropped"])
-        dec_in["code"] = code
-        if state_code is not None:
-            dec_in["state_code"] = state_code
-        fake_data = yield from self.vid_model(dec_in, mode='vid_decoder_iter')
-        fake_data["code"], fake_data["state_code"] = code, state_code
-        if opt.p2p:
-            fake_data["vid"] = torch.cat([fake_data["vid"], ws["data"]["vid"][:, -1:]], dim=1)
-        if opt.state and state_code is not None:
-            fake_data.update(self.state_model({"state_code": state_code}, mode='vid_decoder'))
-        return fake_data
-
     @torch.no_grad()
     def reconstruct(self, ws):
         """The teacher-forced "rec" decode of the clip's own codes (generator.py:172-189)."""
@@ -259,21 +243,23 @@ class Generator:
 
     # ------------------------------------------------------------------ two batches in flight
     @torch.no_grad()
-    def run_pipelined(self, batches, first_iter=0, cu_limit=None, finish=None, tokens_per_turn=2):
+    def run_pipelined(self, batches, first_iter=0, cu_limit=None, finish=None):
         """generate_vid over a sequence of batches with TWO batches in flight: while the flow-guided decoder works on batch
         i (stream D: MFMA convolutions, large grids), the token loop of batch i+1 runs on a high-priority stream T (a
         latency-bound chain of ~120 small launches per token that cannot fill the chip by itself).  Per batch the work is
         exactly generate_vid's -- encode, crop, token synthesis, decode -- and so are the results (same kernels, same
         per-clip noise; tests/test_pipeline_gpu.py checks bit-equality with the serial schedule).
 
-        The convolutions on D are capped to `cu_limit` CUs (`ccvs_conv_desc.cu_limit`) while a token loop is in flight, so
-        its few-hundred-workgroup launches always find free CUs instead of queueing behind thousand-tile convolutions.
-        The host alternates between the two stages at their scheduling points (they are generator-style, tools.utils.drive):
-        `tokens_per_turn` chunks of token steps per decoded frame.
+        Everything on D is capped to `cu_limit` CUs (`ccvs_stream_cu_limit`) while a token loop is in flight, so its
+        few-hundred-workgroup launches always find free CUs instead of queueing behind thousand-tile kernels.
+        The token stage is enqueued by a worker thread: a hipGraph launch blocks the calling thread once the stream's
+        queue is full (a few dozen decode steps), and the decoder's launches must not wait behind that.  One token stage
+        at a time (the transformer's KV cache and sampler state are shared), in batch order.
 
         batches: iterable of data dicts.  finish(i, out) -> anything: called on stream D when batch i's clip is decoded
         (pack / all-gather); its return values are collected.  Returns the list of per-batch results
-        ({"fake", "enc_code", "finished"}); the rec pass is not run here."""
+        ({"fake", "enc_code", "finished", "index"}); the rec pass is not run here."""
+        import threading
         opt = self.opt
         if opt.step_by_step or opt.rec_only:
             raise NotImplementedError("run_pipelined covers the plain synthesis schedule (use generate_vid for step_by_step / rec_only)")
@@ -290,10 +276,12 @@ class Generator:
         results, timings = [], []
         it = iter(batches)
         index = first_iter
-        old_limit = ops.CONV_CU_LIMIT
+
+        def budget(n):   # CU budget of everything submitted to the decode stream from now on
+            ops.stream_cu_limit(s_dec, n)
 
         def start(data, i):
-            """encode + crop on D (full chip unless a token loop is in flight), then open the token stage on T."""
+            """encode + crop on D; returns the job of batch i (its token stage is opened by `launch_tokens`)."""
             ev = {k: torch.cuda.Event(enable_timing=True) for k in ("e0", "e1", "t0", "t1", "d0", "d1")}
             with torch.cuda.stream(s_dec):
                 ev["e0"].record()
@@ -302,40 +290,45 @@ class Generator:
             for t in (ws["cropped"]["code"], ws["cropped"].get("cond_code"), ws["cropped"].get("state_code")):
                 if torch.is_tensor(t) and t.is_cuda:
                     t.record_stream(s_tok)
-            with torch.cuda.stream(s_tok):
-                stage = self.transformer_model(ws["cropped"], mode='inference_iter', total_len=ws["total_len"])
-            return {"i": i, "ws": ws, "tok": stage, "ev": ev, "codes": None, "started": False, "batch": data["vid"].shape[0]}
+            return {"i": i, "ws": ws, "ev": ev, "codes": None, "error": None, "thread": None, "batch": data["vid"].shape[0]}
 
-        def step_tokens(job, n):
-            """advance the token stage of `job` by n scheduling points; True when it has finished."""
-            if job is None or job["tok"] is None:
-                return True
-            with torch.cuda.stream(s_tok):
-                if not job["started"]:   # the transformer (KV cache, sampler state) is shared: one token stage at a time, in order
-                    job["started"] = True
+        def token_stage(job):
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(s_tok), torch.no_grad():
                     s_tok.wait_event(job["ev"]["e1"])
                     self._seed_sampler(job["batch"], job["i"])
                     job["ev"]["t0"].record()
-                for _ in range(n):
-                    try:
-                        next(job["tok"])
-                    except StopIteration as stop:
-                        job["codes"], job["tok"] = stop.value, None
-                        job["ev"]["t1"].record()
-                        return True
-            return False
+                    job["codes"] = self.transformer_model(job["ws"]["cropped"], mode='inference', total_len=job["ws"]["total_len"])
+                    job["ev"]["t1"].record()
+            except BaseException as exc:   # re-raised by the main thread at the join
+                job["error"] = exc
 
+        def launch_tokens(job):
+            if not self.transformer_model.net_t._graphs:
+                token_stage(job)       # nothing captured yet: the hipGraph capture of the decode step runs with no other thread issuing HIP calls
+                return
+            job["thread"] = threading.Thread(target=token_stage, args=(job,), name=f"ccvs-tokens-{job['i']}")
+            job["thread"].start()
+
+        def join_tokens(job):
+            if job["thread"] is not None:
+                job["thread"].join()
+            if job["error"] is not None:
+                raise job["error"]
+
+        cur = None
         try:
-            cur = None
             while True:
                 data = next(it, None)
-                ops.CONV_CU_LIMIT = cu_limit if (cur is not None and cur["tok"] is not None) else 0
+                budget(cu_limit if cur is not None else 0)          # batch `cur`'s token loop is (still) in flight
                 nxt = start(data, index) if data is not None else None
                 index += 1
                 if cur is not None:
-                    # decode batch `cur` on D while batch `nxt`'s tokens are produced on T
-                    while not step_tokens(cur, 8):          # (first batch only: nothing to overlap its tokens with)
-                        pass
+                    join_tokens(cur)                                # all of its steps are enqueued: the transformer is free
+                if nxt is not None:
+                    launch_tokens(nxt)
+                if cur is not None:
                     s_dec.wait_event(cur["ev"]["t1"])
                     codes = cur["codes"]
                     state_code = codes.get("state_code")
@@ -344,22 +337,14 @@ class Generator:
                     for t in (codes["code"], state_code):
                         if torch.is_tensor(t):
                             t.record_stream(s_dec)
-                    ops.CONV_CU_LIMIT = cu_limit if nxt is not None else 0
+                    budget(cu_limit if nxt is not None else 0)
                     with torch.cuda.stream(s_dec):
                         cur["ev"]["d0"].record()
-                        dec = self.decode_codes_iter(cur["ws"], codes["code"], state_code)
-                    fake, done = None, None
-                    while fake is None:
-                        step_tokens(nxt, tokens_per_turn)
-                        with torch.cuda.stream(s_dec):
-                            try:
-                                next(dec)
-                            except StopIteration as stop:
-                                fake = stop.value
-                                cur["ev"]["d1"].record()
-                                done = finish(cur["i"], fake) if finish is not None else None
-                                for t in (fake["vid"], fake["code"]):   # handed to the caller's stream
-                                    t.record_stream(entry)
+                        fake = self.decode_codes(cur["ws"], codes["code"], state_code)
+                        cur["ev"]["d1"].record()
+                        done = finish(cur["i"], fake) if finish is not None else None
+                        for t in (fake["vid"], fake["code"]):   # handed to the caller's stream
+                            t.record_stream(entry)
                     results.append({"fake": fake, "enc_code": cur["ws"]["encoded"]["code"], "finished": done, "index": cur["i"]})
                     timings.append(cur["ev"])
                     cur["ws"] = None
@@ -367,7 +352,10 @@ class Generator:
                     break
                 cur = nxt
         finally:
-            ops.CONV_CU_LIMIT = old_limit
+            for job in (cur, locals().get("nxt")):
+                if job is not None and job.get("thread") is not None and job["thread"].is_alive():
+                    job["thread"].join()
+            budget(0)
         entry.wait_stream(s_dec)
         entry.wait_stream(s_tok)
         self._pipeline_events = timings

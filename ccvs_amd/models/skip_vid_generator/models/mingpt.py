@@ -16,7 +16,6 @@ import torch
 import torch.nn as nn
 
 from ccvs_amd import ops
-from ccvs_amd.tools.utils import drive
 
 
 class GPTConfig:
@@ -399,6 +398,15 @@ class GPT(nn.Module):
         return self._head(x)
 
     @torch.no_grad()
+    def reorder_cache(self, rows):
+        """Cache row r continues the sequence of old row rows[r] (beam-search pruning): gather of the filled part of every
+        layer's keys and values."""
+        c = self._cache
+        n = c["len"]
+        for cache in c["k"] + c["v"]:
+            cache[:, :, :n] = cache[rows, :, :n]
+
+    @torch.no_grad()
     def extend(self, rows):
         """Append tq >= 1 more positions (rows of `_token_table()`, [B,tq]) to the cache; logits of the last one [B,V]."""
         c = self._cache
@@ -418,7 +426,7 @@ class GPT(nn.Module):
         head_key, (hw, hb, hs) = self._head_packed()
         device_rng = sampler["sample"] and sampler["noise"] == "device"
         key = (tuple(blk._folded[0] for blk in self.blocks), head_key, sampler["sample"], sampler["top_k"],
-               sampler["temperature"], device_rng, c["frame_pos0"], ops.DECODE_GEMM_TILES)
+               sampler["temperature"], device_rng, c["frame_pos0"])
         if c["desc"] is None or c["desc"][0] != key:
             layers = []
             for i, blk in enumerate(self.blocks):
@@ -432,7 +440,7 @@ class GPT(nn.Module):
                 tok=c["tok"], codes=c["codes"], widx=c["widx"], length=c["len_dev"],
                 x=c["x"], q=c["q"], att=c["att"], h=c["h"], logits=c["logits"],
                 noise=c["noise"] if (sampler["sample"] and not device_rng) else None, rng=device_rng,
-                top_k=sampler["top_k"], temperature=sampler["temperature"], state=c["state"], gemm_tiles=ops.DECODE_GEMM_TILES)
+                top_k=sampler["top_k"], temperature=sampler["temperature"], state=c["state"])
             c["desc"] = (key, desc)
             self._graphs = {}   # captured graphs replay the OLD descriptor's pointers (packed weights are freed with it)
         return c["desc"][1]
@@ -482,8 +490,8 @@ class GPT(nn.Module):
         return graph
 
     @torch.no_grad()
-    def _generate_stream_iter(self, code, state_code, add_len, cond_idx, delta_length_cond, sampler, state_sampler, host_noise, trace,
-                              use_graph, yield_every=32):
+    def _generate_stream(self, code, state_code, add_len, cond_idx, delta_length_cond, sampler, state_sampler, host_noise, trace,
+                         use_graph):
         """`Transformer.fill_code` (transformer_model.py:343-392) for a frame + ancillary token stream on the KV cache.
         The merged sequence only ever grows at its end, so each new token (plus, at a frame boundary, the next frame's
         given ancillary tokens) is appended to the cache: runs of frame tokens replay the captured decode step, the
@@ -554,10 +562,8 @@ class GPT(nn.Module):
                 c["len_dev"].fill_(c["len"])
                 c["widx"].fill_(n_code)
                 graph = self._decode_graph(sampler, (sampler["sample"], sampler["top_k"], sampler["temperature"], n_cond, b, "stream"))
-                for r in range(run):
+                for _ in range(run):
                     graph.replay()
-                    if (r + 1) % yield_every == 0:
-                        yield
                 c["len"] += run          # each replay appended the previous pick, then picked the next
                 n_code += run
                 fed += run
@@ -589,19 +595,12 @@ class GPT(nn.Module):
                 new_fed = slen(n_code, n_state)
                 logits = self.extend(rows_of(fed, new_fed))
                 fed = new_fed
-            yield
         return frame_codes[:, :n_code].clone(), state_buf[:, :n_state].clone()
 
-    def generate(self, *args, **kwargs):
-        """`generate_iter` run to completion."""
-        return drive(self.generate_iter(*args, **kwargs))
-
     @torch.no_grad()
-    def generate_iter(self, code, add_len, cond_idx=None, delta_length_cond=None, sample=False, top_k=None, temperature=1.0,
-                      noise="device", host_noise=None, trace=None, use_graph=True, state_code=None, state_sampler=None,
-                      yield_every=32):
-        """code [B,t0] -> [B, t0+add_len]: one prefill, then KV-cached decode steps.  A generator: it yields every
-        `yield_every` enqueued steps (scheduling points for Generator.run_pipelined) and returns the result.
+    def generate(self, code, add_len, cond_idx=None, delta_length_cond=None, sample=False, top_k=None, temperature=1.0,
+                 noise="device", host_noise=None, trace=None, use_graph=True, state_code=None, state_sampler=None):
+        """code [B,t0] -> [B, t0+add_len]: one prefill, then KV-cached decode steps.
         With an ancillary stream (`state_code` [B,ns], `state_sampler` = dict(sample, top_k, temperature, vocab)) the
         add_len new tokens are split between the two streams as the reference does and (code, state_code) is returned.
 
@@ -613,9 +612,8 @@ class GPT(nn.Module):
         n_cond = cond_idx.shape[1] if use_cond else 0
         sampler = {"sample": bool(sample), "top_k": top_k, "temperature": float(temperature), "noise": noise}
         if state_code is not None and 0 not in state_code.size():
-            return (yield from self._generate_stream_iter(code, state_code, add_len, cond_idx if use_cond else None,
-                                                          delta_length_cond if use_cond else None, sampler, state_sampler, host_noise,
-                                                          trace, use_graph, yield_every))
+            return self._generate_stream(code, state_code, add_len, cond_idx if use_cond else None,
+                                         delta_length_cond if use_cond else None, sampler, state_sampler, host_noise, trace, use_graph)
         eager = trace is not None or (sample and noise != "device") or not use_graph or add_len < 3
         max_len = n_cond + t0 + add_len
         c = self.begin(b, max_len)
@@ -634,8 +632,7 @@ class GPT(nn.Module):
             self._emit(logits, sampler, host_noise(b, logits.shape[1]).to(logits.device, non_blocking=True) if sample else None, t0)
 
         graph = None if eager else self._decode_graph(sampler, (bool(sample), top_k, float(temperature), n_cond, b))
-        yield
-        for i in range(add_len - 1):
+        for _ in range(add_len - 1):
             if graph is not None:
                 graph.replay()
             else:
@@ -643,8 +640,6 @@ class GPT(nn.Module):
                 if sample and noise != "device":
                     nz = host_noise(b, self.head.weight.shape[0]).to(code.device, non_blocking=True)
                 self._decode_body(sampler, noise=nz, trace=trace)
-            if (i + 1) % yield_every == 0:
-                yield
         c["len"] = n_cond + t0 + add_len - 1
         return c["codes"][:, :t0 + add_len].clone()
 

@@ -16,7 +16,7 @@ same CPU generator stream the reference's CPU path would consume and uploaded; w
 import torch
 
 from .mingpt import GPT
-from ccvs_amd.tools.utils import to_cuda, drive
+from ccvs_amd.tools.utils import to_cuda
 from ccvs_amd.models import load_network, print_network
 from ccvs_amd import ops
 
@@ -42,8 +42,6 @@ class Transformer(torch.nn.Module):
         code, state_code, cond_code, delta_length_cond, vid_lbl = self.preprocess_input(data)
         if mode == 'inference':
             return self.generate_fake(code, state_code, cond_code, delta_length_cond, vid_lbl, total_len, show_progress)
-        if mode == 'inference_iter':   # (ccvs_amd) the same as a generator-style stage, see tools.utils.drive
-            return self.generate_fake_iter(code, state_code, cond_code, delta_length_cond, vid_lbl, total_len)
         if mode in ('transformer', 'eval_transformer'):
             raise NotImplementedError(f"mode '{mode}' (training loss) is outside the MI355X hot path")
         raise ValueError(f"mode '{mode}' is invalid")
@@ -78,26 +76,23 @@ class Transformer(torch.nn.Module):
         out[out < v[..., [-1]]] = -float('Inf')
         return out
 
-    def generate_fake(self, code, state_code, cond_code, delta_length_cond, vid_lbl, total_len, show_progress=False):
-        return drive(self.generate_fake_iter(code, state_code, cond_code, delta_length_cond, vid_lbl, total_len))
-
     @torch.no_grad()
-    def generate_fake_iter(self, code, state_code, cond_code, delta_length_cond, vid_lbl, total_len):
+    def generate_fake(self, code, state_code, cond_code, delta_length_cond, vid_lbl, total_len, show_progress=False):
         """transformer_model.py:263-328, including the sliding token window for total_len > z_len (each slide restarts
         positions at 0, so the window is re-prefilled) and the ancillary (state / STFT) stream bookkeeping."""
         opt = self.opt
         use_state = 0 not in state_code.size()
         n_cond = cond_code.size(1) if 0 not in cond_code.size() else 0
         if total_len is None:
-            code, state_code = yield from self.fill_code_iter(code, state_code, cond_code, delta_length_cond, vid_lbl)
+            code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl)
             return {"code": code, "state_code": state_code}
         total_len = int(total_len)
         if total_len <= opt.z_len:
             add_len = total_len - code.size(1) - n_cond
             add_len -= min(state_code.size(1), opt.state_size * opt.num_blocks) if use_state else 0
-            code, state_code = yield from self.fill_code_iter(code, state_code, cond_code, delta_length_cond, vid_lbl, add_len=add_len)
+            code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl, add_len=add_len)
             return {"code": code, "state_code": state_code}
-        code, state_code = yield from self.fill_code_iter(code, state_code, cond_code, delta_length_cond, vid_lbl)
+        code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl)
         curr_len = opt.z_len
         i = 1
         while curr_len < total_len:
@@ -106,8 +101,7 @@ class Transformer(torch.nn.Module):
                 delta_length_cond = delta_length_cond - 1
             tmp_state_code = state_code[:, i * self.state_size:] if use_state else state_code
             tmp_code = code[:, i * self.size:]
-            pred_code, pred_state_code = yield from self.fill_code_iter(tmp_code, tmp_state_code, cond_code, delta_length_cond, vid_lbl,
-                                                                        add_len=add_len)
+            pred_code, pred_state_code = self.fill_code(tmp_code, tmp_state_code, cond_code, delta_length_cond, vid_lbl, add_len=add_len)
             delta_code = pred_code.size(1) - tmp_code.size(1)
             code = torch.cat([code, pred_code[:, -delta_code:]], dim=1)
             if use_state:
@@ -124,15 +118,12 @@ class Transformer(torch.nn.Module):
         q = torch.empty(b, v, dtype=torch.float32).exponential_(1, generator=self.generator)
         return q.to(device, non_blocking=True)
 
-    def fill_code(self, code, state_code, cond_code, delta_length_cond, vid_lbl, add_len=None, show_progress=False):
-        return drive(self.fill_code_iter(code, state_code, cond_code, delta_length_cond, vid_lbl, add_len))
-
     @torch.no_grad()
-    def fill_code_iter(self, code, state_code, cond_code, delta_length_cond, vid_lbl, add_len=None):
-        """transformer_model.py:331-392 on the KV-cached engine (generator-style stage)."""
+    def fill_code(self, code, state_code, cond_code, delta_length_cond, vid_lbl, add_len=None, show_progress=False):
+        """transformer_model.py:331-392 on the KV-cached engine."""
         opt = self.opt
         if getattr(opt, "beam_size", None) is not None:
-            raise NotImplementedError("beam search is not on the MI355X path yet (SURVEY 8f)")
+            return self._beam_fill(code, state_code, cond_code, add_len)
         b, t0 = code.shape
         n_cond = cond_code.size(1) if 0 not in cond_code.size() else 0
         use_state = 0 not in state_code.size()
@@ -148,7 +139,7 @@ class Transformer(torch.nn.Module):
         if use_state:  # ancillary tokens: first state_num logits, their own sampling options (transformer_model.py:353-356)
             state_sampler = {"sample": bool(opt.sample_state), "top_k": opt.top_k_state, "temperature": float(opt.temperature_state),
                              "vocab": opt.state_num}
-        out = yield from self.net_t.generate_iter(code, add_len, cond_code if n_cond else None, delta_length_cond if n_cond else None,
+        out = self.net_t.generate(code, add_len, cond_code if n_cond else None, delta_length_cond if n_cond else None,
                                   sample=opt.sample, top_k=opt.top_k, temperature=opt.temperature, noise=self.sample_noise,
                                   host_noise=host_noise, trace=self.trace, use_graph=getattr(opt, "use_graph", True),
                                   state_code=state_code if use_state else None, state_sampler=state_sampler)
@@ -157,10 +148,68 @@ class Transformer(torch.nn.Module):
         return out, state_code
 
     @torch.no_grad()
+    def _beam_fill(self, code, state_code, cond_code, add_len):
+        """Beam search of `fill_code` (transformer_model.py:358-391) on the KV cache.
+
+        The reference keeps `beam_size` hypotheses per clip as extra batch rows.  The first pick takes `beam_size` proposals
+        from the prefix's distribution (:362-367); afterwards each hypothesis either continues with ONE pick whose
+        log-probability is added to its score (default, :369-372), or -- with `--x_no_sample` -- proposes `beam_size`
+        continuations, the clip's beam^2 candidates are pruned to the best `beam_size` by accumulated score and the
+        hypotheses are re-ordered (:374-386); the best hypothesis is returned (:387-391).  Here the hypotheses are rows of
+        the cache from the start (the prefix is prefilled once per row) and a re-ordering is a row gather of the cached
+        keys / values.  (sic) In the pruning branch the reference adds score[b, j] -- not score[b, i] -- to candidate j of
+        hypothesis i (`log_p.unsqueeze(1).repeat(...)`, :377-378); kept, the golden vectors pin it.
+        The reference's expansion does not replicate `cond_code` / `state_code`, so it fails with them: so does this."""
+        opt = self.opt
+        beam = int(opt.beam_size)
+        if 0 not in cond_code.size() or 0 not in state_code.size():
+            raise NotImplementedError("beam search with a conditioning prefix / ancillary stream: the reference's expansion "
+                                      "(transformer_model.py:361) does not replicate them and fails too")
+        bs, t0 = code.shape
+        if add_len is None:
+            add_len = opt.z_len - t0
+        if add_len <= 0:
+            return code, state_code
+        net = self.net_t
+        rows = code.repeat_interleave(beam, dim=0).contiguous()            # row b * beam + i = hypothesis i of clip b
+        net.begin(bs * beam, t0 + add_len)
+        logits = net.prefill(rows)                                           # identical for the beam rows of a clip
+        icode, log_p = self.get_icode(logits[::beam].unsqueeze(1), opt.temperature, opt.top_k, opt.sample, n=beam)   # [bs, beam]
+        rows = torch.cat((rows, icode.reshape(-1, 1)), dim=1)
+        for _ in range(add_len - 1):
+            logits = net.step(rows[:, -1:].contiguous())
+            if not getattr(opt, "no_sample", False):
+                icode, ilog_p = self.get_icode(logits.unsqueeze(1), opt.temperature, opt.top_k, opt.sample, n=1)
+                log_p = log_p + ilog_p.view(bs, beam)
+                rows = torch.cat((rows, icode.view(-1, 1)), dim=1)
+            else:
+                icode, ilog_p = self.get_icode(logits.unsqueeze(1), opt.temperature, opt.top_k, opt.sample, n=beam)   # [bs*beam, beam]
+                cand = log_p.unsqueeze(1).repeat(1, beam, 1) + ilog_p.view(bs, beam, beam)
+                log_p, keep = torch.topk(cand.view(bs, beam * beam), dim=1, k=beam)
+                icode = torch.gather(icode.view(bs, beam * beam), dim=1, index=keep).view(-1, 1)
+                parent = (torch.arange(bs, device=keep.device).view(bs, 1) * beam + keep // beam).view(-1)   # cache row each survivor extends
+                net.reorder_cache(parent)
+                rows = torch.cat((rows[parent], icode), dim=1)
+        best = torch.topk(log_p, dim=1, k=1)[1]                            # [bs, 1]
+        rows = rows.view(bs, beam, -1)
+        out = torch.gather(rows, dim=1, index=best.unsqueeze(-1).repeat(1, 1, rows.size(-1))).view(bs, rows.size(-1))
+        return out, state_code
+
+    @torch.no_grad()
     def get_icode(self, logits, temperature, top_k, sample, n=1):
-        """transformer_model.py:395-409 for n = 1: logits [B,T,V] -> (icode [B,1], log p [B,1])."""
+        """transformer_model.py:395-409: logits [B,T,V] -> (icode [B,n], log p [B,n]).  n = 1 is the fused pick kernel; n > 1
+        (beam-search proposals) = `torch.topk` of the probabilities, or of probabilities / Exp(1) noise -- what
+        `torch.multinomial(probs, n)` without replacement computes -- with the noise drawn like the n = 1 case."""
         if n != 1:
-            raise NotImplementedError("n > 1 proposals (beam search) is not on the MI355X path yet")
+            last = logits[:, -1] / temperature
+            if top_k is not None:
+                last = self.top_k_logits(last, top_k)
+            probs = torch.softmax(last, dim=-1)
+            if sample:
+                icode = torch.topk(probs / self._noise(last.shape[0], last.shape[1], last.device), k=n, dim=-1)[1]
+            else:
+                icode = torch.topk(probs, k=n, dim=-1)[1]
+            return icode, torch.log(torch.gather(probs, 1, icode))
         last = logits[:, -1].contiguous()
         noise = self._noise(last.shape[0], last.shape[1], last.device) if sample else None
         icode = ops.sample_topk(last, top_k, temperature, noise=noise).view(-1, 1)

@@ -78,8 +78,7 @@ def _as_rows_dense(t):
 #   "bf16x3": split-bf16, 3 products per fp32 product on v_mfma_f32_32x32x16_bf16 (default)
 #   "f32"   : exact fp32 on v_mfma_f32_32x32x2_f32
 CONV_PRECISION = "bf16x3"
-# CUs a convolution launch may occupy (`ccvs_conv_desc.cu_limit`; 0 = all).  The pipelined Generator sets it for the decoder's
-# stream so that the token loop of the next batch, running concurrently on a high-priority stream, always finds free CUs.
+# Explicit `ccvs_conv_desc.cu_limit` of the convolution launches (0 = the budget of the stream, see `stream_cu_limit`); tests.
 CONV_CU_LIMIT = 0
 
 
@@ -513,16 +512,12 @@ def sample_topk(logits, top_k, temperature, noise=None, out=None, philox=None):
     return out
 
 
-# `ccvs_gpt_decode.gemm_tiles` of the decode steps built from now on (0: whole-chip grids; 4: compact, ~64 CUs per launch).
-DECODE_GEMM_TILES = int(__import__("os").environ.get("CCVS_DECODE_GEMM_TILES", "0"))
-
-
 class GptDecodeStep:
     """A filled `ccvs_gpt_decode` descriptor (include/ccvs_hip.h) plus the tensors it points at.
     `launch()` enqueues one whole decode step on the current stream."""
 
     def __init__(self, layers, B, C, H, Tmax, ln_eps, tok_emb, pos_table, pos_off, head, tok, codes, widx, length,
-                 x, q, att, h, logits, noise, top_k, temperature, state, rng=False, gemm_tiles=0):
+                 x, q, att, h, logits, noise, top_k, temperature, state, rng=False):
         hw, hb, hs = head
         keep = [tok_emb, pos_table, hw, hb, hs, tok, codes, widx, length, x, q, att, h, logits, noise, state]
         for t in keep:
@@ -556,12 +551,18 @@ class GptDecodeStep:
         d.rng = 1 if (rng and noise is None) else 0
         d.top_k, d.temperature = 0 if top_k is None else int(top_k), float(temperature)
         d.workspace, d.state = _p(self.ws), _p(state)
-        d.gemm_tiles = int(gemm_tiles)
         self.desc, self._arr, self._keep = d, arr, keep
 
     def launch(self):
         L = _lib.load()
         _lib.check(L.ccvs_gpt_decode_step(C.byref(self.desc), _stream()), "ccvs_gpt_decode_step")
+
+
+def stream_cu_limit(stream, cu_limit):
+    """`ccvs_stream_cu_limit`: kernels launched on `stream` (a torch.cuda.Stream) from now on occupy at most cu_limit CUs
+    (0: no budget)."""
+    L = _lib.load()
+    _lib.check(L.ccvs_stream_cu_limit(C.c_void_p(stream.cuda_stream), int(cu_limit)), "ccvs_stream_cu_limit")
 
 
 def pack_u8(vid, lo=-1.0, hi=1.0):

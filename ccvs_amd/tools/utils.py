@@ -66,13 +66,3 @@ def color_transfer(im, colormap):
     """tools/utils.py:138-147 colours a semantic layout: layouts are outside the hot path."""
     raise NotImplementedError("layout colour maps are outside the MI355X hot path")
 
-
-def drive(gen):
-    """Run a generator-style stage (one that `yield`s at its scheduling points and `return`s its result) to completion.
-    The token loop and the frame decoder are written as such stages so that a scheduler can interleave the enqueueing
-    of two batches on two streams (Generator.run_pipelined); called through `drive` they are ordinary functions."""
-    try:
-        while True:
-            next(gen)
-    except StopIteration as stop:
-        return stop.value

@@ -271,12 +271,18 @@ typedef struct ccvs_gpt_decode {
     int32_t top_k; float temperature;
     void* workspace;                    /* ccvs_gemm_workspace_bytes(), zeroed once */
     int32_t* state;
-    int32_t gemm_tiles;                 /* 0: every GEMM as one 16-column tile per workgroup over the whole chip (fastest when the
-                                           step runs alone).  T >= 1: compact forms -- up to T tiles per workgroup (never fewer than
-                                           64 workgroups) and the split-K GEMM in one workgroup per tile: the step then needs ~64 CUs
-                                           and can run beside another stream's convolutions (ccvs_conv_desc.cu_limit).  Same bits. */
 } ccvs_gpt_decode;
 int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream);
+
+/* ---- sharing the chip between two streams ------------------------------------------
+ * ccvs_stream_cu_limit(stream, n): work submitted to `stream` from now on occupies at most n compute units (0 lifts the
+ * budget).  The HBM-bound kernels (FIR, warps, cost volume, depthwise up-sampling, tap sums, uint8 pack) then run as a
+ * persistent grid of n x (workgroups per CU) workgroups that stride over their blocks, and the convolutions default their
+ * ccvs_conv_desc.cu_limit to n.  Used by the two-batches-in-flight schedule: the frame decoder of batch i (this budget) runs
+ * beside the token loop of batch i+1 (a chain of ~120 small dependent launches per token on a high-priority stream, which
+ * needs free CUs the moment each launch arrives).  Results do not depend on the budget.  Host state: one table of at most
+ * 16 (stream, budget) pairs, to be written by the thread that drives the device. */
+int ccvs_stream_cu_limit(void* stream, int32_t cu_limit);
 
 /* ---- output stage ---------------------------------------------------------------------
  * save_video_batch's clamp / rescale / x255 / uint8 / channels-last pack

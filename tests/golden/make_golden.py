@@ -236,6 +236,40 @@ def tiny_state_model(ns):
     print("  wrote tiny_statemodel.npz", sum(a.nbytes for a in arrays.values()) / 1e6, "MB raw")
 
 
+def tiny_beam(ns):
+    """Beam search of Transformer.fill_code (transformer_model.py:358-391) on the tiny transformer of tiny_e2e.npz: greedy
+    continuation per hypothesis, expand-and-prune (`--x_no_sample`), and seeded multinomial proposals."""
+    opt = rh.parse_reference_options(rh.TINY_ARGV + ["--x_beam_size", "3", "--x_top_k", "10"])
+    xopt = opt["transformer"]
+    torch.manual_seed(0)
+    ns.qvm.QVidModel(opt["qvid_generator"], is_train=False, is_main=True)   # same construction order as tiny_end_to_end
+    tr = ns.tm.Transformer(xopt, is_train=False, is_main=True).eval()
+    ref = np.load(os.path.join(HERE, "tiny_e2e.npz"))
+    with torch.no_grad():
+        for k, v in tr.net_t.state_dict().items():
+            if k in ("s_emb", "t_emb"):
+                v.copy_(torch.from_numpy(ref["t/" + k]))
+            elif not k.endswith(".mask"):
+                assert np.array_equal(v.numpy(), ref["t/" + k]), k
+    code = torch.from_numpy(ref["gen_code_greedy"])[:, :64].clone()
+    empty = torch.tensor([])
+    out = {"code": code}
+    xo = O.namespace(**vars(xopt))
+    sd = tr.net_t.state_dict()
+    with torch.no_grad():
+        for name, sample, no_sample, add_len in (("greedy", False, False, 12), ("prune", False, True, 12), ("sampled", True, False, 8),
+                                                 ("sampled_prune", True, True, 8)):
+            xopt.sample, xopt.no_sample = sample, no_sample
+            xo.sample, xo.no_sample = sample, no_sample
+            torch.manual_seed(5)
+            got = tr.fill_code(code.clone(), empty, empty, None, empty, add_len=add_len)[0]
+            out["beam_" + name] = got
+            torch.manual_seed(5)
+            report(f"beam/{name} (mismatches)", (O.fill_code_beam(sd, xo, code.clone(), add_len) != got).float(), torch.zeros(1))
+    np.savez_compressed(os.path.join(HERE, "tiny_beam.npz"), **{k: v.numpy() for k, v in out.items()})
+    print("  wrote tiny_beam.npz")
+
+
 def tiny_keep_first(ns):
     """Decoder context ring with `--q_keep_first --q_n_first 1` (quantized_video_model.py:896-898; the drums script uses
     n_first 8): 6 frames through a 3-slot ring.  Same seed / construction order as tiny_end_to_end, so the weights are the
@@ -407,7 +441,7 @@ def op_fixtures(ns):
 
 if __name__ == "__main__":
     ns = rh.load_reference()
-    which = sys.argv[1:] or ["ops", "tiny", "state", "keepfirst", "statemodel"]
+    which = sys.argv[1:] or ["ops", "tiny", "state", "keepfirst", "statemodel", "beam"]
     if "ops" in which:
         print("== op fixtures")
         op_fixtures(ns)
@@ -417,6 +451,9 @@ if __name__ == "__main__":
     if "state" in which:
         print("== tiny ancillary-token stream")
         tiny_state_stream(ns)
+    if "beam" in which:
+        print("== tiny beam search")
+        tiny_beam(ns)
     if "statemodel" in which:
         print("== tiny state model")
         tiny_state_model(ns)

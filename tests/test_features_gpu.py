@@ -262,3 +262,26 @@ def test_sampled_tokens_do_not_depend_on_sharding(tiny):
     finally:
         xopt.sample, xopt.rec_pass = False, True
         tiny["tr"].sample_noise = old_noise
+
+
+def test_beam_search_golden(tiny, golden_dir):
+    """Beam search on the KV cache (hypotheses = cache rows, pruning = row gather) against the reference's own token streams:
+    one continuation per hypothesis, expand-and-prune (`--x_no_sample`), and multinomial proposals from the seeded CPU stream."""
+    g = np.load(os.path.join(golden_dir, "tiny_beam.npz"))
+    tr, xopt = tiny["tr"], tiny["xopt"]
+    code = torch.from_numpy(g["code"])
+    old = (xopt.sample, xopt.top_k, getattr(xopt, "beam_size", None), getattr(xopt, "no_sample", False), tr.sample_noise)
+    empty = torch.tensor([])
+    try:
+        xopt.beam_size, xopt.top_k = 3, 10
+        tr.sample_noise, tr.generator = "host", None
+        for name, sample, no_sample, add_len in (("greedy", False, False, 12), ("prune", False, True, 12), ("sampled", True, False, 8),
+                                                 ("sampled_prune", True, True, 8)):
+            xopt.sample, xopt.no_sample = sample, no_sample
+            torch.manual_seed(5)
+            got = tr.fill_code(code.clone().cuda(), empty.cuda(), empty.cuda(), None, empty, add_len=add_len)[0]
+            assert torch.equal(got.cpu(), torch.from_numpy(g["beam_" + name])), name
+        with pytest.raises(NotImplementedError):
+            tr.fill_code(code.clone().cuda(), empty.cuda(), code[:, :64].cuda(), torch.tensor([3, 3]), empty, add_len=4)
+    finally:
+        xopt.sample, xopt.top_k, xopt.beam_size, xopt.no_sample, tr.sample_noise = old

@@ -49,13 +49,7 @@ def run(n_hog, mem=False):
     return 1e3 * ms / tokens
 
 
-from ccvs_amd import ops  # noqa: E402
-for tiles in (0, 4):
-    ops.DECODE_GEMM_TILES = tiles
-    with torch.cuda.stream(s_tok):
-        net.generate(code, 8, sample=True, top_k=100)   # re-capture with this GEMM form
-    for n_hog in (0, 192, 224):
-        print(f"gemm_tiles {tiles}: idle hog on {n_hog:3d} CUs (free {256 - n_hog:3d}): {run(n_hog):7.1f} us/token over {tokens} tokens", flush=True)
-    for n_hog in (64, 128, 192):
-        print(f"gemm_tiles {tiles}: STREAMING hog (1 workgroup of 512 threads per CU, float4 reads) on {n_hog:3d} CUs: {run(n_hog, True):7.1f} us/token",
-              flush=True)
+for n_hog in (0, 128, 192, 224, 240):
+    print(f"idle hog on {n_hog:3d} CUs (free {256 - n_hog:3d}): {run(n_hog):7.1f} us/token over {tokens} tokens", flush=True)
+for n_hog in (64, 128, 192):
+    print(f"STREAMING hog (1 workgroup of 512 threads per CU, float4 reads) on {n_hog:3d} CUs: {run(n_hog, True):7.1f} us/token", flush=True)
