@@ -506,9 +506,11 @@ __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __r
     __shared__ __attribute__((aligned(16))) float smem[SMEM_WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = lane & 31, half = lane >> 5;
-    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    // grid = (batch x head, query block): blocks are dispatched x-fastest, so ALL (batch, head) pairs of the last query block
+    // -- the one with the most visible keys under the causal mask -- start first and the short blocks fill the tail
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     if (pos_dev) pos0 += *pos_dev;
-    const int q0 = blockIdx.x * 128;                       // first query of the workgroup
+    const int q0 = (gridDim.y - 1 - blockIdx.y) * 128;     // first query of the workgroup
     const int qw = q0 + wave * 32;                         // first query of the wave
     const int qidx = qw + qi;                              // this lane's query
     const int q_last_wg = min(q0 + 127, Tq - 1), q_last_w = min(qw + 31, Tq - 1);
@@ -521,7 +523,8 @@ __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __r
     {
         const float* qp = q + (long)b * q_sB + (long)min(qidx, Tq - 1) * ldq + h * D + half;
 #pragma unroll
-        for (int i = 0; i < DK; ++i) qreg[i] = (qidx < Tq) ? qp[2 * i] * scale : 0.f;
+        // scores are kept in the log2 domain (scale * log2(e) folded into Q): the softmax then needs v_exp_f32 only
+        for (int i = 0; i < DK; ++i) qreg[i] = (qidx < Tq) ? qp[2 * i] * (scale * 1.44269504088896340736f) : 0.f;
     }
     if (MT * 32 > D) {  // zero the padding columns of both V buffers once (D = 16)
         for (int e = tid; e < 2 * 32 * (DP - D); e += 256) {
@@ -597,21 +600,24 @@ __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __r
             }
             m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
             const float m_new = fmaxf(m_run, m_t);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;   // nothing visible yet: every p below is exp(-inf) = 0
-            const float alpha = expf(m_run - m_use);                   // m_run = -inf -> 0
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;   // nothing visible yet: every p below is 2^-inf = 0
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
             float l_t = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = expf(s[r] - m_use);
+                s[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
                 l_t += s[r];
             }
             l_t += __shfl_xor(l_t, 32, 64);
             l_run = l_run * alpha + l_t;
             m_run = m_new;
+            const bool rescale = __any(alpha != 1.f);   // wave-uniform: the running max of no lane moved -> O keeps its scale
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
+                if (rescale) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc_o[mt][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) acc_o[mt][r] *= alpha;
+                }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const int kk = 8 * (j >> 2) + 4 * half + (j & 3);
@@ -759,7 +765,7 @@ extern "C" int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const f
     CCVS_REQUIRE(q && kcache && vcache && out, "ccvs_attention: null pointer");
     CCVS_REQUIRE(D == 64 || D == 32 || D == 16, "ccvs_attention: head dim %d unsupported (16, 32, 64)", D);
     CCVS_REQUIRE(B > 0 && H > 0 && Tq > 0 && pos0 >= 0 && pos0 + Tq <= Tmax, "ccvs_attention: bad positions");
-    CCVS_REQUIRE((long)B * H <= 65535, "ccvs_attention: batch x heads %ld too large for one launch", (long)B * H);
+    CCVS_REQUIRE(cdiv(Tq, 128) <= 65535, "ccvs_attention: %d queries too many for one launch", Tq);
     // with a device-side position the visible length is unknown to the host: size LDS for the whole cache
     const int maxL = pos_dev ? Tmax : pos0 + Tq;
     const float scale = 1.0f / sqrtf((float)D);
@@ -772,7 +778,7 @@ extern "C" int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const f
         else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
         else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
     } else {
-        const dim3 grid((unsigned)cdiv(Tq, 128), (unsigned)(B * H));
+        const dim3 grid((unsigned)(B * H), (unsigned)cdiv(Tq, 128));
         if (D == 64) hipLaunchKernelGGL((attention_prefill_kernel<64>), grid, dim3(256), 0, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, pos_dev, Tmax, scale);
         else if (D == 32) hipLaunchKernelGGL((attention_prefill_kernel<32>), grid, dim3(256), 0, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, pos_dev, Tmax, scale);
         else hipLaunchKernelGGL((attention_prefill_kernel<16>), grid, dim3(256), 0, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, pos_dev, Tmax, scale);

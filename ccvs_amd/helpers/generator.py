@@ -265,7 +265,8 @@ class Generator:
             raise NotImplementedError("run_pipelined covers the plain synthesis schedule (use generate_vid for step_by_step / rec_only)")
         dev = torch.device("cuda", torch.cuda.current_device())
         if getattr(self, "_streams", None) is None:
-            self._streams = (torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev, priority=0))
+            prio = [int(v) for v in os.environ.get("CCVS_PIPELINE_PRIORITIES", "-1,0").split(",")]   # (token stream, decode stream)
+            self._streams = (torch.cuda.Stream(device=dev, priority=prio[0]), torch.cuda.Stream(device=dev, priority=prio[1]))
         s_tok, s_dec = self._streams
         if cu_limit is None:
             cu_limit = int(os.environ.get("CCVS_PIPELINE_CU_LIMIT", torch.cuda.get_device_properties(dev).multi_processor_count * 3 // 4))
