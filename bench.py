@@ -46,7 +46,8 @@ def parse_args():
     ap.add_argument("--conv-precision", type=str, default=None, choices=["bf16x3", "f32"])
     ap.add_argument("--schedule", type=str, default=os.environ.get("CCVS_BENCH_SCHEDULE", "pipelined"), choices=["serial", "pipelined"],
                     help="serial: batches one after the other; pipelined: token loop of batch i+1 beside the decoder of batch i")
-    ap.add_argument("--cu-limit", type=int, default=None, help="pipelined: CUs the convolutions may occupy while a token loop is in flight")
+    ap.add_argument("--cu-limit", type=int, default=None, help="pipelined: CUs the decoder stream may occupy while token loops are in flight")
+    ap.add_argument("--lanes", type=int, default=None, help="pipelined: token loops (of consecutive batches) that run at the same time")
     ap.add_argument("--rec-pass", action="store_true", help="also run the reference's teacher-forced reconstruction decode (not counted)")
     return ap.parse_args()
 
@@ -264,7 +265,7 @@ def main():
         def run(first, batches):
             """K batches from resident inputs to all-gathered uint8 clips; returns the gathered clips of the last one."""
             if args.schedule == "pipelined":
-                res = gen.run_pipelined(iter(batches), first_iter=first, cu_limit=args.cu_limit, finish=finish)
+                res = gen.run_pipelined(iter(batches), first_iter=first, cu_limit=args.cu_limit, finish=finish, lanes=args.lanes)
                 handles = [r["finished"] for r in res]
                 stages = gen.pipeline_stage_ms() if engine.is_main else {}
             else:
@@ -317,14 +318,16 @@ def main():
                            "predicted_frames_per_clip": predicted,
                            "rec_pass": ("also run, not counted" if args.rec_pass else "off: the reference's extra teacher-forced reconstruction decode is not part of "
                                         "the synthesized-frames metric (SURVEY 8d)"), "sampling": f"top-k {xopt.top_k}, T={xopt.temperature}, noise={args.sample_noise}",
-                           "schedule": ("pipelined: two batches in flight per GPU -- token loop of batch i+1 on a high-priority stream beside the "
-                                        f"encoder/decoder of batch i, whose convolutions are capped to {gen.last_cu_limit} of {n_cu} CUs; K batches timed "
-                                        "from resident inputs to gathered clips, fill and drain included") if args.schedule == "pipelined"
+                           "schedule": (f"pipelined: {gen.last_lanes + 1} batches in flight per GPU -- the token loops of batches i+1..i+{gen.last_lanes} on "
+                                        f"{gen.last_lanes} high-priority streams (shared weights, one KV cache each) beside the encoder/decoder of batch i"
+                                        + (f", whose kernels are capped to {gen.last_cu_limit} of {n_cu} CUs" if gen.last_cu_limit else "")
+                                        + f"; every generate call is one batch of {args.batch} clips; "
+                                        "K batches timed from resident inputs to gathered clips, fill and drain included") if args.schedule == "pipelined"
                                        else "serial: one batch at a time",
                            "parallelism": f"dp{world} (batch sharded, one RCCL all-gather of uint8 clips on a side stream)"},
                 "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
                 "stage_note": "per-batch stage durations from HIP events on the stage's own stream" +
-                              ("; in the pipelined schedule encode+decode (stream D) and transformer (stream T) overlap" if args.schedule == "pipelined" else ""),
+                              ("; in the pipelined schedule encode+decode (stream D) and the transformer stages (one stream per lane) overlap" if args.schedule == "pipelined" else ""),
                 "roofline": {"kernel": ("conv2d_bf16x3_pc_kernel<TW,MB,NTY> + conv2d_bf16x3_kernel<TW,MB> (every instantiation: all conv launches)"
                                         if kind == "bf16x3" else "conv2d_mfma_kernel<TW,MB>"), "bound": "mfma",
                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,

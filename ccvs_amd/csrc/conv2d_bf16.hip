@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4
 //   NTY = -2     the same with two pixel passes per thread and step (transposed layers: larger halo tiles).
 // Stride-2 layers and halo tiles that do not fit the double buffer use the synchronous kernel above.
 // ---------------------------------------------------------------------------------------
+// (MB = 2 compiled for 4 waves per SIMD -- two workgroups per CU, 17 VGPRs spilled -- measured 236 vs 246 TFLOP/s on 128->64 3x3 at 256^2: not kept)
 template <int TW, int MB, int NTY>
 __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
     constexpr bool VEC = NTY > 0;

@@ -14,6 +14,7 @@ Differences by design:
 State / STFT / layout / deblurring conditioning are "next" rows and raise.
 """
 import os
+import sys
 import time
 from itertools import cycle
 
@@ -40,8 +41,8 @@ class Generator:
         self.timings = {}
         self.stft_model = None
         self.state_model = None
-        self._streams = None
-        self.last_cu_limit = 0
+        self._lanes, self._dec_stream, self._warm_lanes = None, None, set()
+        self.last_cu_limit, self.last_lanes = 0, 0
         for flag in ("layout", "deblurring", "cat"):
             if getattr(self.opt, flag, False):
                 raise NotImplementedError(f"--{flag} is not on the MI355X path (SURVEY 8f); --x_state / --x_stft [--keep_state] are")
@@ -104,9 +105,10 @@ class Generator:
         """Global index of this rank's clip 0 when every rank holds `batch` clips."""
         return self.engine.rank * batch if self.engine is not None else 0
 
-    def _seed_sampler(self, batch, global_iter):
-        if self.transformer_model is not None:
+    def _seed_sampler(self, batch, global_iter, net_t=None):
+        if net_t is None and self.transformer_model is not None:
             net_t = self.transformer_model.net_t
+        if net_t is not None:
             net_t.noise_key, net_t.noise_call = self.noise_key(global_iter), 0
             net_t.row_offset = self.first_clip(batch)
 
@@ -241,47 +243,78 @@ class Generator:
             self.save_results(out, global_iter)
         return out
 
-    # ------------------------------------------------------------------ two batches in flight
-    @torch.no_grad()
-    def run_pipelined(self, batches, first_iter=0, cu_limit=None, finish=None):
-        """generate_vid over a sequence of batches with TWO batches in flight: while the flow-guided decoder works on batch
-        i (stream D: MFMA convolutions, large grids), the token loop of batch i+1 runs on a high-priority stream T (a
-        latency-bound chain of ~120 small launches per token that cannot fill the chip by itself).  Per batch the work is
-        exactly generate_vid's -- encode, crop, token synthesis, decode -- and so are the results (same kernels, same
-        per-clip noise; tests/test_pipeline_gpu.py checks bit-equality with the serial schedule).
+    # ------------------------------------------------------------------ several batches in flight
+    def _token_lane(self, k):
+        """Token lane k: a Transformer wrapper that SHARES the parameters (and their packed forms) of self.transformer_model
+        but owns its KV cache, decode hipGraph, sampler state and stream, so that the token loops of different batches can
+        run at the same time.  Lane 0 is the model itself."""
+        import copy
+        if getattr(self, "_lanes", None) is None:
+            self._lanes = []
+        while len(self._lanes) <= k:
+            tr = self.transformer_model
+            if self._lanes:
+                net = copy.copy(tr.net_t)                  # same Parameter objects / blocks, separate engine state
+                net._cache, net._graphs = None, {}
+                lane = copy.copy(tr)
+                lane._modules = dict(tr._modules)
+                lane._modules["net_t"] = net
+                tr = lane
+            dev = torch.device("cuda", torch.cuda.current_device())
+            prio = int(os.environ.get("CCVS_PIPELINE_PRIORITIES", "-1,0").split(",")[0])
+            self._lanes.append((tr, torch.cuda.Stream(device=dev, priority=prio)))
+        return self._lanes[k]
 
-        Everything on D is capped to `cu_limit` CUs (`ccvs_stream_cu_limit`) while a token loop is in flight, so its
-        few-hundred-workgroup launches always find free CUs instead of queueing behind thousand-tile kernels.
-        The token stage is enqueued by a worker thread: a hipGraph launch blocks the calling thread once the stream's
-        queue is full (a few dozen decode steps), and the decoder's launches must not wait behind that.  One token stage
-        at a time (the transformer's KV cache and sampler state are shared), in batch order.
+    @torch.no_grad()
+    def run_pipelined(self, batches, first_iter=0, cu_limit=None, finish=None, lanes=None):
+        """generate_vid over a sequence of batches with SEVERAL batches in flight on one GPU.  The token loop of a batch is a
+        latency-bound chain of ~120 small dependent launches per token that cannot fill the chip, the flow-guided decoder a
+        throughput-bound stream of large MFMA / HBM kernels: while stream D encodes and decodes batch i, the token loops of
+        batches i+1 .. i+L run on L high-priority streams ("lanes": shared weights, one KV cache and one captured decode
+        step each).  Per batch the work is exactly generate_vid's -- encode, crop, token synthesis, decode -- and so are
+        the results (same kernels, same per-clip noise; tests/test_pipeline_gpu.py checks bit-equality with the serial
+        schedule).
+
+        `cu_limit` > 0 caps everything on D to that many CUs (`ccvs_stream_cu_limit`) while token loops are in flight, so
+        that their few-hundred-workgroup launches always find free CUs; it pays with ONE lane (the token loop is then the
+        longer stage), not with several (the decoder is), hence the default 0.
+        Every token stage is enqueued by its own worker thread: a hipGraph launch blocks the calling thread once the
+        stream's queue is full (a few dozen decode steps), and neither the decoder's launches nor the other lanes' may
+        wait behind that.  A lane runs one token stage at a time, batches take the lanes round-robin and are decoded in
+        order.
 
         batches: iterable of data dicts.  finish(i, out) -> anything: called on stream D when batch i's clip is decoded
         (pack / all-gather); its return values are collected.  Returns the list of per-batch results
         ({"fake", "enc_code", "finished", "index"}); the rec pass is not run here."""
         import threading
+        from collections import deque
         opt = self.opt
         if opt.step_by_step or opt.rec_only:
             raise NotImplementedError("run_pipelined covers the plain synthesis schedule (use generate_vid for step_by_step / rec_only)")
         dev = torch.device("cuda", torch.cuda.current_device())
-        if getattr(self, "_streams", None) is None:
-            prio = [int(v) for v in os.environ.get("CCVS_PIPELINE_PRIORITIES", "-1,0").split(",")]   # (token stream, decode stream)
-            self._streams = (torch.cuda.Stream(device=dev, priority=prio[0]), torch.cuda.Stream(device=dev, priority=prio[1]))
-        s_tok, s_dec = self._streams
-        if cu_limit is None:
-            cu_limit = int(os.environ.get("CCVS_PIPELINE_CU_LIMIT", torch.cuda.get_device_properties(dev).multi_processor_count * 3 // 4))
-        self.last_cu_limit = cu_limit
+        if lanes is None:
+            lanes = int(os.environ.get("CCVS_PIPELINE_LANES", "3"))   # measured best on MI355X at BAIR size (2: -6 %, 4: -17 %)
+        if getattr(self, "_dec_stream", None) is None:
+            prio = [int(v) for v in os.environ.get("CCVS_PIPELINE_PRIORITIES", "-1,0").split(",")]   # (token streams, decode stream)
+            self._dec_stream = torch.cuda.Stream(device=dev, priority=prio[1])
+        s_dec = self._dec_stream
+        lane_list = [self._token_lane(k) for k in range(lanes)]
+        if cu_limit is None:   # 0 = no budget: with several lanes the decoder is the longer stage and any cap costs throughput
+            cu_limit = int(os.environ.get("CCVS_PIPELINE_CU_LIMIT", "0"))
+        self.last_cu_limit, self.last_lanes = cu_limit, lanes
         entry = torch.cuda.current_stream()
         s_dec.wait_stream(entry)
-        s_tok.wait_stream(entry)
+        for _, st in lane_list:
+            st.wait_stream(entry)
         results, timings = [], []
         it = iter(batches)
         index = first_iter
+        debug = os.environ.get("CCVS_PIPELINE_DEBUG", "0") == "1"
 
         def budget(n):   # CU budget of everything submitted to the decode stream from now on
             ops.stream_cu_limit(s_dec, n)
 
-        def start(data, i):
+        def start(data, i, lane):
             """encode + crop on D; returns the job of batch i (its token stage is opened by `launch_tokens`)."""
             ev = {k: torch.cuda.Event(enable_timing=True) for k in ("e0", "e1", "t0", "t1", "d0", "d1")}
             with torch.cuda.stream(s_dec):
@@ -290,75 +323,105 @@ class Generator:
                 ev["e1"].record()
             for t in (ws["cropped"]["code"], ws["cropped"].get("cond_code"), ws["cropped"].get("state_code")):
                 if torch.is_tensor(t) and t.is_cuda:
-                    t.record_stream(s_tok)
-            return {"i": i, "ws": ws, "ev": ev, "codes": None, "error": None, "thread": None, "batch": data["vid"].shape[0]}
+                    t.record_stream(lane_list[lane][1])
+            return {"i": i, "ws": ws, "ev": ev, "codes": None, "error": None, "thread": None, "batch": data["vid"].shape[0], "lane": lane}
 
         def token_stage(job):
+            tr, s_tok = lane_list[job["lane"]]
             try:
                 torch.cuda.set_device(dev)
                 with torch.cuda.stream(s_tok), torch.no_grad():
                     s_tok.wait_event(job["ev"]["e1"])
-                    self._seed_sampler(job["batch"], job["i"])
+                    self._seed_sampler(job["batch"], job["i"], tr.net_t)
                     job["ev"]["t0"].record()
-                    job["codes"] = self.transformer_model(job["ws"]["cropped"], mode='inference', total_len=job["ws"]["total_len"])
+                    job["codes"] = tr(job["ws"]["cropped"], mode='inference', total_len=job["ws"]["total_len"])
                     job["ev"]["t1"].record()
             except BaseException as exc:   # re-raised by the main thread at the join
                 job["error"] = exc
 
         def launch_tokens(job):
-            if not self.transformer_model.net_t._graphs:
-                token_stage(job)       # nothing captured yet: the hipGraph capture of the decode step runs with no other thread issuing HIP calls
-                return
+            cold = [k for k in range(lanes) if k not in self._warm_lanes]
+            if cold:
+                # First use of a lane: its decode step is captured into a hipGraph, which must not race with HIP calls of other
+                # threads -- run the stage in this thread.  All cold lanes are warmed on THIS job (the others' result is
+                # discarded), so that a short warm-up phase covers every lane.
+                for k in cold:
+                    if k != job["lane"]:
+                        warm = dict(job, lane=k)
+                        token_stage(warm)
+                        if warm["error"] is not None:
+                            raise warm["error"]
+                        self._warm_lanes.add(k)
+                if job["lane"] in cold:
+                    token_stage(job)
+                    self._warm_lanes.add(job["lane"])
+                    return
             job["thread"] = threading.Thread(target=token_stage, args=(job,), name=f"ccvs-tokens-{job['i']}")
             job["thread"].start()
 
         def join_tokens(job):
             if job["thread"] is not None:
                 job["thread"].join()
+                job["thread"] = None
             if job["error"] is not None:
                 raise job["error"]
 
-        cur = None
+        pending = deque()                 # jobs whose tokens are in flight / done, oldest first
+        lane_job = [None] * lanes         # last job given to each lane
+        n_started = 0
         try:
             while True:
+                t_round = time.perf_counter()
                 data = next(it, None)
-                budget(cu_limit if cur is not None else 0)          # batch `cur`'s token loop is (still) in flight
-                nxt = start(data, index) if data is not None else None
-                index += 1
-                if cur is not None:
-                    join_tokens(cur)                                # all of its steps are enqueued: the transformer is free
-                if nxt is not None:
-                    launch_tokens(nxt)
-                if cur is not None:
-                    s_dec.wait_event(cur["ev"]["t1"])
-                    codes = cur["codes"]
-                    state_code = codes.get("state_code")
-                    if state_code is not None and 0 in state_code.size():
-                        state_code = None
-                    for t in (codes["code"], state_code):
-                        if torch.is_tensor(t):
-                            t.record_stream(s_dec)
-                    budget(cu_limit if nxt is not None else 0)
-                    with torch.cuda.stream(s_dec):
-                        cur["ev"]["d0"].record()
-                        fake = self.decode_codes(cur["ws"], codes["code"], state_code)
-                        cur["ev"]["d1"].record()
-                        done = finish(cur["i"], fake) if finish is not None else None
-                        for t in (fake["vid"], fake["code"]):   # handed to the caller's stream
-                            t.record_stream(entry)
-                    results.append({"fake": fake, "enc_code": cur["ws"]["encoded"]["code"], "finished": done, "index": cur["i"]})
-                    timings.append(cur["ev"])
-                    cur["ws"] = None
-                if nxt is None:
+                if data is not None:
+                    lane = n_started % lanes
+                    budget(cu_limit if pending else 0)
+                    job = start(data, index, lane)
+                    index += 1
+                    n_started += 1
+                    if lane_job[lane] is not None:
+                        join_tokens(lane_job[lane])                 # all of its steps are enqueued: the lane's engine is free
+                    lane_job[lane] = job
+                    launch_tokens(job)
+                    pending.append(job)
+                    if len(pending) <= lanes:
+                        continue                                    # fill the lanes before the first decode
+                elif not pending:
                     break
-                cur = nxt
+                t_enc = time.perf_counter()
+                cur = pending.popleft()
+                join_tokens(cur)
+                t_join = time.perf_counter()
+                s_dec.wait_event(cur["ev"]["t1"])
+                codes = cur["codes"]
+                state_code = codes.get("state_code")
+                if state_code is not None and 0 in state_code.size():
+                    state_code = None
+                for t in (codes["code"], state_code):
+                    if torch.is_tensor(t):
+                        t.record_stream(s_dec)
+                budget(cu_limit if pending else 0)
+                with torch.cuda.stream(s_dec):
+                    cur["ev"]["d0"].record()
+                    fake = self.decode_codes(cur["ws"], codes["code"], state_code)
+                    cur["ev"]["d1"].record()
+                    done = finish(cur["i"], fake) if finish is not None else None
+                    for t in (fake["vid"], fake["code"]):   # handed to the caller's stream
+                        t.record_stream(entry)
+                if debug:
+                    print(f"[pipeline] batch {cur['i']}: host ms -- encode(next) enqueue {1e3 * (t_enc - t_round):.0f}, wait for its token stage to be "
+                          f"enqueued {1e3 * (t_join - t_enc):.0f}, decode enqueue {1e3 * (time.perf_counter() - t_join):.0f}", file=sys.stderr, flush=True)
+                results.append({"fake": fake, "enc_code": cur["ws"]["encoded"]["code"], "finished": done, "index": cur["i"]})
+                timings.append(cur["ev"])
+                cur["ws"] = None
         finally:
-            for job in (cur, locals().get("nxt")):
-                if job is not None and job.get("thread") is not None and job["thread"].is_alive():
+            for job in list(pending) + [j for j in lane_job if j is not None]:
+                if job.get("thread") is not None and job["thread"].is_alive():
                     job["thread"].join()
             budget(0)
         entry.wait_stream(s_dec)
-        entry.wait_stream(s_tok)
+        for _, st in lane_list:
+            entry.wait_stream(st)
         self._pipeline_events = timings
         return results
 

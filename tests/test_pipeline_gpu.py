@@ -8,8 +8,8 @@ from tests.test_e2e_gpu import tiny, TINY_ARGV  # noqa: F401  (fixture)
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("sample,cu_limit", [(False, 0), (True, 6), (True, 200)])
-def test_pipelined_equals_serial(tiny, sample, cu_limit):
+@pytest.mark.parametrize("sample,cu_limit,lanes", [(False, 0, 1), (True, 6, 2), (True, 200, 3)])
+def test_pipelined_equals_serial(tiny, sample, cu_limit, lanes):
     from ccvs_amd.helpers.generator import Generator
     from ccvs_amd import ops
     xopt = tiny["xopt"]
@@ -19,13 +19,13 @@ def test_pipelined_equals_serial(tiny, sample, cu_limit):
     try:
         gen = Generator(tiny["opt"])
         gen.vid_model, gen.transformer_model = tiny["qv"], tiny["tr"]
-        batches = [gen.synthetic_batch(2, seed=80 + i)["vid"] for i in range(4)]
+        batches = [gen.synthetic_batch(2, seed=80 + i)["vid"] for i in range(5)]
         serial = [gen.generate_vid({"vid": b.clone()}, global_iter=10 + i) for i, b in enumerate(batches)]
         packed = []
-        res = gen.run_pipelined(({"vid": b.clone()} for b in batches), first_iter=10, cu_limit=cu_limit,
+        res = gen.run_pipelined(({"vid": b.clone()} for b in batches), first_iter=10, cu_limit=cu_limit, lanes=lanes,
                                 finish=lambda i, fake: packed.append((i, ops.pack_u8(fake["vid"]))))
         torch.cuda.synchronize()
-        assert [r["index"] for r in res] == [10, 11, 12, 13] and [i for i, _ in packed] == [10, 11, 12, 13]
+        assert [r["index"] for r in res] == [10, 11, 12, 13, 14] and [i for i, _ in packed] == [10, 11, 12, 13, 14]
         for want, got, (_, u8) in zip(serial, res, packed):
             assert torch.equal(got["enc_code"], want["enc_code"])
             assert torch.equal(got["fake"]["code"], want["fake"]["code"])

@@ -1,0 +1,57 @@
+"""Two token loops at once: two shallow copies of the BAIR-size GPT (shared weights, own KV cache / decode graph) generate on
+two high-priority streams from two host threads.  How much does each slow down?   python tools/token_lanes_probe.py [tokens]"""
+import copy
+import os
+import sys
+import threading
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ccvs_amd.models.skip_vid_generator.models import mingpt  # noqa: E402
+
+tokens = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+torch.manual_seed(0)
+net = mingpt.GPT(vocab_size=1024, block_size=1024, num_blocks=16, n_layer=24, n_head=16, n_embd=1024, emb_mode="temporal", shape=(8, 8)).cuda()
+
+
+def lane_of(n):
+    c = copy.copy(n)
+    c._cache, c._graphs = None, {}
+    return c
+
+
+lanes = [net, lane_of(net), lane_of(net)]
+streams = [torch.cuda.Stream(priority=-1) for _ in lanes]
+code = torch.randint(0, 1024, (16, 64), device="cuda")
+for ln, st in zip(lanes, streams):
+    with torch.cuda.stream(st):
+        ln.generate(code, 8, sample=True, top_k=100)   # capture, one lane at a time
+torch.cuda.synchronize()
+
+
+def run(k):
+    res = [None] * k
+
+    def work(i):
+        with torch.cuda.stream(streams[i]), torch.no_grad():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            lanes[i].generate(code, tokens, sample=True, top_k=100)
+            e1.record()
+            e1.synchronize()
+            res[i] = 1e3 * e0.elapsed_time(e1) / tokens
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(k)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    return res
+
+
+for k in (1, 2, 3):
+    r = run(k)
+    print(f"{k} token loop(s) at once: " + ", ".join(f"{v:.0f}" for v in r) + f" us/token each -> {sum(1e6 / v for v in r) * 16 / 1e3:.1f} k clip-tokens/s in total", flush=True)
