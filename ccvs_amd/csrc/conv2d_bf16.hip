@@ -810,19 +810,26 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, int CinG, int
     // CUs and work on another stream (the token loop of the next batch) always finds the remaining ones free.
     long n_chunk = 1, cap = 0;
     const long total = (long)grid3.x * grid3.y * grid3.z;
+    static const int xcd_aware = getenv("CCVS_CONV_XCD") ? atoi(getenv("CCVS_CONV_XCD")) : 1;
     auto plan = [&](const void* fn, int threads, size_t smem_bytes) {
         k.nwork = 0; k.work0 = 0;
+        k.gx = (int)grid3.x; k.gy = (int)grid3.y;
+        k.xcd_chunk = (xcd_aware && total % 8 == 0 && total >= 64) ? (int)(total / 8) : 0;
         n_chunk = 1;
         if (k.cu_limit <= 0) return;
         cap = (long)k.cu_limit * conv_occupancy(fn, threads, smem_bytes);
         if (total <= cap) return;  // fits as it is
-        k.nwork = (int)total; k.gx = (int)grid3.x; k.gy = (int)grid3.y;
+        cap -= cap % 8;            // chunks of whole rounds over the XCDs
+        if (cap < 8) cap = 8;
+        k.nwork = (int)total;
         n_chunk = (total + cap - 1) / cap;
     };
     auto chunk_grid = [&](long c) -> dim3 {
         if (k.nwork == 0) return grid3;
         k.work0 = (int)(c * cap);
-        return dim3((unsigned)((total - c * cap < cap) ? total - c * cap : cap));
+        const long n = (total - c * cap < cap) ? total - c * cap : cap;
+        k.xcd_chunk = (xcd_aware && n % 8 == 0 && n >= 64) ? (int)(n / 8) : 0;   // within the chunk
+        return dim3((unsigned)n);
     };
 #define CB_LAUNCH(KERNEL, THREADS, SMEM, ...)                                                    \
     do {                                                                                          \
@@ -914,7 +921,7 @@ extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const flo
     k.act = d->act; k.accumulate = d->accumulate; k.out_scale = d->out_scale;
     k.pre = d->pre; k.pre_sN = d->pre_sN; k.pre_sC = d->pre_sC; k.pre_div = d->pre_div > 0 ? d->pre_div : 1;
     k.in_p8 = d->in_p8 ? 1 : 0; k.out_p8 = d->out_p8 ? 1 : 0;
-    k.nwork = 0; k.gx = k.gy = 1; k.work0 = 0; k.cu_limit = d->cu_limit > 0 ? d->cu_limit : ccvs_cu_limit_of(stream);
+    k.nwork = 0; k.gx = k.gy = 1; k.work0 = 0; k.xcd_chunk = 0; k.cu_limit = d->cu_limit > 0 ? d->cu_limit : ccvs_cu_limit_of(stream);
     if (k.in_p8) CCVS_REQUIRE(!d->transposed && d->stride == 1 && d->Cin % 8 == 0, "ccvs_conv2d_bf16x3: packed input needs stride 1, Cin %% 8 == 0");
     if (k.out_p8) CCVS_REQUIRE(!d->transposed && d->Cout % 8 == 0 && !d->accumulate && !residual, "ccvs_conv2d_bf16x3: packed output needs Cout %% 8 == 0, no residual / accumulate");
     const int CinG = 2 * ((d->Cin + 15) / 16);  // 8-channel groups, Cin padded to 16

@@ -24,20 +24,26 @@ struct ConvK {
     // CU-limited form (ccvs_conv_desc.cu_limit > 0): the nwork = gx * gy * gz tiles (x fastest, like the 3-D grid's dispatch
     // order) are launched as consecutive 1-D chunks of at most cu_limit x occupancy workgroups; a chunk starts at tile work0
     int nwork, gx, gy, work0;
+    int xcd_chunk;  // XCD-aware order of the tiles of one launch (see CONV_TILE_COORDS)
     int cu_limit;  // host side only: CUs this launch may occupy (0 = classic 3-D grid over all of them)
 };
 
-// tile coordinates of a workgroup: the 3-D grid (nwork == 0) or tile work0 + blockIdx.x of a chunk
+// Tile coordinates of a workgroup.  Workgroups are handed to the 8 XCDs round-robin in dispatch order (linear id % 8), and
+// each XCD has its own L2: with the identity mapping the 8 neighbours of a tile -- whose halo rows and columns it shares --
+// are all fetched through OTHER L2s.  The linear id is therefore re-mapped so that XCD j walks the j-th contiguous eighth
+// of the tile sequence (x fastest within an image): neighbouring tiles then meet in the same L2, at about the same time.
+// (xcd_chunk = tiles / 8 when that divides, else 0 = identity; correctness does not depend on the placement.)
 #define CONV_TILE_COORDS(p, bx, by, bz)                                         \
     int bx, by, bz;                                                             \
-    if ((p).nwork > 0) {                                                        \
-        const int w_ = (p).work0 + (int)blockIdx.x;                             \
+    {                                                                           \
+        int w_ = (p).nwork > 0 ? (int)blockIdx.x                                \
+                               : (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)); \
+        if ((p).xcd_chunk > 0) w_ = (w_ & 7) * (p).xcd_chunk + (w_ >> 3);       \
+        w_ += (p).work0;                                                        \
         bx = w_ % (p).gx;                                                       \
         const int r_ = w_ / (p).gx;                                             \
         by = r_ % (p).gy;                                                       \
         bz = r_ / (p).gy;                                                       \
-    } else {                                                                    \
-        bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;                      \
     }
 
 struct AxisTaps {

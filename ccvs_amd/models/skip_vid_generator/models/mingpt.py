@@ -464,8 +464,25 @@ class GPT(nn.Module):
         if trace is not None:
             trace.append(c["logits"].clone())
 
-    def _decode_graph(self, sampler, key):
-        """The decode step of the current cache captured in a hipGraph (once per key).  Captured on live state: a warm-up
+    GRAPH_STEPS = 8   # decode steps per replay of the long form of the captured graph
+
+    def _replay_steps(self, sampler, key, n):
+        """n decode steps: replays of a hipGraph of GRAPH_STEPS steps (all per-step state is device-resident, so a graph of
+        several steps is just the step captured several times; it costs the host 1/GRAPH_STEPS of the launches -- the token
+        stages of several batches are enqueued by concurrent host threads) and of the one-step graph for the remainder."""
+        k = self.GRAPH_STEPS
+        if n >= 2 * k:
+            long_graph = self._decode_graph(sampler, key + (k,), steps=k)
+            for _ in range(n // k):
+                long_graph.replay()
+            n -= (n // k) * k
+        if n:
+            graph = self._decode_graph(sampler, key)
+            for _ in range(n):
+                graph.replay()
+
+    def _decode_graph(self, sampler, key, steps=1):
+        """`steps` decode steps of the current cache captured in a hipGraph (once per key).  Captured on live state: a warm-up
         step runs first (one-time attribute calls, descriptor), then the device-resident state is put back."""
         c = self._cache
         self._decode_desc(sampler)   # a changed weight version / sampler rebuilds the descriptor and drops the graphs built on the old one
@@ -483,7 +500,8 @@ class GPT(nn.Module):
             # thread_local: with torch.distributed initialised the RCCL watchdog thread issues HIP calls of its own, which the
             # default 'global' capture mode would treat as capture violations
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                self._decode_body(sampler)
+                for _ in range(steps):
+                    self._decode_body(sampler)
             for k, v in state.items():   # capture does not execute; kept for clarity
                 c[k].copy_(v)
             self._graphs[key] = graph
@@ -561,9 +579,7 @@ class GPT(nn.Module):
                     run += 1
                 c["len_dev"].fill_(c["len"])
                 c["widx"].fill_(n_code)
-                graph = self._decode_graph(sampler, (sampler["sample"], sampler["top_k"], sampler["temperature"], n_cond, b, "stream"))
-                for _ in range(run):
-                    graph.replay()
+                self._replay_steps(sampler, (sampler["sample"], sampler["top_k"], sampler["temperature"], n_cond, b, "stream"), run)
                 c["len"] += run          # each replay appended the previous pick, then picked the next
                 n_code += run
                 fed += run
@@ -631,11 +647,10 @@ class GPT(nn.Module):
         else:
             self._emit(logits, sampler, host_noise(b, logits.shape[1]).to(logits.device, non_blocking=True) if sample else None, t0)
 
-        graph = None if eager else self._decode_graph(sampler, (bool(sample), top_k, float(temperature), n_cond, b))
-        for _ in range(add_len - 1):
-            if graph is not None:
-                graph.replay()
-            else:
+        if not eager:
+            self._replay_steps(sampler, (bool(sample), top_k, float(temperature), n_cond, b), add_len - 1)
+        else:
+            for _ in range(add_len - 1):
                 nz = None
                 if sample and noise != "device":
                     nz = host_noise(b, self.head.weight.shape[0]).to(code.device, non_blocking=True)
