@@ -199,6 +199,76 @@ extern "C" int ccvs_backwarp_ctx(const ccvs_ctx_list* ctx, int64_t x_sC, const f
 }
 
 // ---------------------------------------------------------------------------------------
+// backwarp + 1x1 projection in one pass: Matching warps each context feature with the carried flow and immediately
+// projects it to max(16, C/4) channels for the cost volume (skip_autoencoder.py:186-190: proj(backwarp(inter, flow))).
+// Done as two kernels the warped C-channel tensor is written and read back once (6 GB per level-5 call at BAIR size) only
+// to be reduced 4x; here a lane owns one pixel, samples channel after channel (set-up shared by all channels) and keeps
+// the CO projected channels in registers:  y[n][o][p] = lrelu(b[o] + sum_c W[o][c] * warp(x)[n][c][p]).
+// The weight row of a channel is wave-uniform (scalar loads).  fp32 FMAs: exact products, unlike the split-bf16 convolution.
+// ---------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256) void warp_proj_kernel(CtxList ctx, long x_sC, const float* __restrict__ flow, long flow_sN, float mult,
+                                                        const float* __restrict__ wt, const float* __restrict__ bias,
+                                                        float* __restrict__ y, int Cin, int Cout, int H, int W, int act, GridWalk gw) {
+    const int HW = H * W;
+    GRID_WALK_BEGIN(gw, bx, by, bz)
+    (void)bz;
+    const int pix = bx * 256 + threadIdx.x;
+    if (pix >= HW) continue;
+    const int n = by;
+    const int jn = n % ctx.k;
+    const float* x = ctx.p[jn] + (long)(n / ctx.k) * ctx.sN[jn];
+    const int py = pix / W, px = pix - py * W;
+    const float fx = flow[(long)n * flow_sN + pix] * mult, fy = flow[(long)n * flow_sN + HW + pix] * mult;
+    const Bilin b = bilin_setup(px, py, fx, fy, H, W);
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+#pragma unroll 2
+    for (int c = 0; c < Cin; ++c) {
+        const float v = bilin_sample(x + (long)c * x_sC, b);
+        const float* wr = wt + (long)c * CO;   // [Cin][CO]: the CO weights of input channel c, the same for every lane
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[o] += wr[o] * v;
+    }
+    float* yo = y + (long)n * Cout * HW + pix;
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+        if (o < Cout) {
+            float v = acc[o] + (bias ? bias[o] : 0.f);
+            if (act == CCVS_ACT_LRELU) v = lrelu01(v);
+            yo[(long)o * HW] = v;
+        }
+    }
+    GRID_WALK_END
+}
+
+extern "C" int ccvs_backwarp_proj_ctx(const ccvs_ctx_list* ctx, int64_t x_sC, const float* flow, int64_t flow_sN, float flow_mult,
+                                      const float* w_t, const float* bias, float* y, int32_t N, int32_t Cin, int32_t Cout, int32_t CoutPad,
+                                      int32_t H, int32_t W, int32_t act, void* stream) {
+    CCVS_REQUIRE(flow && w_t && y, "ccvs_backwarp_proj_ctx: null pointer");
+    CtxList l = {};
+    const int rc = fill_ctx(l, ctx, "ccvs_backwarp_proj_ctx");
+    if (rc != CCVS_OK) return rc;
+    CCVS_REQUIRE(N > 0 && N % l.k == 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "ccvs_backwarp_proj_ctx: bad shape");
+    CCVS_REQUIRE(CoutPad >= Cout && (CoutPad == 16 || CoutPad == 24 || CoutPad == 48 || CoutPad == 96),
+                 "ccvs_backwarp_proj_ctx: %d output channels (padded %d) unsupported (16, 24, 48, 96)", Cout, CoutPad);
+    const GridWalk gw = grid_walk(cdiv(H * W, 256), N, 1);
+    const dim3 grid(limited_grid(gw.total, stream, 4));
+    hipStream_t st = (hipStream_t)stream;
+#define WP_LAUNCH(CO)                                                                                                               \
+    hipLaunchKernelGGL((warp_proj_kernel<CO>), grid, dim3(256), 0, st, l, (long)x_sC, flow, (long)flow_sN, flow_mult, w_t, bias, y, Cin, Cout, \
+                       H, W, act, gw)
+    if (CoutPad == 16) WP_LAUNCH(16);
+    else if (CoutPad == 24) WP_LAUNCH(24);
+    else if (CoutPad == 48) WP_LAUNCH(48);
+    else WP_LAUNCH(96);
+#undef WP_LAUNCH
+    CCVS_CHECK_LAUNCH("ccvs_backwarp_proj_ctx");
+    return CCVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // InterBlock tail (skip_autoencoder.py:254-264): warp each of the k context features with
 // its final flow, fuse with confidences 1 - sigmoid(occ_k) + eps, blend into the decoder
 // feature with sigmoid of the fused occlusion.  One lane per pixel, WARP_CCH channels per

@@ -264,13 +264,22 @@ class InterBlock(nn.Module):
         # (`pre`) and broadcast inside the conv epilogue; only [warped | flow | occ] is materialised per pair.
         sp_in = torch.empty(n * k, s + 3, h, w, dtype=torch.float32, device=dec.device)
         fo = sp_in[:, s:]
+        inter_w = None
         if fo_prev is not None:
             ops.dwconvT4x4s2(fo_prev, self._upsample_fo_weight(), out=fo)       # learned x2 of flow and occ
-            inter_w = ops.backwarp(ctxs, fo[:, :2], self.flow_mult)
+            proj_w = self._proj_weight() if (m.proj is not None and ops.FUSE_WARP_PROJ) else None
+            if proj_w is None:
+                inter_w = ops.backwarp(ctxs, fo[:, :2], self.flow_mult)
         else:  # coarsest level: the cost volume reads the contexts themselves
+            proj_w = None
             inter_w = torch.stack(ctxs, dim=1).view(n * k, s, h, w)
         if m.proj is not None:
-            pa, pb = m.proj(dec), m.proj(inter_w)                                # input projected once per n, not k times
+            pa = m.proj(dec)                                                     # input projected once per n, not k times
+            if inter_w is None:   # warp and projection in one pass: the warped s-channel tensor is never written
+                pb = ops.backwarp_proj(ctxs, fo[:, :2], self.flow_mult, proj_w[0], proj_w[1], m.proj.conv.bias, m.proj.conv.out_channel,
+                                       act=m.proj.activate)
+            else:
+                pb = m.proj(inter_w)
         else:
             pa, pb = dec.contiguous(), inter_w
         corr = ops.correlation7x7(pa, pb, self.corr_stride, first_div=k, lrelu=True)
@@ -291,6 +300,14 @@ class InterBlock(nn.Module):
         del feat, pre
         ops.warp_fuse_blend(dec, ctxs, fo[:, :2], fo[:, 2:3], self.flow_mult, k)
         return fo
+
+    def _proj_weight(self):
+        """(w_t, CoutPad) of Matching.proj for `ops.backwarp_proj`, or None when the fused kernel has no instantiation."""
+        w = self.matching.proj.conv.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if getattr(self, "_projw", None) is None or self._projw[0] != key:
+            self._projw = (key, ops.pack_proj_weight(w))
+        return self._projw[1]
 
     def _sub0_split(self):
         """First Subpixel conv split along its input channels: (dec block, [warped | flow | occ] block), both

@@ -78,6 +78,8 @@ def _as_rows_dense(t):
 #   "bf16x3": split-bf16, 3 products per fp32 product on v_mfma_f32_32x32x16_bf16 (default)
 #   "f32"   : exact fp32 on v_mfma_f32_32x32x2_f32
 CONV_PRECISION = "bf16x3"
+# Matching: warp + 1x1 projection of the contexts in one kernel (`backwarp_proj`) instead of backwarp followed by the convolution.
+FUSE_WARP_PROJ = __import__("os").environ.get("CCVS_FUSE_WARP_PROJ", "1") == "1"
 # Explicit `ccvs_conv_desc.cu_limit` of the convolution launches (0 = the budget of the stream, see `stream_cu_limit`); tests.
 CONV_CU_LIMIT = 0
 
@@ -322,6 +324,36 @@ def backwarp(x, flow, flow_mult=1.0, out=None):
     assert _rows_dense(out)
     _lib.check(L.ccvs_backwarp(_p(x), x.stride(0), x.stride(1), _p(flow), flow.stride(0), flow_mult, _p(out), out.stride(0),
                                out.stride(1), n, c, h, w, _stream()), "ccvs_backwarp")
+    return out
+
+
+def pack_proj_weight(weight):
+    """1x1 EqualConv2d weight [Cout,Cin,1,1] -> (w_t [Cin][CoutPad] with the 1/sqrt(Cin) scale multiplied in, CoutPad) for
+    `backwarp_proj`; None when Cout has no instantiation."""
+    cout, cin = weight.shape[:2]
+    pads = [p_ for p_ in (16, 24, 48, 96) if p_ >= cout]
+    if not pads:
+        return None
+    w = (weight.detach().float().view(cout, cin) * (1 / math.sqrt(cin))).t()
+    out = torch.zeros(cin, pads[0], dtype=torch.float32, device=weight.device)
+    out[:, :cout] = w
+    return out.contiguous(), pads[0]
+
+
+def backwarp_proj(ctxs, flow, flow_mult, w_t, cout_pad, bias, cout, act=True):
+    """act(bias + W . backwarp(ctx, flow * flow_mult)) for the list of k context tensors [N/k,C,H,W] (see `backwarp`):
+    [N,cout,H,W], the warped tensor is never materialised (`ccvs_backwarp_proj_ctx`)."""
+    _need_gpu(flow, w_t, bias)
+    if not _planes_dense(flow):
+        flow = flow.contiguous()
+    cl, keep = _ctx_list(ctxs)
+    nf, c, h, w = keep[0].shape
+    n = nf * cl.k
+    assert flow.shape == (n, 2, h, w) and w_t.shape == (c, cout_pad)
+    out = torch.empty(n, cout, h, w, dtype=torch.float32, device=flow.device)
+    L = _lib.load()
+    _lib.check(L.ccvs_backwarp_proj_ctx(C.byref(cl), h * w, _p(flow), flow.stride(0), flow_mult, _p(w_t), _p(bias), _p(out), n, c, cout, cout_pad,
+                                        h, w, ACT_LRELU if act else ACT_NONE, _stream()), "ccvs_backwarp_proj_ctx")
     return out
 
 

@@ -140,6 +140,14 @@ int ccvs_warp_fuse_blend_ctx(float* dec, int64_t dec_sN, int64_t dec_sC, const c
                              int64_t flows_sN, const float* occs, int64_t occs_sN, float flow_mult, int32_t N, int32_t C,
                              int32_t H, int32_t W, void* stream);
 
+/* Matching's proj(backwarp(inter, flow * flow_mult)) (skip_autoencoder.py:186-190, ConvLayer(C, max(16, C/4), 1)) in one pass:
+ * y[n][o] = act(bias[o] + sum_c w_t[c][o] * backwarp(ctx)[n][c]) -- the warped C-channel tensor is never written.
+ * ctx as in ccvs_backwarp_ctx; w_t [Cin][CoutPad] fp32, the 1x1 weight transposed with the EqualConv2d scale multiplied in
+ * and zero columns up to CoutPad in {16, 24, 48, 96}; y [N,Cout,H,W] dense.  fp32 FMAs. */
+int ccvs_backwarp_proj_ctx(const ccvs_ctx_list* ctx, int64_t x_sC, const float* flow, int64_t flow_sN, float flow_mult,
+                           const float* w_t, const float* bias, float* y, int32_t N, int32_t Cin, int32_t Cout, int32_t CoutPad,
+                           int32_t H, int32_t W, int32_t act, void* stream);
+
 /* Tail of InterBlock.forward (skip_autoencoder.py:254-264): final back-warp of the k
  * context features, confidence fusion over k (eps 1e-6) and occlusion blend, written in
  * place into the first C channels of the decoder feature.

@@ -538,3 +538,23 @@ def test_attention_prefill_mfma(ops, D, B, H, Tq, pos0):
     close(got, want, 2e-5)
     pos_dev = torch.tensor([pos0], dtype=torch.int32).cuda()      # device-resident offset
     close(ops.attention(q.cuda(), kc.cuda(), vc.cuda(), 0, pos_dev), want, 2e-5)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,k", [(96, 24, 40, 72, 3), (192, 48, 16, 16, 2), (384, 96, 8, 8, 1), (40, 16, 9, 13, 2)])
+def test_backwarp_proj_fused(ops, cin, cout, h, w, k):
+    """ccvs_backwarp_proj_ctx == ConvLayer(C, C', 1)(backwarp(ctx, flow * mult)) of Matching (skip_autoencoder.py:186-190), with
+    the contexts read in place from a list, out-of-range flows, and Cout below its padded instantiation."""
+    g = torch.Generator().manual_seed(cin + k)
+    nf = 3
+    ctxs = [torch.randn(nf, cin, h, w, generator=g) for _ in range(k)]
+    flow = torch.randn(nf * k, 2, h, w, generator=g) * 2.5
+    flow[0, :, 0, 0] = 1e4                                   # far outside: zero padding
+    wt = torch.randn(cout, cin, 1, 1, generator=g)
+    bias = torch.randn(cout, generator=g)
+    mult = 4.0
+    stacked = torch.stack(ctxs, dim=1).reshape(nf * k, cin, h, w)
+    warped = O.backwarp(stacked, flow * mult, O.backwarp_grid(h, w))
+    want = torch.nn.functional.leaky_relu(O.equal_conv2d(warped, wt, bias), 0.1)
+    w_t, cpad = ops.pack_proj_weight(wt.cuda())
+    got = ops.backwarp_proj([c.cuda() for c in ctxs], flow.cuda(), mult, w_t, cpad, bias.cuda(), cout)
+    close(got, want, 1e-4)   # sample positions differ from grid_sample's by an ulp of the (scaled) coordinates
