@@ -235,8 +235,8 @@ def conv_traffic(args, kind, launches):
 
 def main():
     args = parse_args()
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(launch_ranks(args))
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("CCVS_BENCH_FORCE_LAUNCHER") == "1"):
+        sys.exit(launch_ranks(args))       # (the env switch exercises the child-launch path on a one-GPU box)
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
