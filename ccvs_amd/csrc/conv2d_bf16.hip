@@ -539,8 +539,13 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
     } else if (producer && VEC) {
         // chunk c is requested at step (c-2, 0) and converted + stored at step (c-1, 0), a whole chunk later; these are
         // the wave's only outstanding loads.  Requests past the end re-read the last chunk (and are never stored).
+        // The step barrier of the staging waves is a RAW s_barrier behind an LDS-only wait: __syncthreads() also drains
+        // vmcnt, i.e. it would make the wave sit at the first barrier of a chunk until the global loads it has just requested
+        // for the chunk after next have landed -- and the MFMA waves with it.  The loads stay in flight across the three
+        // barriers; hipcc waits for them where their registers are first read (store_xv, a chunk later).
         constexpr int NTYc = VEC ? NTY : 1;
         const bool work = !(ablate & 1);
+        const bool drain = ablate & 64;   // experiments: the old __syncthreads() steps
         if (work) load_xv(min(1, nchunks - 1));
         __syncthreads();
         for (int ci = 0; ci < nchunks; ++ci) {
@@ -549,8 +554,12 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
                 load_xv(min(ci + 2, nchunks - 1));
             }
 #pragma unroll
-            for (int a = 0; a < NTYc; ++a) __syncthreads();
+            for (int a = 0; a < NTYc; ++a) {
+                if (drain) __syncthreads();
+                else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (never stored) request
     } else if (producer) {
       int ci = -1, a = nt - 1;
       for (int s = -1; s < nsteps; ++s) {
