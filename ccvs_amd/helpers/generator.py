@@ -43,9 +43,9 @@ class Generator:
         self.state_model = None
         self._lanes, self._dec_stream, self._warm_lanes = None, None, set()
         self.last_cu_limit, self.last_lanes = 0, 0
-        for flag in ("layout", "deblurring", "cat"):
+        for flag in ("layout", "deblurring"):
             if getattr(self.opt, flag, False):
-                raise NotImplementedError(f"--{flag} is not on the MI355X path (SURVEY 8f); --x_state / --x_stft [--keep_state] are")
+                raise NotImplementedError(f"--{flag} is not on the MI355X path (SURVEY 8f); --x_state / --x_stft [--keep_state] / --x_cat are")
 
     # ------------------------------------------------------------------ models / data
     def build_models(self, is_main=True):
@@ -164,6 +164,10 @@ class Generator:
                 cropped["state_code"] = self.state_model(custom_state, mode='vid_encoder')["state_code"]
             else:
                 cropped["state_code"] = encoded_data["state_code"][:, :int(crop_prop * encoded_data["state_code"].size(1))]
+        if opt.cat:                                                         # generator.py:123-126: class-conditional generation
+            if "vid_lbl" not in data:
+                data["vid_lbl"] = torch.randint(low=0, high=len(opt.categories), size=[encoded_data["code"].size(0)])
+            cropped["vid_lbl"] = data["vid_lbl"]
         return {"data": data, "encoded": encoded_data, "cropped": cropped, "total_len": total_len, "cond_len": cond_len,
                 "crop_prop": crop_prop}
 

@@ -106,8 +106,8 @@ class GPT(nn.Module):
                  attn_pdrop=0., n_unmasked=0, resid_noise=False, emb_mode=None, shape=None, state_vocab_size=0, state_size=0,
                  use_start_token=False, num_lbl=0, use_lbl=False, state_front=False):
         super().__init__()
-        if use_start_token or use_lbl or n_unmasked:
-            raise NotImplementedError("start / label tokens and unmasked prefixes are not on the MI355X path (SURVEY 8f)")
+        if n_unmasked:
+            raise NotImplementedError("unmasked prefixes are not on the MI355X path (SURVEY 8f)")
         config = GPTConfig(block_size=block_size, vocab_size=vocab_size, embd_pdrop=embd_pdrop, resid_pdrop=resid_pdrop,
                            attn_pdrop=attn_pdrop, n_layer=n_layer, n_head=n_head, n_embd=n_embd, n_unmasked=n_unmasked,
                            resid_noise=resid_noise, shape=shape, emb_mode=emb_mode, state_vocab_size=state_vocab_size,
@@ -116,6 +116,10 @@ class GPT(nn.Module):
         self.tok_emb = nn.Embedding(config.vocab_size, config.n_embd)
         if config.state_vocab_size > 0:  # ancillary (state / STFT) token stream, mingpt.py:134-135
             self.state_tok_emb = nn.Embedding(config.state_vocab_size, config.n_embd)
+        if config.use_start_token:   # mingpt.py:136-137 (consumes the RNG stream right here)
+            self.start_tok_emb = nn.Parameter(torch.randn(1, config.n_embd))
+        if config.use_lbl:           # mingpt.py:140-141
+            self.lbl_emb = nn.Embedding(config.num_lbl, config.n_embd)
         height, width = config.shape
         if config.emb_mode is not None:
             if config.emb_mode == "spatio-temporal":
@@ -138,7 +142,7 @@ class GPT(nn.Module):
         self.blocks = nn.Sequential(*[Block(config) for _ in range(config.n_layer)])
         self.ln_f = nn.LayerNorm(config.n_embd)
         self.head = nn.Linear(config.n_embd, max(config.vocab_size, config.state_vocab_size), bias=False)
-        self.block_size = config.block_size
+        self.block_size = config.block_size + (1 if config.use_start_token else 0) + (1 if config.use_lbl else 0)   # mingpt.py:171
         self.apply(self._init_weights)
         self.config = config
         self._cache = None
@@ -315,7 +319,7 @@ class GPT(nn.Module):
             tot = cfg.shape[0] * cfg.shape[1] + cfg.state_size
             table = self._stream_pos_table(c["T"] if cfg.state_front else min(c["T"], cfg.num_blocks * tot), n_state_front)
         else:
-            table = self.get_pos_emb(min(c["T"], self.block_size))[0]
+            table = self.get_pos_emb(min(c["T"], cfg.block_size))[0]   # frame-token positions (label / start tokens carry none)
         if "pos_table" in c and c["pos_table"].shape == table.shape:
             c["pos_table"].copy_(table)   # same storage: captured graphs keep pointing at it
         else:
@@ -355,16 +359,35 @@ class GPT(nn.Module):
     def _head(self, x):
         return ops.gemm_ln(x, *self._head_packed()[1], eps=self.ln_f.eps)
 
+    def n_prefix(self):
+        """Positions the label / start tokens occupy in front of every sequence (mingpt.py:289-297)."""
+        return (1 if self.config.use_lbl else 0) + (1 if self.config.use_start_token else 0)
+
+    def _prefix_emb(self, b, lbl_idx):
+        """[B, n_prefix, C]: [label embedding | start embedding] -- no positional part (mingpt.py:289-297)."""
+        rows = []
+        if self.config.use_lbl:
+            assert lbl_idx is not None and 0 not in lbl_idx.size(), "label tokens (--x_cat) need data['vid_lbl']"
+            rows.append(self.lbl_emb.weight.detach()[lbl_idx.to(self.lbl_emb.weight.device).view(-1)].view(b, 1, -1))
+        if self.config.use_start_token:
+            rows.append(self.start_tok_emb.detach().view(1, 1, -1).expand(b, 1, -1))
+        return torch.cat(rows, dim=1) if rows else None
+
     @torch.no_grad()
-    def prefill(self, idx, cond_idx=None, delta_length_cond=None, all_logits=False):
-        """Run [cond prefix | idx] through the network, filling the cache from position 0.  `idx` holds rows of
+    def prefill(self, idx, cond_idx=None, delta_length_cond=None, all_logits=False, lbl_idx=None):
+        """Run [label | start | cond prefix | idx] through the network, filling the cache from position 0.  `idx` holds rows of
         `_token_table()` (= frame token ids; merged-sequence rows for a stream cache, see `_stream_rows`).
-        Returns logits of the last position [B,V], or of every idx position [B,T,V]."""
+        Returns logits of the last position [B,V], or -- like the reference's `head(x)[:, t_cond:]` -- of every position
+        from t_cond on [B, n_prefix + T, V]."""
         c = self._cache
         b, t = idx.shape
         C = self.config.n_embd
         use_cond = cond_idx is not None and 0 not in cond_idx.size()
         parts = []
+        prefix = self._prefix_emb(b, lbl_idx)
+        n_pre = 0 if prefix is None else prefix.shape[1]
+        if prefix is not None:
+            parts.append(prefix.float())
         if use_cond:
             t_cond = cond_idx.shape[1]
             cond_tab = self.get_pos_emb(t_cond, delta_length_cond)               # [n, t_cond, C]
@@ -377,13 +400,13 @@ class GPT(nn.Module):
             t_cond = 0
         parts.append(ops.gpt_embed(idx.contiguous(), self._token_table(), c["pos_table"], 0).view(b, t, C))
         x = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
-        tq = t_cond + t
+        tq = n_pre + t_cond + t
         assert c["len"] == 0 and tq <= c["T"], "Cannot forward, model block size is exhausted."
         x = self._layers(x.reshape(b * tq, C).contiguous(), b, tq)
-        c["frame_pos0"] = t_cond  # cache position of frame token 0
+        c["frame_pos0"] = n_pre + t_cond  # cache position of frame token 0
         if all_logits:
-            xs = x.view(b, tq, C)[:, t_cond:].reshape(b * t, C)
-            return self._head(xs).view(b, t, -1)
+            xs = x.view(b, tq, C)[:, t_cond:].reshape(b * (tq - t_cond), C)
+            return self._head(xs).view(b, tq - t_cond, -1)
         return self._head(x.view(b, tq, C)[:, -1].contiguous())
 
     @torch.no_grad()
@@ -615,7 +638,7 @@ class GPT(nn.Module):
 
     @torch.no_grad()
     def generate(self, code, add_len, cond_idx=None, delta_length_cond=None, sample=False, top_k=None, temperature=1.0,
-                 noise="device", host_noise=None, trace=None, use_graph=True, state_code=None, state_sampler=None):
+                 noise="device", host_noise=None, trace=None, use_graph=True, state_code=None, state_sampler=None, lbl_idx=None):
         """code [B,t0] -> [B, t0+add_len]: one prefill, then KV-cached decode steps.
         With an ancillary stream (`state_code` [B,ns], `state_sampler` = dict(sample, top_k, temperature, vocab)) the
         add_len new tokens are split between the two streams as the reference does and (code, state_code) is returned.
@@ -627,20 +650,23 @@ class GPT(nn.Module):
         use_cond = cond_idx is not None and 0 not in cond_idx.size()
         n_cond = cond_idx.shape[1] if use_cond else 0
         sampler = {"sample": bool(sample), "top_k": top_k, "temperature": float(temperature), "noise": noise}
+        n_pre = self.n_prefix()
         if state_code is not None and 0 not in state_code.size():
+            if n_pre:
+                raise NotImplementedError("label / start tokens together with an ancillary token stream")
             return self._generate_stream(code, state_code, add_len, cond_idx if use_cond else None,
                                          delta_length_cond if use_cond else None, sampler, state_sampler, host_noise, trace, use_graph)
         eager = trace is not None or (sample and noise != "device") or not use_graph or add_len < 3
-        max_len = n_cond + t0 + add_len
+        max_len = n_pre + n_cond + t0 + add_len
         c = self.begin(b, max_len)
 
         device_rng = sample and noise == "device"
         words = self._philox_words() if device_rng else None
-        logits = self.prefill(code, cond_idx if use_cond else None, delta_length_cond if use_cond else None)
+        logits = self.prefill(code, cond_idx if use_cond else None, delta_length_cond if use_cond else None, lbl_idx=lbl_idx)
         if trace is not None:
             trace.append(logits.clone())
         c["codes"][:, :t0] = code
-        c["len_dev"].fill_(n_cond + t0)
+        c["len_dev"].fill_(n_pre + n_cond + t0)
         self._set_decode_state(words)     # the step counter (a Philox counter word) restarts with the call
         if device_rng:                    # first pick: step word 0xffffffff (the decode steps count 0, 1, ...)
             self._emit(logits, sampler, None, t0, philox=(words[0], words[1], words[2], 0xffffffff, words[3]))
@@ -648,14 +674,14 @@ class GPT(nn.Module):
             self._emit(logits, sampler, host_noise(b, logits.shape[1]).to(logits.device, non_blocking=True) if sample else None, t0)
 
         if not eager:
-            self._replay_steps(sampler, (bool(sample), top_k, float(temperature), n_cond, b), add_len - 1)
+            self._replay_steps(sampler, (bool(sample), top_k, float(temperature), n_pre + n_cond, b), add_len - 1)
         else:
             for _ in range(add_len - 1):
                 nz = None
                 if sample and noise != "device":
                     nz = host_noise(b, self.head.weight.shape[0]).to(code.device, non_blocking=True)
                 self._decode_body(sampler, noise=nz, trace=trace)
-        c["len"] = n_cond + t0 + add_len - 1
+        c["len"] = n_pre + n_cond + t0 + add_len - 1
         return c["codes"][:, :t0 + add_len].clone()
 
     # ------------------------------------------------------------------ reference-shaped forward
@@ -663,14 +689,13 @@ class GPT(nn.Module):
     def forward(self, idx, cond_idx=torch.tensor([]), state_idx=torch.tensor([]), lbl_idx=torch.tensor([]), delta_length_cond=None):
         """Teacher-forced logits [B, T, V] for positions after the conditioning prefix (mingpt.py:232-305); with an
         ancillary stream T counts the merged sequence."""
-        if 0 not in lbl_idx.size():
-            raise NotImplementedError("label tokens are not on the MI355X path (SURVEY 8f)")
         t_cond = cond_idx.shape[1] if 0 not in cond_idx.size() else 0
-        assert t_cond + idx.shape[1] <= self.block_size, "Cannot forward, model block size is exhausted."  # mingpt.py:299
+        n_pre = self.n_prefix()
+        assert t_cond + n_pre + idx.shape[1] <= self.block_size, "Cannot forward, model block size is exhausted."  # mingpt.py:299
         if 0 not in state_idx.size():
             state_idx = state_idx[:, :self.config.num_blocks * self.config.state_size].to(idx.device)
             rows = self._stream_rows(idx, state_idx)
             self.begin(idx.shape[0], t_cond + rows.shape[1], stream=True, n_state_front=state_idx.shape[1])
             return self.prefill(rows, cond_idx if t_cond else None, delta_length_cond, all_logits=True)
-        self.begin(idx.shape[0], t_cond + idx.shape[1])
-        return self.prefill(idx, cond_idx if t_cond else None, delta_length_cond, all_logits=True)
+        self.begin(idx.shape[0], n_pre + t_cond + idx.shape[1])
+        return self.prefill(idx, cond_idx if t_cond else None, delta_length_cond, all_logits=True, lbl_idx=lbl_idx)

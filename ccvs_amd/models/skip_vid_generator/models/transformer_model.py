@@ -142,7 +142,8 @@ class Transformer(torch.nn.Module):
         out = self.net_t.generate(code, add_len, cond_code if n_cond else None, delta_length_cond if n_cond else None,
                                   sample=opt.sample, top_k=opt.top_k, temperature=opt.temperature, noise=self.sample_noise,
                                   host_noise=host_noise, trace=self.trace, use_graph=getattr(opt, "use_graph", True),
-                                  state_code=state_code if use_state else None, state_sampler=state_sampler)
+                                  state_code=state_code if use_state else None, state_sampler=state_sampler,
+                                  lbl_idx=vid_lbl if getattr(opt, "cat", False) else None)
         if use_state:
             return out
         return out, state_code

@@ -270,6 +270,37 @@ def tiny_beam(ns):
     print("  wrote tiny_beam.npz")
 
 
+def tiny_prefix_tokens(ns):
+    """Start token + class-label token in front of the sequence (mingpt.py:136-141,289-297; `--x_use_start_token --x_cat`):
+    teacher-forced logits and a greedy continuation from the reference."""
+    opt = rh.parse_reference_options(rh.TINY_ARGV + ["--x_use_start_token", "--x_cat", "--categories", "a", "b", "c", "--x_top_k", "10"])
+    xopt = opt["transformer"]
+    torch.manual_seed(0)
+    tr = ns.tm.Transformer(xopt, is_train=False, is_main=True).eval()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        tr.net_t.s_emb.normal_(0, 0.02, generator=g)
+        tr.net_t.t_emb.normal_(0, 0.02, generator=g)
+    torch.manual_seed(17)
+    code = torch.randint(0, 32, (3, 70))
+    lbl = torch.tensor([2, 0, 1])
+    empty = torch.tensor([])
+    out = {"code": code, "lbl": lbl}
+    with torch.no_grad():
+        out["logits"] = tr.net_t(code, lbl_idx=lbl)
+        xopt.sample = False
+        out["greedy"] = tr.fill_code(code[:, :64].clone(), empty, empty, None, lbl, add_len=10)[0]
+    sd = tr.net_t.state_dict()
+    xo = O.namespace(**vars(xopt))
+    with torch.no_grad():
+        report("prefix/logits", O.gpt_forward(sd, xo, code, lbl_idx=lbl), out["logits"])
+        report("prefix/greedy (mismatches)", (O.fill_code(sd, xo, code[:, :64].clone(), 10, lbl=lbl) != out["greedy"]).float(), torch.zeros(1))
+    arrays = {k: v.detach().cpu().numpy() for k, v in out.items()}
+    arrays.update(sd_np("t", tr.net_t))
+    np.savez_compressed(os.path.join(HERE, "tiny_prefix.npz"), **arrays)
+    print("  wrote tiny_prefix.npz", sum(a.nbytes for a in arrays.values()) / 1e6, "MB raw")
+
+
 def tiny_keep_first(ns):
     """Decoder context ring with `--q_keep_first --q_n_first 1` (quantized_video_model.py:896-898; the drums script uses
     n_first 8): 6 frames through a 3-slot ring.  Same seed / construction order as tiny_end_to_end, so the weights are the
@@ -441,7 +472,7 @@ def op_fixtures(ns):
 
 if __name__ == "__main__":
     ns = rh.load_reference()
-    which = sys.argv[1:] or ["ops", "tiny", "state", "keepfirst", "statemodel", "beam"]
+    which = sys.argv[1:] or ["ops", "tiny", "state", "keepfirst", "statemodel", "beam", "prefix"]
     if "ops" in which:
         print("== op fixtures")
         op_fixtures(ns)
@@ -451,6 +482,9 @@ if __name__ == "__main__":
     if "state" in which:
         print("== tiny ancillary-token stream")
         tiny_state_stream(ns)
+    if "prefix" in which:
+        print("== tiny start / label tokens")
+        tiny_prefix_tokens(ns)
     if "beam" in which:
         print("== tiny beam search")
         tiny_beam(ns)

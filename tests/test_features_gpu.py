@@ -285,3 +285,33 @@ def test_beam_search_golden(tiny, golden_dir):
             tr.fill_code(code.clone().cuda(), empty.cuda(), code[:, :64].cuda(), torch.tensor([3, 3]), empty, add_len=4)
     finally:
         xopt.sample, xopt.top_k, xopt.beam_size, xopt.no_sample, tr.sample_noise = old
+
+
+def test_start_and_label_tokens_golden(golden_dir):
+    """`--x_use_start_token --x_cat`: label and start embeddings in front of the sequence (mingpt.py:136-141,289-297): same
+    parameter tree / initialiser stream as the reference, teacher-forced logits (prefix positions included) and a greedy
+    KV-cached continuation against the reference's outputs."""
+    from ccvs_amd.tools.options import Options
+    from ccvs_amd.models.skip_vid_generator.models.transformer_model import Transformer
+    g = np.load(os.path.join(golden_dir, "tiny_prefix.npz"))
+    opt = Options().parse(load_qvid_generator=True, load_transformer=True,
+                          argv=TINY_ARGV + ["--x_use_start_token", "--x_cat", "--categories", "a", "b", "c", "--x_top_k", "10"])
+    xopt = opt["transformer"]
+    torch.manual_seed(0)
+    tr = Transformer(xopt, is_train=False, is_main=True).eval()
+    ref = _sd(g, "t")
+    own = tr.net_t.state_dict()
+    assert set(own) == set(ref)
+    for k in ("start_tok_emb", "lbl_emb.weight", "tok_emb.weight", "head.weight"):      # same initialiser stream as the reference
+        assert torch.equal(own[k].cpu(), ref[k]), k
+    _load(tr.net_t, ref)
+    assert tr.net_t.get_block_size() == 256 + 2
+    code, lbl = torch.from_numpy(g["code"]), torch.from_numpy(g["lbl"])
+    logits = tr.net_t(code.cuda(), lbl_idx=lbl.cuda())
+    assert logits.shape == (3, 72, 32) and maxdiff(logits, torch.from_numpy(g["logits"])) < 1e-4
+    xopt.sample = False
+    empty = torch.tensor([])
+    out = tr.fill_code(code[:, :64].clone().cuda(), empty.cuda(), empty.cuda(), None, lbl.cuda(), add_len=10)[0]
+    assert torch.equal(out.cpu(), torch.from_numpy(g["greedy"]))
+    out = tr({"code": code[:, :64].clone(), "vid_lbl": lbl.clone()}, mode="inference", total_len=74)["code"]
+    assert torch.equal(out.cpu(), torch.from_numpy(g["greedy"]))
