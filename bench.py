@@ -299,6 +299,17 @@ def main():
         ops.KERNEL_TIMER = None
         assert clips.shape[0] == args.batch * world
 
+        alone = None
+        if engine.is_main and args.schedule == "pipelined":
+            # the same convolution launches with the chip to themselves (one more batch, serial schedule, outside the timed
+            # region): in the pipelined schedule the figure above is measured beside the token loops of other batches
+            timer_alone = ops.KernelTimer()
+            ops.KERNEL_TIMER = timer_alone
+            gen.generate_vid(make_batch(2000), 2000)
+            torch.cuda.synchronize()
+            ops.KERNEL_TIMER = None
+            n_a, f_a, ms_a = timer_alone.summary("conv2d_" + ops.CONV_PRECISION)
+            alone = f_a / (ms_a * 1e-3) / 1e12 if ms_a > 0 else None
         if engine.is_main:
             n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
             frames = predicted * args.batch * world * args.steps
@@ -333,6 +344,8 @@ def main():
                 "roofline": {"kernel": ("conv2d_bf16x3_pc_kernel<TW,MB,NTY> + conv2d_bf16x3_kernel<TW,MB> (every instantiation: all conv launches)"
                                         if kind == "bf16x3" else "conv2d_mfma_kernel<TW,MB>"), "bound": "mfma",
                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                             "alone": ({"achieved": alone, "frac": alone / peak, "note": "the same launches of one more batch run serially after the timed region: "
+                                        "`achieved` above is measured while the token loops of other batches share the chip"} if alone else None),
                              "cu_share": (f"launches capped to {gen.last_cu_limit} of {n_cu} CUs while a token loop is in flight: against that share of the "
                                           f"peak the fraction is {achieved / (peak * gen.last_cu_limit / n_cu):.4f}") if args.schedule == "pipelined" and gen.last_cu_limit else None,
                              "traffic": (conv_traffic(args, kind, n_conv) or {}).get("bytes_per_launch"),
