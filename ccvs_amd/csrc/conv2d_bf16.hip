@@ -544,7 +544,7 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
         // for the chunk after next have landed -- and the MFMA waves with it.  The loads stay in flight across the three
         // barriers; hipcc waits for them where their registers are first read (store_xv, a chunk later).
         constexpr int NTYc = VEC ? NTY : 1;
-        const bool work = !(ablate & 1);
+        const bool work = !(ablate & (1 | 256));   // 256: weights still arrive, activations are not staged
         const bool drain = ablate & 64;   // experiments: the old __syncthreads() steps
         if (work) load_xv(min(1, nchunks - 1));
         __syncthreads();
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
     } else {
       int ci = -1, a = nt - 1;
       for (int s = -1; s < nsteps; ++s) {
-        if (DMAW && !(ablate & 1) && s + 1 < nsteps) {  // weights of step s+1 by LDS-DMA; hipcc drains them (vmcnt 0) at the barrier
+        if (DMAW && !(ablate & (1 | 128)) && s + 1 < nsteps) {   // 128: activations still staged, no weight DMA  // weights of step s+1 by LDS-DMA; hipcc drains them (vmcnt 0) at the barrier
             int a1 = a + 1, c1 = ci;
             if (a1 == nt) { a1 = 0; ++c1; }
             dma_w(c1, a1, w_buf + ((s + 1) & 1) * w_sz);
@@ -811,7 +811,7 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, int CinG, int
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    static const int ablate = getenv("CCVS_CONV_ABLATE") ? atoi(getenv("CCVS_CONV_ABLATE")) : 0;  // timing experiments only (1: no staging, 2: no MFMA, 4: scalar staging)
+    static const int ablate = getenv("CCVS_CONV_ABLATE") ? atoi(getenv("CCVS_CONV_ABLATE")) : 0;  // timing experiments only (1: no staging, 2: no MFMA, 4: scalar staging, 128: no weight DMA, 256: no activation staging)
     ConvK k = k_in;
     const dim3 grid3(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
     // cu_limit > 0: the tiles go out as consecutive 1-D chunks of cu_limit x (workgroups of this instantiation that fit one

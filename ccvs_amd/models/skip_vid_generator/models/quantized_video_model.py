@@ -143,10 +143,10 @@ class QVidModel(torch.nn.Module):
             if has_cond:
                 inters.append(cond_inter)
             if opt.skip_mode == "enc":
-                fake_img, _ = self.net_g(z[:, [curr]], inters, has_ctx=curr > 0)
+                fake_img, _ = self.net_g(z[:, curr:curr + 1], inters, has_ctx=curr > 0)
                 new_inter = self.encode(fake_img, None, "vid", False, None, None, quantize=False)["inter"]
             elif opt.skip_mode == "dec":
-                fake_img, _, _, _, inter_dec = self.net_g(z[:, [curr]], inters, return_all=True, inter_pre_warping=False,
+                fake_img, _, _, _, inter_dec = self.net_g(z[:, curr:curr + 1], inters, return_all=True, inter_pre_warping=False,
                                                           has_ctx=curr > 0)
                 new_inter = list(reversed(inter_dec))
             else:
