@@ -539,7 +539,7 @@ class GPT(nn.Module):
         rest goes through `extend`."""
         cfg = self.config
         if cfg.state_front:
-            raise NotImplementedError("state_front generation re-orders the merged sequence at every ancillary token")
+            return self._generate_state_front(code, state_code, add_len, cond_idx, delta_length_cond, sampler, state_sampler, host_noise, trace)
         size, ss = cfg.shape[0] * cfg.shape[1], cfg.state_size
         tot = size + ss
         b, t0 = code.shape
@@ -635,6 +635,47 @@ class GPT(nn.Module):
                 logits = self.extend(rows_of(fed, new_fed))
                 fed = new_fed
         return frame_codes[:, :n_code].clone(), state_buf[:, :n_state].clone()
+
+    @torch.no_grad()
+    def _generate_state_front(self, code, state_code, add_len, cond_idx, delta_length_cond, sampler, state_sampler, host_noise, trace):
+        """`Transformer.fill_code` (transformer_model.py:343-357) with `--x_state_front` (mingpt.py:261-263): the merged sequence
+        is [every ancillary token][every frame token], while the picks still alternate between the streams by the interleaved
+        count (transformer_model.py:352).  A new ancillary token therefore lands in the MIDDLE of the sequence, every frame
+        token behind it moves one position and attends to it: nothing of a KV cache survives such a pick, and the prediction
+        is read at the last FRAME position either way.  Every pick is a full forward over the merged prefix -- what the
+        reference does for every token of every configuration."""
+        cfg = self.config
+        size, ss = cfg.shape[0] * cfg.shape[1], cfg.state_size
+        tot, cap = size + ss, cfg.num_blocks * ss
+        b = code.shape[0]
+        dev = code.device
+        n_cond = cond_idx.shape[1] if cond_idx is not None else 0
+        device_noise = sampler["noise"] == "device"
+        words = self._philox_words() if device_noise and (sampler["sample"] or state_sampler["sample"]) else None
+        state_code = state_code.to(dev)
+        for i in range(add_len):
+            st = state_code[:, :cap]
+            assert n_cond + code.shape[1] <= self.block_size, "Cannot forward, model block size is exhausted."  # mingpt.py:299
+            rows = self._stream_rows(code, st)
+            self.begin(b, n_cond + rows.shape[1], stream=True, n_state_front=st.shape[1])
+            logits = self.prefill(rows, cond_idx, delta_length_cond)
+            is_state = rows.shape[1] % tot < ss
+            smp = state_sampler if is_state else sampler
+            lg = logits[:, :state_sampler["vocab"]].contiguous() if is_state else logits
+            if trace is not None:
+                trace.append(lg.clone())
+            nz, ph = None, None
+            if smp["sample"]:
+                if device_noise:
+                    ph = (words[0], words[1], words[2], i, words[3] | 0x80000000)
+                else:
+                    nz = host_noise(b, lg.shape[1]).to(dev, non_blocking=True)
+            tok = ops.sample_topk(lg, smp["top_k"], smp["temperature"], noise=nz, philox=ph).view(b, 1).to(torch.int64)
+            if is_state:
+                state_code = torch.cat((state_code, tok), dim=1)
+            else:
+                code = torch.cat((code, tok), dim=1)
+        return code, state_code
 
     @torch.no_grad()
     def generate(self, code, add_len, cond_idx=None, delta_length_cond=None, sample=False, top_k=None, temperature=1.0,

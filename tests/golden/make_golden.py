@@ -203,6 +203,56 @@ def tiny_state_stream(ns):
     print("  wrote tiny_state.npz", sum(a.nbytes for a in arrays.values()) / 1e6, "MB raw")
 
 
+def tiny_state_front(ns):
+    """`--x_state_front` (mingpt.py:261-263): every ancillary token in front of the frame tokens.  Same networks as
+    tiny_state.npz (their weights are read from it, not stored again): teacher-forced logits and Transformer.generate_fake
+    with given, with predicted and with sampled ancillary tokens."""
+    opt = rh.parse_reference_options(rh.TINY_STATE_ARGV + ["--x_state_front"])
+    xopt = opt["transformer"]
+    assert xopt.state_front
+    base = np.load(os.path.join(HERE, "tiny_state.npz"))
+    torch.manual_seed(0)
+    tr = ns.tm.Transformer(xopt, is_train=False, is_main=True).eval()
+    sd_t = {k[2:]: torch.from_numpy(base[k]) for k in base.files if k.startswith("t/")}
+    missing = tr.net_t.load_state_dict(sd_t, strict=False)
+    assert not missing.unexpected_keys, missing
+    state_code = torch.from_numpy(base["state_code"])
+    code = torch.from_numpy(base["tf_code"])
+    out = {}
+    with torch.no_grad():
+        out["tf_logits"] = tr.net_t(code, state_idx=state_code[:, :8])
+        xopt.sample, xopt.top_k, xopt.sample_state = False, 10, False
+        total = 2 * 64 + 4 * 2 + 20          # the state slots of the interleaved count decide which stream a pick goes to
+        fa = tr({"code": code[:, :64].clone(), "state_code": state_code[:, :8].clone()}, mode="inference", total_len=total)
+        out["given_code"], out["given_state"] = fa["code"], fa["state_code"]
+        total_b = 64 + 2 + 2 + 40
+        fb = tr({"code": code[:, :64].clone(), "state_code": state_code[:, :2].clone()}, mode="inference", total_len=total_b)
+        out["pred_code"], out["pred_state"] = fb["code"], fb["state_code"]
+        xopt.sample, xopt.sample_state = True, True
+        torch.manual_seed(7)
+        fd = tr({"code": code[:, :64].clone(), "state_code": state_code[:, :2].clone()}, mode="inference", total_len=64 + 2 + 2 + 6)
+        out["samp_code"], out["samp_state"] = fd["code"], fd["state_code"]
+        xopt.sample, xopt.sample_state = False, False
+    xo = O.namespace(**vars(xopt))
+    nets_t = tr.net_t.state_dict()
+    with torch.no_grad():
+        report("state_front/tf_logits", O.gpt_forward(nets_t, xo, code, state_idx=state_code[:, :8]), out["tf_logits"])
+        oc, os_ = O.generate_fake(nets_t, xo, code[:, :64], total, state_code=state_code[:, :8])
+        report("state_front/given (mismatches)", (oc != fa["code"]).float(), torch.zeros(1))
+        oc, os_ = O.generate_fake(nets_t, xo, code[:, :64], total_b, state_code=state_code[:, :2])
+        report("state_front/pred code (mismatches)", (oc != fb["code"]).float(), torch.zeros(1))
+        report("state_front/pred state (mismatches)", (os_ != fb["state_code"]).float(), torch.zeros(1))
+        xo.sample, xo.sample_state = True, True
+        torch.manual_seed(7)
+        oc, os_ = O.generate_fake(nets_t, xo, code[:, :64], 64 + 2 + 2 + 6, state_code=state_code[:, :2])
+        report("state_front/sampled code (mismatches)", (oc != fd["code"]).float(), torch.zeros(1))
+        report("state_front/sampled state (mismatches)", (os_ != fd["state_code"]).float(), torch.zeros(1))
+    print("  shapes:", {k: tuple(v.shape) for k, v in out.items()})
+    arrays = {k: v.detach().cpu().numpy() for k, v in out.items()}
+    np.savez_compressed(os.path.join(HERE, "tiny_state_front.npz"), **arrays)
+    print("  wrote tiny_state_front.npz", sum(a.nbytes for a in arrays.values()) / 1e6, "MB raw")
+
+
 def tiny_state_model(ns):
     """StateModel (state_model.py:109-124) in miniature: StateEstimator on a quantised latent map, the scalar (e_dim = 1)
     quantiser, and the code -> state decode."""
@@ -472,7 +522,7 @@ def op_fixtures(ns):
 
 if __name__ == "__main__":
     ns = rh.load_reference()
-    which = sys.argv[1:] or ["ops", "tiny", "state", "keepfirst", "statemodel", "beam", "prefix"]
+    which = sys.argv[1:] or ["ops", "tiny", "state", "statefront", "keepfirst", "statemodel", "beam", "prefix"]
     if "ops" in which:
         print("== op fixtures")
         op_fixtures(ns)
@@ -488,6 +538,9 @@ if __name__ == "__main__":
     if "beam" in which:
         print("== tiny beam search")
         tiny_beam(ns)
+    if "statefront" in which:
+        print("== tiny state_front")
+        tiny_state_front(ns)
     if "statemodel" in which:
         print("== tiny state model")
         tiny_state_model(ns)

@@ -360,6 +360,37 @@ def test_generate_sampled_state_stream_golden(state_stream):
     xopt.sample, xopt.sample_state = False, False
 
 
+def test_state_front_golden(state_stream, golden_dir):
+    """`--x_state_front` (every ancillary token in front of the frame tokens, mingpt.py:261-263): teacher-forced logits, and
+    generation -- a full forward per pick, the sequence is re-ordered by every new ancillary token -- with given, predicted
+    and sampled ancillary tokens, against the reference's outputs."""
+    from ccvs_amd.tools.options import Options
+    from ccvs_amd.models.skip_vid_generator.models.transformer_model import Transformer
+    g = np.load(os.path.join(golden_dir, "tiny_state_front.npz"))
+    base = state_stream["gold"]
+    xopt = Options().parse(load_qvid_generator=True, load_transformer=True, load_stft_ae=True,
+                           argv=TINY_STATE_ARGV + ["--x_state_front"])["transformer"]
+    tr = Transformer(xopt, is_train=False, is_main=True).eval()
+    _load(tr.net_t, _sd(base, "t"))
+    code, state = torch.from_numpy(base["tf_code"]), torch.from_numpy(base["state_code"])
+    got = tr.net_t(code.cuda(), state_idx=state[:, :8].cuda())
+    want = torch.from_numpy(g["tf_logits"])
+    assert got.shape == want.shape and maxdiff(got, want) < 2e-4
+    xopt.sample, xopt.top_k, xopt.sample_state = False, 10, False
+    out = tr({"code": code[:, :64].clone(), "state_code": state[:, :8].clone()}, mode="inference", total_len=2 * 64 + 4 * 2 + 20)
+    _audit_pair(out["code"], out["state_code"], torch.from_numpy(g["given_code"]), torch.from_numpy(g["given_state"]))
+    out = tr({"code": code[:, :64].clone(), "state_code": state[:, :2].clone()}, mode="inference", total_len=64 + 2 + 2 + 40)
+    _audit_pair(out["code"], out["state_code"], torch.from_numpy(g["pred_code"]), torch.from_numpy(g["pred_state"]))
+    xopt.sample, xopt.sample_state = True, True
+    tr.sample_noise, tr.generator = "host", None
+    torch.manual_seed(7)
+    out = tr({"code": code[:, :64].clone(), "state_code": state[:, :2].clone()}, mode="inference", total_len=64 + 2 + 2 + 6)
+    _audit_pair(out["code"], out["state_code"], torch.from_numpy(g["samp_code"]), torch.from_numpy(g["samp_state"]))
+    tr.sample_noise = "device"      # in-kernel Philox: runs, stays in range, depends on the key
+    out2 = tr({"code": code[:, :64].clone(), "state_code": state[:, :2].clone()}, mode="inference", total_len=64 + 2 + 2 + 6)
+    assert out2["code"].shape == out["code"].shape and int(out2["state_code"].max()) < xopt.state_num
+
+
 def test_keep_first_ring_golden(tiny, golden_dir):
     """`--q_keep_first --q_n_first 1`: slot 0 of the context ring pinned once the ring is full (quantized_video_model.py:
     896-898), 6 frames through 3 slots -- against the reference's own decode."""
