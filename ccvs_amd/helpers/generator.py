@@ -42,6 +42,7 @@ class Generator:
         self.stft_model = None
         self.state_model = None
         self._lanes, self._dec_stream, self._warm_lanes = None, None, set()
+        self._pipeline_primed = False
         self.last_cu_limit, self.last_lanes = 0, 0
         for flag in ("layout", "deblurring"):
             if getattr(self.opt, flag, False):
@@ -285,7 +286,8 @@ class Generator:
         Every token stage is enqueued by its own worker thread: a hipGraph launch blocks the calling thread once the
         stream's queue is full (a few dozen decode steps), and neither the decoder's launches nor the other lanes' may
         wait behind that.  A lane runs one token stage at a time, batches take the lanes round-robin and are decoded in
-        order.
+        order.  The very first batch of a Generator's first call runs alone (encode, tokens, decode from this thread, then
+        a wait): nothing is launched for the first time while a second thread is launching.
 
         batches: iterable of data dicts.  finish(i, out) -> anything: called on stream D when batch i's clip is decoded
         (pack / all-gather); its return values are collected.  Returns the list of per-batch results
@@ -388,7 +390,7 @@ class Generator:
                     lane_job[lane] = job
                     launch_tokens(job)
                     pending.append(job)
-                    if len(pending) <= lanes:
+                    if len(pending) <= lanes and self._pipeline_primed:
                         continue                                    # fill the lanes before the first decode
                 elif not pending:
                     break
@@ -418,6 +420,12 @@ class Generator:
                 results.append({"fake": fake, "enc_code": cur["ws"]["encoded"]["code"], "finished": done, "index": cur["i"]})
                 timings.append(cur["ev"])
                 cur["ws"] = None
+                if not self._pipeline_primed:
+                    # The very first batch of this Generator ran alone, enqueued by this thread, and is waited for here:
+                    # every kernel of the path has been launched once (code objects loaded, function attributes and the
+                    # library's lazily built tables set, graphs captured) before a second host thread starts launching.
+                    s_dec.synchronize()
+                    self._pipeline_primed = True
         finally:
             for job in list(pending) + [j for j in lane_job if j is not None]:
                 if job.get("thread") is not None and job["thread"].is_alive():

@@ -14,12 +14,14 @@ python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --schedule serial --conv
 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --config kinetics --batch 64 > $OUT/${TAG}_bench_kinetics.json 2> $OUT/${TAG}_bench_kinetics.err
 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --rec-pass --schedule serial > $OUT/${TAG}_bench_serial_recpass.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
+export CCVS_BENCH_SUPERVISE=0   # under rocprofv3 the measuring process is the profiled one (no supervising parent)
 for SCHED in pipelined serial; do
   rm -rf /tmp/prof_$SCHED
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$SCHED -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --schedule $SCHED > /tmp/prof_$SCHED.log 2>&1
   cp $(ls /tmp/prof_$SCHED/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_${SCHED}_kernel_stats.csv
   tail -1 /tmp/prof_$SCHED.log > $OUT/${TAG}_bench_${SCHED}_under_rocprof.json
 done
+unset CCVS_BENCH_SUPERVISE
 bash $ROOT/tools/pmc_conv_counters.sh > $OUT/${TAG}_pmc_conv_counters.txt 2>&1
 bash $ROOT/tools/pmc_attention.sh > $OUT/${TAG}_pmc_attention.txt 2>&1
 bash $ROOT/tools/pmc_conv_traffic.sh > $OUT/${TAG}_pmc_conv_traffic.log 2>&1
