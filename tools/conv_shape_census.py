@@ -49,15 +49,16 @@ with torch.no_grad():
     gen.vid_model({"code": code, "inter": inter}, mode="vid_decoder")
     torch.cuda.synchronize()
     ops.KERNEL_TIMER = None
-agg = defaultdict(lambda: [0, 0.0, 0.0, 0.0])
+agg = defaultdict(lambda: [0, 0.0, 0.0, 0.0, 0])
 for key, flops, e0, e1, nbytes in census.records:
-    a = agg[key]
+    a = agg[(key[0][1:],) + key[1:]]          # launches that differ only in the number of images are folded together
     a[0] += 1
     a[1] += e0.elapsed_time(e1)
     a[2] += flops
     a[3] += nbytes
+    a[4] = max(a[4], key[0][0])
 total = sum(a[1] for a in agg.values())
 print(f"{len(census.records)} convolution launches, {total:.0f} ms (HIP events around each launch)")
-for key, (n, ms, fl, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
-    print(f"{ms:7.1f} ms {100 * ms / total:5.1f}%  x{n:4d}  in {str(key[0]):26s} cout {key[1]:4d} k{key[2]}x{key[5]} s{key[3]} "
+for key, (n, ms, fl, nb, nmax) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+    print(f"{ms:7.1f} ms {100 * ms / total:5.1f}%  x{n:4d}  in [<={nmax:3d}]x{str(key[0]):16s} cout {key[1]:4d} k{key[2]}x{key[5]} s{key[3]} "
           f"{'T' if key[4] else ' '}  {fl / ms / 1e9:6.1f} TF/s  {nb / ms / 1e6:6.0f} GB/s")
