@@ -127,7 +127,55 @@ __device__ __forceinline__ float bilin_sample(const float* __restrict__ plane, c
     return ((plane[b.o00] * b.w00 + plane[b.o01] * b.w01) + plane[b.o10] * b.w10) + plane[b.o11] * b.w11;
 }
 
+// Four-pixel form of the warp kernels (W % 4 == 0): a lane owns 4 consecutive pixels of a row and writes them with ONE
+// 16-byte store per channel -- with one pixel per lane and 4-byte stores the warps ran at 2.5 TB/s, 0.6 of what a plain
+// copy reaches on this chip; this form reaches 3.96 (tools/mem_bench.py, 120 x 96 x 256^2).  The two x-taps of a sample row
+// are adjacent in memory and come in one 8-byte load: each row is re-based on a column pair (xb, xb + 1) that lies inside
+// the image and the weights move with it (a corner outside the image keeps weight 0), so a sample is the same four products
+// summed in the same order as bilin_sample.  All accesses are dword-aligned only (packed structs).
+struct BilinPair {
+    int o0, o1;              // offsets of the column pairs in rows y0, y1
+    float a0, b0, a1, b1;    // weights of (pair.x, pair.y) in row y0, row y1
+};
+struct __attribute__((packed, aligned(4))) F32Pair { float x, y; };
+struct __attribute__((packed, aligned(4))) F32Quad { float v[4]; };
+
+__device__ __forceinline__ BilinPair bilin_setup_pair(int x, int y, float fx, float fy, int H, int W) {
+    const float gx = ((2.f * x + 1.f) / W - 1.f) + fx / ((W - 1.0f) / 2.0f);
+    const float gy = ((2.f * y + 1.f) / H - 1.f) + fy / ((H - 1.0f) / 2.0f);
+    const float ix = ((gx + 1.f) * W - 1.f) * 0.5f;
+    const float iy = ((gy + 1.f) * H - 1.f) * 0.5f;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float tx = ix - x0f, ty = iy - y0f;
+    const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
+    const float xc = fminf(fmaxf(x0f, -2.f), (float)W + 1.f), yc = fminf(fmaxf(y0f, -2.f), (float)H + 1.f);
+    const int x0 = (int)xc, y0 = (int)yc, y1 = y0 + 1;
+    const bool vy0 = (y0 >= 0 && y0 < H), vy1 = (y1 >= 0 && y1 < H);
+    BilinPair q;
+    int xb = 0;
+    q.a0 = 0.f; q.b0 = 0.f; q.a1 = 0.f; q.b1 = 0.f;
+    if (x0 >= 0 && x0 + 1 < W) {          // both columns inside
+        xb = x0; q.a0 = w00; q.b0 = w01; q.a1 = w10; q.b1 = w11;
+    } else if (x0 == -1) {                // only x1 = 0 inside: it is the pair's first element
+        xb = 0; q.a0 = w01; q.a1 = w11;
+    } else if (x0 == W - 1) {             // only x0 = W - 1 inside: the pair's second element
+        xb = W - 2; q.b0 = w00; q.b1 = w10;
+    }
+    if (!vy0) { q.a0 = 0.f; q.b0 = 0.f; }
+    if (!vy1) { q.a1 = 0.f; q.b1 = 0.f; }
+    q.o0 = (vy0 ? y0 : 0) * W + xb;
+    q.o1 = (vy1 ? y1 : 0) * W + xb;
+    return q;
+}
+
+__device__ __forceinline__ float bilin_sample_pair(const float* __restrict__ plane, const BilinPair& q) {
+    const F32Pair r0 = *reinterpret_cast<const F32Pair*>(plane + q.o0);
+    const F32Pair r1 = *reinterpret_cast<const F32Pair*>(plane + q.o1);
+    return ((r0.x * q.a0 + r0.y * q.b0) + r1.x * q.a1) + r1.y * q.b1;
+}
+
 #define WARP_CCH 16  // channels per thread
+#define WARP4_CCH 8  // ... of the four-pixel kernels
 
 // The k context features of a decode step live in slots of the per-level context ring (and, point-to-point, in a
 // separate tensor): item n of the batch of N*k pairs reads source ctx.p[n % k] + (n / k) * ctx.sN[n % k], so the
@@ -158,6 +206,45 @@ __global__ __launch_bounds__(256) void backwarp_kernel(CtxList ctx, long x_sC,
     GRID_WALK_END
 }
 
+__global__ __launch_bounds__(256) void backwarp4_kernel(CtxList ctx, long x_sC, const float* __restrict__ flow, long flow_sN, float mult,
+                                                        float* __restrict__ y, long y_sN, long y_sC, int C, int H, int W, GridWalk gw) {
+    const int HW = H * W;
+    GRID_WALK_BEGIN(gw, bx, by, bz)
+    const int pix = (bx * 256 + threadIdx.x) * 4;
+    if (pix >= HW) continue;
+    const int n = bz, c0 = by * WARP4_CCH;
+    const int jn = n % ctx.k;
+    const float* x = ctx.p[jn] + (long)(n / ctx.k) * ctx.sN[jn];
+    const int py = pix / W, px = pix - py * W;
+    const F32Quad fx = *reinterpret_cast<const F32Quad*>(flow + (long)n * flow_sN + pix);
+    const F32Quad fy = *reinterpret_cast<const F32Quad*>(flow + (long)n * flow_sN + HW + pix);
+    BilinPair q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = bilin_setup_pair(px + i, py, fx.v[i] * mult, fy.v[i] * mult, H, W);
+    const int cend = min(c0 + WARP4_CCH, C);
+    for (int c = c0; c < cend; ++c) {
+        const float* pl = x + (long)c * x_sC;
+        F32Quad o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.v[i] = bilin_sample_pair(pl, q[i]);
+        *reinterpret_cast<F32Quad*>(y + (long)n * y_sN + (long)c * y_sC + pix) = o;
+    }
+    GRID_WALK_END
+}
+
+static void launch_backwarp(const CtxList& l, long x_sC, const float* flow, long flow_sN, float mult, float* y, long y_sN, long y_sC, int N, int C,
+                            int H, int W, void* stream) {
+    if (W % 4 == 0) {
+        const GridWalk gw = grid_walk(cdiv(H * W / 4, 256), cdiv(C, WARP4_CCH), N);
+        hipLaunchKernelGGL(backwarp4_kernel, dim3(limited_grid(gw.total, stream, 8)), dim3(256), 0, (hipStream_t)stream, l, x_sC, flow, flow_sN, mult,
+                           y, y_sN, y_sC, C, H, W, gw);
+    } else {
+        const GridWalk gw = grid_walk(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
+        hipLaunchKernelGGL(backwarp_kernel, dim3(limited_grid(gw.total, stream, 8)), dim3(256), 0, (hipStream_t)stream, l, x_sC, flow, flow_sN, mult,
+                           y, y_sN, y_sC, C, H, W, gw);
+    }
+}
+
 static int fill_ctx(CtxList& l, const ccvs_ctx_list* c, const char* name) {
     if (!c || c->k < 1 || c->k > CCVS_MAX_CTX) { ccvs_set_error("%s: context list of 1..%d entries expected", name, CCVS_MAX_CTX); return CCVS_ERR_ARG; }
     l.k = c->k;
@@ -173,12 +260,9 @@ extern "C" int ccvs_backwarp(const float* x, int64_t x_sN, int64_t x_sC, const f
                              int64_t y_sN, int64_t y_sC, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
     CCVS_REQUIRE(x && flow && y, "ccvs_backwarp: null pointer");
     CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "ccvs_backwarp: bad shape");
-    const GridWalk gw = grid_walk(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
-    const dim3 grid(limited_grid(gw.total, stream, 8));
     CtxList l = {};
     l.k = 1; l.p[0] = x; l.sN[0] = (long)x_sN;
-    hipLaunchKernelGGL(backwarp_kernel, grid, dim3(256), 0, (hipStream_t)stream, l, (long)x_sC, flow, (long)flow_sN, flow_mult, y,
-                       (long)y_sN, (long)y_sC, C, H, W, gw);
+    launch_backwarp(l, (long)x_sC, flow, (long)flow_sN, flow_mult, y, (long)y_sN, (long)y_sC, N, C, H, W, stream);
     CCVS_CHECK_LAUNCH("ccvs_backwarp");
     return CCVS_OK;
 }
@@ -190,10 +274,7 @@ extern "C" int ccvs_backwarp_ctx(const ccvs_ctx_list* ctx, int64_t x_sC, const f
     const int rc = fill_ctx(l, ctx, "ccvs_backwarp_ctx");
     if (rc != CCVS_OK) return rc;
     CCVS_REQUIRE(N > 0 && N % l.k == 0 && C > 0 && H > 0 && W > 0, "ccvs_backwarp_ctx: bad shape");
-    const GridWalk gw = grid_walk(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
-    const dim3 grid(limited_grid(gw.total, stream, 8));
-    hipLaunchKernelGGL(backwarp_kernel, grid, dim3(256), 0, (hipStream_t)stream, l, (long)x_sC, flow, (long)flow_sN, flow_mult, y,
-                       (long)y_sN, (long)y_sC, C, H, W, gw);
+    launch_backwarp(l, (long)x_sC, flow, (long)flow_sN, flow_mult, y, (long)y_sN, (long)y_sC, N, C, H, W, stream);
     CCVS_CHECK_LAUNCH("ccvs_backwarp_ctx");
     return CCVS_OK;
 }
@@ -317,19 +398,86 @@ __global__ __launch_bounds__(256) void warp_fuse_blend_kernel(float* __restrict_
     GRID_WALK_END
 }
 
+__global__ __launch_bounds__(256) void warp_fuse_blend4_kernel(float* __restrict__ dec, long dec_sN, long dec_sC, CtxList ctx,
+                                                               const float* __restrict__ flows, long flows_sN, const float* __restrict__ occs,
+                                                               long occs_sN, float mult, int k, int C, int H, int W, GridWalk gw) {
+    const int HW = H * W;
+    GRID_WALK_BEGIN(gw, bx, by, bz)
+    const int pix = (bx * 256 + threadIdx.x) * 4;
+    if (pix >= HW) continue;
+    const int n = bz, c0 = by * WARP4_CCH;
+    const int py = pix / W, px = pix - py * W;
+    const int cn = min(WARP4_CCH, C - c0);
+    float acc[WARP4_CCH][4];
+#pragma unroll
+    for (int j = 0; j < WARP4_CCH; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+    float sum_conf[4] = {0.f, 0.f, 0.f, 0.f}, sum_occ[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < k; ++kk) {
+        const long nk = (long)n * k + kk;
+        const F32Quad fx = *reinterpret_cast<const F32Quad*>(flows + nk * flows_sN + pix);
+        const F32Quad fy = *reinterpret_cast<const F32Quad*>(flows + nk * flows_sN + HW + pix);
+        const F32Quad oc = *reinterpret_cast<const F32Quad*>(occs + nk * occs_sN + pix);
+        float conf[4];
+        BilinPair q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            conf[i] = (k > 1) ? (1.f - sigmoidf_(oc.v[i])) + 1e-6f : 1.f;
+            sum_conf[i] += conf[i];
+            sum_occ[i] += oc.v[i] * conf[i];
+            q[i] = bilin_setup_pair(px + i, py, fx.v[i] * mult, fy.v[i] * mult, H, W);
+        }
+        const float* base = ctx.p[kk] + (long)n * ctx.sN[kk] + (long)c0 * HW;
+#pragma unroll
+        for (int j = 0; j < WARP4_CCH; ++j)
+            if (j < cn) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i] += conf[i] * bilin_sample_pair(base + (long)j * HW, q[i]);
+            }
+    }
+    float m[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = sigmoidf_((k > 1) ? sum_occ[i] / sum_conf[i] : sum_occ[i]);
+#pragma unroll
+    for (int j = 0; j < WARP4_CCH; ++j) {
+        if (j < cn) {
+            F32Quad* d = reinterpret_cast<F32Quad*>(dec + (long)n * dec_sN + (long)(c0 + j) * dec_sC + pix);
+            F32Quad dv = *d;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float wv = (k > 1) ? acc[j][i] / sum_conf[i] : acc[j][i];
+                dv.v[i] = m[i] * dv.v[i] + (1.f - m[i]) * wv;
+            }
+            *d = dv;
+        }
+    }
+    GRID_WALK_END
+}
+
+static void launch_warp_fuse_blend(float* dec, long dec_sN, long dec_sC, const CtxList& l, const float* flows, long flows_sN, const float* occs,
+                                   long occs_sN, float mult, int N, int k, int C, int H, int W, void* stream) {
+    if (W % 4 == 0) {
+        const GridWalk gw = grid_walk(cdiv(H * W / 4, 256), cdiv(C, WARP4_CCH), N);
+        hipLaunchKernelGGL(warp_fuse_blend4_kernel, dim3(limited_grid(gw.total, stream, 8)), dim3(256), 0, (hipStream_t)stream, dec, dec_sN, dec_sC, l,
+                           flows, flows_sN, occs, occs_sN, mult, k, C, H, W, gw);
+    } else {
+        const GridWalk gw = grid_walk(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
+        hipLaunchKernelGGL(warp_fuse_blend_kernel, dim3(limited_grid(gw.total, stream, 8)), dim3(256), 0, (hipStream_t)stream, dec, dec_sN, dec_sC, l,
+                           flows, flows_sN, occs, occs_sN, mult, k, C, H, W, gw);
+    }
+}
+
 extern "C" int ccvs_warp_fuse_blend(float* dec, int64_t dec_sN, int64_t dec_sC, const float* ctx, const float* flows, int64_t flows_sN,
                                     const float* occs, int64_t occs_sN, float flow_mult, int32_t N, int32_t k, int32_t C, int32_t H,
                                     int32_t W, void* stream) {
     CCVS_REQUIRE(dec && ctx && flows && occs, "ccvs_warp_fuse_blend: null pointer");
     CCVS_REQUIRE(N > 0 && k > 0 && C > 0 && H > 0 && W > 0, "ccvs_warp_fuse_blend: bad shape");
-    const GridWalk gw = grid_walk(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
-    const dim3 grid(limited_grid(gw.total, stream, 8));
     CCVS_REQUIRE(k <= CCVS_MAX_CTX, "ccvs_warp_fuse_blend: at most %d contexts", CCVS_MAX_CTX);
     CtxList l = {};
     l.k = k;
     for (int j = 0; j < k; ++j) { l.p[j] = ctx + (long)j * C * H * W; l.sN[j] = (long)k * C * H * W; }
-    hipLaunchKernelGGL(warp_fuse_blend_kernel, grid, dim3(256), 0, (hipStream_t)stream, dec, (long)dec_sN, (long)dec_sC, l, flows,
-                       (long)flows_sN, occs, (long)occs_sN, flow_mult, k, C, H, W, gw);
+    launch_warp_fuse_blend(dec, (long)dec_sN, (long)dec_sC, l, flows, (long)flows_sN, occs, (long)occs_sN, flow_mult, N, k, C, H, W, stream);
     CCVS_CHECK_LAUNCH("ccvs_warp_fuse_blend");
     return CCVS_OK;
 }
@@ -342,10 +490,7 @@ extern "C" int ccvs_warp_fuse_blend_ctx(float* dec, int64_t dec_sN, int64_t dec_
     const int rc = fill_ctx(l, ctx, "ccvs_warp_fuse_blend_ctx");
     if (rc != CCVS_OK) return rc;
     CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "ccvs_warp_fuse_blend_ctx: bad shape");
-    const GridWalk gw = grid_walk(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
-    const dim3 grid(limited_grid(gw.total, stream, 8));
-    hipLaunchKernelGGL(warp_fuse_blend_kernel, grid, dim3(256), 0, (hipStream_t)stream, dec, (long)dec_sN, (long)dec_sC, l, flows,
-                       (long)flows_sN, occs, (long)occs_sN, flow_mult, l.k, C, H, W, gw);
+    launch_warp_fuse_blend(dec, (long)dec_sN, (long)dec_sC, l, flows, (long)flows_sN, occs, (long)occs_sN, flow_mult, N, l.k, C, H, W, stream);
     CCVS_CHECK_LAUNCH("ccvs_warp_fuse_blend_ctx");
     return CCVS_OK;
 }
