@@ -59,6 +59,12 @@ static inline unsigned limited_grid(long blocks, void* stream, int per_cu) {
     return (unsigned)(n < 1 ? 1 : (n > 0x7fffffffL ? 0x7fffffffL : n));
 }
 
+// 8 / 16 bytes of floats at a dword-aligned address: one global_load/store_dwordx2 / dwordx4 (gfx950 takes dword-aligned
+// wide accesses).  The HBM-bound kernels write 16 bytes per lane wherever a row allows it: with 4-byte stores per lane they
+// ran at 0.6 of what a plain copy reaches on this chip (tools/mem_bench.py).
+struct __attribute__((packed, aligned(4))) F32Pair { float x, y; };
+struct __attribute__((packed, aligned(4))) F32Quad { float v[4]; };
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

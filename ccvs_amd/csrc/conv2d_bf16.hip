@@ -260,7 +260,6 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
     // get a whole chunk (NTY steps).  (Measured alternative: waves 4-5 activations / 6-7 weights was 10 % slower --
     // the conversion work then sits on two of the four SIMDs.)
     const bool xrole = VEC && producer;
-    const bool wrole = DMAW ? !producer : producer;
     const int rtw = rt;
     CONV_TILE_COORDS(p, bx, by, bz)
     const int ty = bx / p.tiles_x, tx = bx - ty * p.tiles_x;

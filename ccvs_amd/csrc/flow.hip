@@ -132,13 +132,11 @@ __device__ __forceinline__ float bilin_sample(const float* __restrict__ plane, c
 // copy reaches on this chip; this form reaches 3.96 (tools/mem_bench.py, 120 x 96 x 256^2).  The two x-taps of a sample row
 // are adjacent in memory and come in one 8-byte load: each row is re-based on a column pair (xb, xb + 1) that lies inside
 // the image and the weights move with it (a corner outside the image keeps weight 0), so a sample is the same four products
-// summed in the same order as bilin_sample.  All accesses are dword-aligned only (packed structs).
+// summed in the same order as bilin_sample.  All accesses are dword-aligned only (F32Pair / F32Quad, common.h).
 struct BilinPair {
     int o0, o1;              // offsets of the column pairs in rows y0, y1
     float a0, b0, a1, b1;    // weights of (pair.x, pair.y) in row y0, row y1
 };
-struct __attribute__((packed, aligned(4))) F32Pair { float x, y; };
-struct __attribute__((packed, aligned(4))) F32Quad { float v[4]; };
 
 __device__ __forceinline__ BilinPair bilin_setup_pair(int x, int y, float fx, float fy, int H, int W) {
     const float gx = ((2.f * x + 1.f) / W - 1.f) + fx / ((W - 1.0f) / 2.0f);

@@ -94,12 +94,16 @@ __global__ __launch_bounds__(256) void blur4x4_tile_kernel(FirK p, int tiles_x, 
     }
     const long oi = (nc * p.Ho + oy) * (long)p.Wo + ox0;
     const int nv = min(4, p.Wo - ox0);
-    if (nv == 4 && (oi & 3) == 0) {
+    if (nv == 4) {   // 16-byte store whatever the row's alignment (Wo = 254: every other row starts 8 bytes off)
         if (p.res) {
-            const float4 r4 = *reinterpret_cast<const float4*>(p.res + oi);
-            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+            const F32Quad r4 = *reinterpret_cast<const F32Quad*>(p.res + oi);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) v[o] += r4.v[o];
         }
-        *reinterpret_cast<float4*>(p.y + oi) = make_float4(v[0] * p.out_scale, v[1] * p.out_scale, v[2] * p.out_scale, v[3] * p.out_scale);
+        F32Quad o4;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) o4.v[o] = v[o] * p.out_scale;
+        *reinterpret_cast<F32Quad*>(p.y + oi) = o4;
     } else {
         for (int o = 0; o < nv; ++o) p.y[oi + o] = (v[o] + (p.res ? p.res[oi + o] : 0.f)) * p.out_scale;
     }
@@ -147,6 +151,124 @@ __global__ __launch_bounds__(256) void upsample2_kernel(FirK p) {
     }
 }
 
+// The same for TWO input pixels (jx, jx + 1) per thread (W even): the 3 x 4 neighbourhood gives a 2 x 4 output block, written
+// as two 16-byte stores.  Per output the arithmetic is that of upsample2_kernel.
+__global__ __launch_bounds__(256) void upsample2x2_kernel(FirK p) {
+    const int W2 = p.W >> 1;
+    const long total = p.NC * p.H * W2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int jx = (int)(i % W2) * 2;
+        const long t = i / W2;
+        const int iy = (int)(t % p.H);
+        const long nc = t / p.H;
+        const float* xp = p.x + nc * (long)p.H * p.W;
+        float v[3][4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int yy = iy + a - 1, xx = jx + b - 1;
+                const float tv = xp[(long)min(max(yy, 0), p.H - 1) * p.W + min(max(xx, 0), p.W - 1)];
+                v[a][b] = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? tv : 0.f;
+            }
+        float hr[3][4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { hr[a][2 * b] = v[a][b] + 3.f * v[a][b + 1]; hr[a][2 * b + 1] = 3.f * v[a][b + 1] + v[a][b + 2]; }
+        const float g = p.gain * (1.f / 64.f);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const long oi = (nc * p.Ho + 2 * iy + a) * (long)p.Wo + 2 * jx;
+            F32Quad o4;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                float r = (a == 0 ? hr[0][b] + 3.f * hr[1][b] : 3.f * hr[1][b] + hr[2][b]) * g;
+                if (p.act == CCVS_ACT_LRELU) r = lrelu01(r);
+                o4.v[b] = r;
+            }
+            if (p.res) {
+                const F32Quad r4 = *reinterpret_cast<const F32Quad*>(p.res + oi);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) o4.v[b] += r4.v[b];
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) o4.v[b] *= p.out_scale;
+            *reinterpret_cast<F32Quad*>(p.y + oi) = o4;
+        }
+    }
+}
+
+// up = 1, down = 2: the encoder's blur + decimate.  A thread owns 4 consecutive outputs of a row: their 4 x 10 input window
+// comes in as three 16-byte loads per row where it lies inside the row, and they leave as one 16-byte store.  Per output
+// the sums run in the order of upfirdn2d_generic_kernel (taps outside the image contribute zeros instead of being skipped).
+__global__ __launch_bounds__(256) void down2_kernel(FirK p) {
+    const int Wq = (p.Wo + 3) >> 2;
+    const long total = p.NC * p.Ho * Wq;
+    const float t4[4] = {1.f, 3.f, 3.f, 1.f};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ox0 = (int)(i % Wq) * 4;
+        const long t = i / Wq;
+        const int oy = (int)(t % p.Ho);
+        const long nc = t / p.Ho;
+        const float* xp = p.x + nc * (long)p.H * p.W;
+        const int v0 = ox0 * 2 - p.pad0;            // first input column of the window
+        const bool inside = v0 >= 0 && v0 + 12 <= p.W;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const int iy = oy * 2 + ky - p.pad0;
+            if (iy < 0 || iy >= p.H) continue;     // (whole row outside: adds nothing in the generic kernel either)
+            const float* rp = xp + (long)iy * p.W;
+            float w[12];
+            if (inside) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const F32Quad r4 = *reinterpret_cast<const F32Quad*>(rp + v0 + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[4 * q + e] = r4.v[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 10; ++e) {
+                    const int ix = v0 + e;
+                    const float tv = rp[min(max(ix, 0), p.W - 1)];
+                    w[e] = (ix >= 0 && ix < p.W) ? tv : 0.f;
+                }
+                w[10] = 0.f; w[11] = 0.f;
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float row = 0.f;
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) row += t4[kx] * w[2 * o + kx];
+                acc[o] += t4[ky] * row;
+            }
+        }
+        const long oi = (nc * p.Ho + oy) * (long)p.Wo + ox0;
+        const int nv = min(4, p.Wo - ox0);
+        float v[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            v[o] = acc[o] * (p.gain * (1.f / 64.f));
+            if (p.act == CCVS_ACT_LRELU) v[o] = lrelu01(v[o]);
+        }
+        if (nv == 4) {
+            if (p.res) {
+                const F32Quad r4 = *reinterpret_cast<const F32Quad*>(p.res + oi);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) v[o] += r4.v[o];
+            }
+            F32Quad o4;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) o4.v[o] = v[o] * p.out_scale;
+            *reinterpret_cast<F32Quad*>(p.y + oi) = o4;
+        } else {
+            for (int o = 0; o < nv; ++o) p.y[oi + o] = (v[o] + (p.res ? p.res[oi + o] : 0.f)) * p.out_scale;
+        }
+    }
+}
+
 extern "C" int ccvs_upfirdn2d(const float* x, float* y, const float* residual, int64_t NC, int32_t H, int32_t W, int32_t up,
                               int32_t down, int32_t pad0, int32_t pad1, float gain, int32_t act, float out_scale, void* stream) {
     CCVS_REQUIRE(x && y, "ccvs_upfirdn2d: null pointer");
@@ -166,7 +288,17 @@ extern "C" int ccvs_upfirdn2d(const float* x, float* y, const float* residual, i
     } else if (up == 2 && down == 1 && pad0 == 2 && pad1 == 1) {
         const long work = NC * (long)H * W;
         const unsigned blocks = limited_grid(cdiv64(work, 256) < 65536 * 16 ? cdiv64(work, 256) : 65536 * 16, stream, 8);
-        hipLaunchKernelGGL(upsample2_kernel, dim3(blocks), dim3(256), 0, st, k);
+        if (W % 2 == 0) {
+            const long work2 = NC * (long)H * (W / 2);
+            const unsigned blocks2 = limited_grid(cdiv64(work2, 256) < 65536 * 16 ? cdiv64(work2, 256) : 65536 * 16, stream, 8);
+            hipLaunchKernelGGL(upsample2x2_kernel, dim3(blocks2), dim3(256), 0, st, k);
+        } else {
+            hipLaunchKernelGGL(upsample2_kernel, dim3(blocks), dim3(256), 0, st, k);
+        }
+    } else if (up == 1 && down == 2) {
+        const long work = NC * k.Ho * ((k.Wo + 3) / 4);
+        const unsigned blocks = limited_grid(cdiv64(work, 256) < 65536 * 16 ? cdiv64(work, 256) : 65536 * 16, stream, 8);
+        hipLaunchKernelGGL(down2_kernel, dim3(blocks), dim3(256), 0, st, k);
     } else {
         const long work = NC * k.Ho * k.Wo;
         const unsigned blocks = limited_grid(cdiv64(work, 256) < 65536 * 16 ? cdiv64(work, 256) : 65536 * 16, stream, 8);
@@ -220,13 +352,63 @@ __global__ __launch_bounds__(256) void dwconvT4x4s2_kernel(const float* __restri
     }
 }
 
+// The same for TWO input pixels (jx, jx + 1) per thread (W even): 3 x 4 neighbourhood in, a 2 x 4 output block out as two
+// 16-byte stores; per output the sum is that of dwconvT4x4s2_kernel.
+__global__ __launch_bounds__(256) void dwconvT4x4s2x2_kernel(const float* __restrict__ x, long x_sN, const float* __restrict__ w,
+                                                             float* __restrict__ y, long y_sN, long N, int C, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W, W2 = W >> 1;
+    const long total = N * C * (long)H * W2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int jx = (int)(i % W2) * 2;
+        const long t = i / W2;
+        const int iy = (int)(t % H);
+        const long nc = t / H;
+        const int c = (int)(nc % C);
+        const long n = nc / C;
+        const float* xp = x + n * x_sN + (long)c * H * W;
+        const float* wp = w + c * 16;
+        float v[3][4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int yy = iy + a - 1, xx = jx + b - 1;
+                const float tv = xp[(long)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];
+                v[a][b] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? tv : 0.f;
+            }
+        const int kyt[2][2] = {{1, 3}, {0, 2}}, nyt[2][2] = {{1, 0}, {2, 1}};
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            F32Quad o4;
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)       // input column jx + bi
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {    // output parity along x
+                    float acc = 0.f;
+#pragma unroll
+                    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < 2; ++tb) acc += v[nyt[a][ta]][bi + nyt[b][tb]] * wp[kyt[a][ta] * 4 + kyt[b][tb]];
+                    o4.v[2 * bi + b] = acc;
+                }
+            *reinterpret_cast<F32Quad*>(y + n * y_sN + ((long)c * Ho + 2 * iy + a) * Wo + 2 * jx) = o4;
+        }
+    }
+}
+
 extern "C" int ccvs_dwconvT4x4s2(const float* x, int64_t x_sN, const float* w, float* y, int64_t y_sN, int32_t N, int32_t C, int32_t H,
                                  int32_t W, void* stream) {
     CCVS_REQUIRE(x && w && y, "ccvs_dwconvT4x4s2: null pointer");
     CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "ccvs_dwconvT4x4s2: empty tensor");
     const long work = (long)N * C * H * W;
     const unsigned blocks = limited_grid(cdiv64(work, 256) < 65536 * 16 ? cdiv64(work, 256) : 65536 * 16, stream, 8);
-    hipLaunchKernelGGL(dwconvT4x4s2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)x_sN, w, y, (long)y_sN, (long)N, C, H, W);
+    if (W % 2 == 0) {
+        const long work2 = (long)N * C * H * (W / 2);
+        const unsigned blocks2 = limited_grid(cdiv64(work2, 256) < 65536 * 16 ? cdiv64(work2, 256) : 65536 * 16, stream, 8);
+        hipLaunchKernelGGL(dwconvT4x4s2x2_kernel, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, x, (long)x_sN, w, y, (long)y_sN, (long)N, C, H, W);
+    } else {
+        hipLaunchKernelGGL(dwconvT4x4s2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)x_sN, w, y, (long)y_sN, (long)N, C, H, W);
+    }
     CCVS_CHECK_LAUNCH("ccvs_dwconvT4x4s2");
     return CCVS_OK;
 }
