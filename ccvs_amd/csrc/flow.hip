@@ -322,6 +322,62 @@ __global__ __launch_bounds__(256) void warp_proj_kernel(CtxList ctx, long x_sC, 
     GRID_WALK_END
 }
 
+// Four pixels per lane (W % 4 == 0, CO <= 24: the accumulators are CO x 4 registers): 8-byte tap pairs in, one 16-byte store
+// per output channel out.  Per output the sum runs over the input channels in the order of warp_proj_kernel.
+template <int CO>
+__global__ __launch_bounds__(256) void warp_proj4_kernel(CtxList ctx, long x_sC, const float* __restrict__ flow, long flow_sN, float mult,
+                                                         const float* __restrict__ wt, const float* __restrict__ bias,
+                                                         float* __restrict__ y, int Cin, int Cout, int H, int W, int act, GridWalk gw) {
+    const int HW = H * W;
+    GRID_WALK_BEGIN(gw, bx, by, bz)
+    (void)bz;
+    const int pix = (bx * 256 + threadIdx.x) * 4;
+    if (pix >= HW) continue;
+    const int n = by;
+    const int jn = n % ctx.k;
+    const float* x = ctx.p[jn] + (long)(n / ctx.k) * ctx.sN[jn];
+    const int py = pix / W, px = pix - py * W;
+    const F32Quad fx = *reinterpret_cast<const F32Quad*>(flow + (long)n * flow_sN + pix);
+    const F32Quad fy = *reinterpret_cast<const F32Quad*>(flow + (long)n * flow_sN + HW + pix);
+    BilinPair q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = bilin_setup_pair(px + i, py, fx.v[i] * mult, fy.v[i] * mult, H, W);
+    float acc[CO][4];
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[o][i] = 0.f;
+    for (int c = 0; c < Cin; ++c) {
+        const float* pl = x + (long)c * x_sC;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = bilin_sample_pair(pl, q[i]);
+        const float* wr = wt + (long)c * CO;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            const float wv = wr[o];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[o][i] += wv * v[i];
+        }
+    }
+    float* yo = y + (long)n * Cout * HW + pix;
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+        if (o < Cout) {
+            const float bv = bias ? bias[o] : 0.f;
+            F32Quad o4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = acc[o][i] + bv;
+                if (act == CCVS_ACT_LRELU) v = lrelu01(v);
+                o4.v[i] = v;
+            }
+            *reinterpret_cast<F32Quad*>(yo + (long)o * HW) = o4;
+        }
+    }
+    GRID_WALK_END
+}
+
 extern "C" int ccvs_backwarp_proj_ctx(const ccvs_ctx_list* ctx, int64_t x_sC, const float* flow, int64_t flow_sN, float flow_mult,
                                       const float* w_t, const float* bias, float* y, int32_t N, int32_t Cin, int32_t Cout, int32_t CoutPad,
                                       int32_t H, int32_t W, int32_t act, void* stream) {
@@ -338,7 +394,14 @@ extern "C" int ccvs_backwarp_proj_ctx(const ccvs_ctx_list* ctx, int64_t x_sC, co
 #define WP_LAUNCH(CO)                                                                                                               \
     hipLaunchKernelGGL((warp_proj_kernel<CO>), grid, dim3(256), 0, st, l, (long)x_sC, flow, (long)flow_sN, flow_mult, w_t, bias, y, Cin, Cout, \
                        H, W, act, gw)
-    if (CoutPad == 16) WP_LAUNCH(16);
+    if (W % 4 == 0 && CoutPad <= 24) {
+        const GridWalk gw4 = grid_walk(cdiv(H * W / 4, 256), N, 1);
+        const dim3 grid4(limited_grid(gw4.total, stream, 4));
+        if (CoutPad == 16)
+            hipLaunchKernelGGL((warp_proj4_kernel<16>), grid4, dim3(256), 0, st, l, (long)x_sC, flow, (long)flow_sN, flow_mult, w_t, bias, y, Cin, Cout, H, W, act, gw4);
+        else
+            hipLaunchKernelGGL((warp_proj4_kernel<24>), grid4, dim3(256), 0, st, l, (long)x_sC, flow, (long)flow_sN, flow_mult, w_t, bias, y, Cin, Cout, H, W, act, gw4);
+    } else if (CoutPad == 16) WP_LAUNCH(16);
     else if (CoutPad == 24) WP_LAUNCH(24);
     else if (CoutPad == 48) WP_LAUNCH(48);
     else WP_LAUNCH(96);
