@@ -37,7 +37,8 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (de
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=20,
+                    help="timed batches (default 20: ~30 s; the fill and drain of the pipelined schedule are inside the timed region and weigh 1/K)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU (weak scaling)")
     ap.add_argument("--config", type=str, default="bair", choices=["bair", "kinetics"])
