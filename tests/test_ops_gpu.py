@@ -203,12 +203,22 @@ def test_backwarp_golden(ops, gold):
     close(got, torch.from_numpy(gold["warp/y"]), 1e-5)
 
 
-def test_backwarp_oracle(ops):
+@pytest.mark.parametrize("w", [47, 48, 4])      # W % 4 == 0: four pixels per lane, column pairs re-based at both borders
+def test_backwarp_oracle(ops, w):
     torch.manual_seed(2)
-    x, flow = torch.randn(3, 20, 33, 47), torch.randn(3, 2, 33, 47) * 4
+    x, flow = torch.randn(3, 20, 33, w), torch.randn(3, 2, 33, w) * 4
     flow[0, :, 0, 0] = 1e4  # far outside -> zeros
-    want = O.backwarp(x, flow * 2.0, O.backwarp_grid(33, 47))
+    flow[1, 0, :, 0] = -0.25        # x0 = -1: only the right tap is inside
+    flow[1, 0, :, w - 1] = 0.25     # x0 = W - 1: only the left tap is inside
+    flow[2, 0, 5, :] = -float(w)    # a whole row sampled left of the image
+    want = O.backwarp(x, flow * 2.0, O.backwarp_grid(33, w))
     close(ops.backwarp(x.cuda(), flow.cuda(), 2.0), want, 1e-4)
+    ch = torch.randn(3, 24, 33, w)  # a channel-sliced destination (not 16-byte aligned rows for w = 47)
+    out = ch.clone().cuda()
+    ops.backwarp(x.cuda(), flow.cuda(), 2.0, out=out[:, 2:22])
+    close(out[:, 2:22], want, 1e-4)
+    close(out[:, :2], ch[:, :2], 0)
+    close(out[:, 22:], ch[:, 22:], 0)
 
 
 @pytest.mark.parametrize("k", [1, 3])
