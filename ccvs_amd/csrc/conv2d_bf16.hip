@@ -82,10 +82,13 @@ __device__ __forceinline__ void stage_pixel(const float* __restrict__ xn, long i
     }
 }
 
-template <int TW, int MB>
-__global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG) {
+// NW waves (4 or 8): with 8, every wave owns ONE 32-pixel block (half the accumulators) and twice as many threads stage the
+// halo tile -- the workgroup is alone on its CU (LDS), so the extra waves are what overlaps its loads (env CCVS_CONV_SYNC_WAVES).
+template <int TW, int MB, int NW>
+__global__ __launch_bounds__(64 * NW) void conv2d_bf16x3_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG) {
     constexpr int TH = 256 / TW;
     constexpr int NT = 32 * MB;
+    constexpr int NTH = 64 * NW, PP = 8 / NW;
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4
     int off[CB_MAX_E];
 #pragma unroll
     for (int j = 0; j < CB_MAX_E; ++j) {
-        const int e = tid + 256 * j;
+        const int e = tid + NTH * j;
         off[j] = -2;
         if (e < plane) {
             const int r = e / IW, c = e - r * IW;
@@ -116,20 +119,20 @@ __global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4
             off[j] = (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) ? gy * p.Win + gx : -1;
         }
     }
-    int bofs[2];
+    int bofs[PP];
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-        const int pj = (wave * 2 + pp) * 32 + (lane & 31);
+    for (int pp = 0; pp < PP; ++pp) {
+        const int pj = (wave * PP + pp) * 32 + (lane & 31);
         const int prow = pj / TW, pcol = pj - prow * TW;
         bofs[pp] = prow * ay.s * IW + pcol * ax.s;
     }
     const int khalf = lane >> 5;
 
-    f32x16 acc[MB][2];
+    f32x16 acc[MB][PP];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp)
+        for (int pp = 0; pp < PP; ++pp)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][pp][r] = 0.f;
 
@@ -140,13 +143,13 @@ __global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < CB_MAX_E; ++j) {
-            if (off[j] != -2) stage_pixel(xn, p.in_sC, p.Cin, c0, off[j], in_tile, plane, tid + 256 * j);
+            if (off[j] != -2) stage_pixel(xn, p.in_sC, p.Cin, c0, off[j], in_tile, plane, tid + NTH * j);
         }
         const int cg0 = c0 >> 3;
         for (int a = 0; a < ay.nt; ++a) {
             if (a > 0) __syncthreads();
             const int wy = ay.w0 + a * ay.dw;
-            for (int i = tid; i < wunits; i += 256) {
+            for (int i = tid; i < wunits; i += NTH) {
                 const int b = i / (4 * NT), rem = i - b * (4 * NT);
                 const int hp = rem / NT, co = rem - hp * NT;   // hp = half*2 + part
                 const int tap = wy * p.kw + (ax.w0 + b * ax.dw);
@@ -159,9 +162,9 @@ __global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4
                 const int dl = dyl + (ax.d0 + b * ax.dd - ax.lo);
                 const uint4* wt = w_tile + (b * 4 + khalf * 2) * NT + (lane & 31);
                 const uint4* it = in_tile + (khalf * 2) * plane + dl;
-                bf16x8 bh[2], bl[2];
+                bf16x8 bh[PP], bl[PP];
 #pragma unroll
-                for (int pp = 0; pp < 2; ++pp) {
+                for (int pp = 0; pp < PP; ++pp) {
                     bh[pp] = __builtin_bit_cast(bf16x8, it[bofs[pp]]);
                     bl[pp] = __builtin_bit_cast(bf16x8, it[plane + bofs[pp]]);
                 }
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4
                     const bf16x8 ah = __builtin_bit_cast(bf16x8, wt[m * 32]);
                     const bf16x8 al = __builtin_bit_cast(bf16x8, wt[NT + m * 32]);
 #pragma unroll
-                    for (int pp = 0; pp < 2; ++pp) {
+                    for (int pp = 0; pp < PP; ++pp) {
                         acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[pp], acc[m][pp], 0, 0, 0);
                         acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[pp], acc[m][pp], 0, 0, 0);
                         acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[pp], acc[m][pp], 0, 0, 0);
@@ -181,8 +184,8 @@ __global__ __launch_bounds__(256) void conv2d_bf16x3_kernel(ConvK p, const uint4
     }
 
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-        const int pj = (wave * 2 + pp) * 32 + (lane & 31);
+    for (int pp = 0; pp < PP; ++pp) {
+        const int pj = (wave * PP + pp) * 32 + (lane & 31);
         const int prow = pj / TW, pcol = pj - prow * TW;
         const int vy = ty * TH + prow, vx = tx * TW + pcol;
         if (vy >= ay.V || vx >= ax.V) continue;
@@ -802,7 +805,8 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, int CinG, int
     }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_kernel<TW, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_kernel<TW, MB, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_kernel<TW, MB, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, -2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, -8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -896,7 +900,9 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, int CinG, int
         ccvs_set_error("ccvs_conv2d_bf16x3: %zu bytes of LDS needed", smem);
         return CCVS_ERR_ARG;
     }
-    CB_LAUNCH((conv2d_bf16x3_kernel<TW, MB>), 256, smem, (const uint4*)wsplit, CinG);
+    static const int sync_waves = getenv("CCVS_CONV_SYNC_WAVES") ? atoi(getenv("CCVS_CONV_SYNC_WAVES")) : 8;
+    if (sync_waves == 8) CB_LAUNCH((conv2d_bf16x3_kernel<TW, MB, 8>), 512, smem, (const uint4*)wsplit, CinG);
+    else CB_LAUNCH((conv2d_bf16x3_kernel<TW, MB, 4>), 256, smem, (const uint4*)wsplit, CinG);
     CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
     return CCVS_OK;
 }
