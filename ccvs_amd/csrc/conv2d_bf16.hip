@@ -879,7 +879,9 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, int CinG, int
     const int nt_min = (k.transposed ? 1 : k.kh);               // fewest tap rows of any parity class
     const int passes = (plane + 255) / 256;
     const bool regs_ok = (ntx_max <= (MB == 1 ? 9 : 3)) && (passes <= nt_min);
-    const bool regs_ok2 = (ntx_max <= (MB == 1 ? 9 : 3)) && (passes <= 2 * nt_min) && !(ablate & 32);
+    // transposed layers (1-2 taps per row and parity class: little MFMA work per staged tile) are faster on the 8-wave synchronous
+    // kernel than on the two-pass producer / consumer form: 117 vs 77 TFLOP/s on 128->128 at 128^2 (CCVS_CONV_ABLATE=1024 keeps the old routing)
+    const bool regs_ok2 = (ntx_max <= (MB == 1 ? 9 : 3)) && (passes <= 2 * nt_min) && !(ablate & 32) && (!k.transposed || (ablate & 1024));
     // (8 staging waves for <= 64 output channels were measured slower: the steps are latency- not staging-bound)
     if (smem_pc <= 156 * 1024 && regs_ok) {  // double-buffered producer / consumer form, scalar staging
         CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, 0>), 512, smem_pc, (const uint4*)wsplit, CinG, ntx_max, ablate);
