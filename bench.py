@@ -141,8 +141,8 @@ def calibrate_codebook(gen, data):
 def cpu_baseline(gen, opt):
     """The oracle (CPU restatement of the reference algorithm, incl. its no-KV-cache token loop)
     timed on this host on a BOUNDED sample of config 1 (BAIR, batch 1) and extrapolated:
-    encoder on 1 frame, decoder on 1 frame with k=1 and k=2 contexts, GPT forward at
-    T = 64 / 384 / 768, integrated over the 960-token loop and the 15-frame decode loop."""
+    encoder on 1 frame, decoder on 1 frame with k=1 and k=3 contexts, GPT forward at
+    T = 64 / 384 / 704 / 1023, integrated over the 960-token loop and the 15-frame decode loop."""
     from oracle import ccvs_oracle as O
     qopt, xopt = opt["qvid_generator"], opt["transformer"]
     cpu = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
@@ -152,6 +152,26 @@ def cpu_baseline(gen, opt):
     g = torch.Generator().manual_seed(1)
     frame = torch.rand(1, 1, 3, qopt.max_dim, qopt.max_dim, generator=g) * 2 - 1
     t_all = time.perf_counter()
+    # The sample is bounded in TIME as well: the GPU box's host is shared, and on a loaded host the same calls were seen to take
+    # 5x longer (148 s instead of 30 s).  Every measurement runs once; it is repeated (the faster of two is kept: the first
+    # call of a kind also pays one-time allocator / thread-pool costs) only while less than half of the budget is spent, and
+    # the fourth GPT length is dropped when the budget is gone (three points still fix the quadratic).
+    budget = float(os.environ.get("CCVS_CPU_BASELINE_BUDGET", "40"))
+    repeats = []
+
+    def timed(fn):
+        t0 = time.perf_counter()
+        fn()
+        best = time.perf_counter() - t0
+        if time.perf_counter() - t_all < 0.5 * budget:
+            t0 = time.perf_counter()
+            fn()
+            best = min(best, time.perf_counter() - t0)
+            repeats.append(2)
+        else:
+            repeats.append(1)
+        return best
+
     with torch.no_grad():
         O.encoder_forward(nets["e"], qopt, frame[:, :, :, :64, :64])  # untimed warm-up (thread pool, allocator)
         t0 = time.perf_counter()
@@ -159,24 +179,18 @@ def cpu_baseline(gen, opt):
         t_enc = time.perf_counter() - t0
         z = enc["z"]
         ctx = [f for f in enc["inter"]]
-        t_dec1 = float("inf")
-        for _ in range(2):  # the first decoder call also pays one-time allocator / thread-pool costs: keep the faster of two
-            t0 = time.perf_counter()
-            O.decoder_forward(nets["g"], qopt, z, [ctx])
-            t_dec1 = min(t_dec1, time.perf_counter() - t0)
+        t_dec1 = timed(lambda: O.decoder_forward(nets["g"], qopt, z, [ctx]))
         t0 = time.perf_counter()
         O.decoder_forward(nets["g"], qopt, z, [ctx, ctx, ctx])
         t_dec3 = time.perf_counter() - t0
         t_dec2 = 0.5 * (t_dec1 + t_dec3)   # linear in the number of contexts
         ts = {}
-        for T in (64, 384, 704, 1023):      # least-squares quadratic through four cache lengths, each the faster of two runs
+        for T in (64, 1023, 384, 704):      # least-squares quadratic through the cache lengths sampled
+            if T == 704 and time.perf_counter() - t_all > budget:
+                continue
             idx = torch.randint(0, xopt.z_num, (1, T), generator=g)
-            best = float("inf")
-            for _ in range(2):
-                t0 = time.perf_counter()
-                O.gpt_forward(nets["t"], xopt, idx)
-                best = min(best, time.perf_counter() - t0)
-            ts[T] = best
+            ts[T] = timed(lambda: O.gpt_forward(nets["t"], xopt, idx))
+        ts = dict(sorted(ts.items()))
     # decode: frame with k contexts costs a + b*k ; 1 cond frame (k=1) + 15 frames with k = 1..15
     b = max(t_dec2 - t_dec1, 0.0)
     a = max(t_dec1 - b, 0.0)
@@ -192,7 +206,7 @@ def cpu_baseline(gen, opt):
     return {"value": 15.0 / total, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": (f"oracle on BAIR batch 1, extrapolated from {time.perf_counter() - t_all:.1f}s of CPU work: encoder 1 frame "
                        f"{t_enc:.2f}s, decoder 1 frame k=1 {t_dec1:.2f}s / k=3 {t_dec3:.2f}s, GPT forward T={'/'.join(str(k) for k in ts)} "
-                       f"{'/'.join(f'{v:.2f}' for v in ts.values())}s (least-squares quadratic, worst relative residual "
+                       f"{'/'.join(f'{v:.2f}' for v in ts.values())}s ({sum(repeats)} timed calls in a {budget:.0f} s budget; least-squares quadratic, worst relative residual "
                        f"{100 * fit_err:.0f}%) -> clip = encode {t_encode:.0f}s + no-cache token loop "
                        f"{t_gpt:.0f}s + decode {t_decode:.0f}s")}
 
