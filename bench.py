@@ -55,7 +55,8 @@ def parse_args():
 
 def supervise(args, cmd, env):
     """Run the measuring process(es) `cmd` as a child of this one -- which never touches the GPU -- with a time limit, relay
-    the JSON line, and start them again if they do not finish: once more as they are, then with the serial schedule.  One
+    the JSON line, and start them again if they do not finish: once more without the host-side cpu_baseline leg, then also
+    with the serial schedule.  One
     default run in some dozens on this pool's boxes stopped making progress in a state that could not be reproduced under
     a stack-dumping watchdog; a measurement that may never return is not one, so the limit is part of the harness.  The
     line then says so (`supervisor.attempts`, `supervisor.note`)."""
@@ -64,7 +65,11 @@ def supervise(args, cmd, env):
     limit = float(os.environ.get("CCVS_BENCH_TIME_LIMIT", 600 + 12 * (args.steps + args.warmup)))
     notes = []
     for attempt in range(1, 4):
-        extra = ["--schedule", "serial"] if attempt == 3 and args.schedule == "pipelined" else []
+        extra = []
+        if attempt >= 2 and not args.no_cpu_baseline:
+            extra += ["--no-cpu-baseline"]      # the host-side leg is the one part whose duration the GPU does not decide
+        if attempt == 3 and args.schedule == "pipelined":
+            extra += ["--schedule", "serial"]
         proc = subprocess.Popen(cmd + extra, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
         try:
             out, _ = proc.communicate(timeout=limit)
@@ -81,7 +86,7 @@ def supervise(args, cmd, env):
         line = lines[-1]
         if notes:
             rec = json.loads(line)
-            rec["supervisor"] = {"attempts": attempt, "note": "; ".join(notes) + ("; this line is the serial schedule" if extra else "")}
+            rec["supervisor"] = {"attempts": attempt, "note": "; ".join(notes) + ("; this line was measured with " + " ".join(extra) if extra else "")}
             line = json.dumps(rec)
         print(line)
         return proc.returncode

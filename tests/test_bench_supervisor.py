@@ -26,7 +26,7 @@ def _run(tmp_path, monkeypatch, capsys, hangs, schedule="pipelined"):
     script.write_text(CHILD)
     marker = tmp_path / "count"
     monkeypatch.setenv("CCVS_BENCH_TIME_LIMIT", "1.5")
-    args = types.SimpleNamespace(steps=1, warmup=0, schedule=schedule)
+    args = types.SimpleNamespace(steps=1, warmup=0, schedule=schedule, no_cpu_baseline=False)
     rc = bench.supervise(args, [sys.executable, str(script), str(marker), str(hangs)], dict(os.environ))
     out = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
     return rc, out, int(marker.read_text())
@@ -44,14 +44,14 @@ def test_hung_child_is_killed_and_restarted(tmp_path, monkeypatch, capsys):
     assert rc == 0 and runs == 2 and len(out) == 1
     rec = json.loads(out[0])
     assert rec["supervisor"]["attempts"] == 2 and "killed" in rec["supervisor"]["note"]
-    assert "--schedule" not in rec["argv"]
+    assert "--schedule" not in rec["argv"] and rec["argv"] == ["--no-cpu-baseline"]
 
 
 def test_third_attempt_takes_the_serial_schedule(tmp_path, monkeypatch, capsys):
     rc, out, runs = _run(tmp_path, monkeypatch, capsys, hangs=2)
     rec = json.loads(out[0])
     assert rc == 0 and runs == 3 and rec["supervisor"]["attempts"] == 3
-    assert rec["argv"][-2:] == ["--schedule", "serial"] and "serial schedule" in rec["supervisor"]["note"]
+    assert rec["argv"] == ["--no-cpu-baseline", "--schedule", "serial"] and "--schedule serial" in rec["supervisor"]["note"]
 
 
 def test_gives_up_after_three(tmp_path, monkeypatch, capsys):
