@@ -6,18 +6,21 @@
 // 7x7 displacement correlation (modules/correlation.py:11-100):
 //   out[n][7*(dy+3)+(dx+3)][y][x] = (1/C) sum_c A[n/div][c][y*s][x*s] * B[n][c][(y+dy)*s][(x+dx)*s]
 // One workgroup = 8x32 output pixels, one lane per pixel with 49 running sums in
-// registers; per chunk of CORR_CC channels the B halo tile ((7+6)*s+1 x (31+6)*s+1) is
-// staged in LDS (zero outside the image: the reference's padded `rearrange` copy is never
-// materialised).
+// registers; per chunk of CORR_CC channels the B halo tile is staged in LDS (zero outside the
+// image: the reference's padded `rearrange` copy is never materialised).  Only the samples
+// B[(y+dy)*s][(x+dx)*s] are ever read, so the tile holds the stride-s SUBSAMPLED halo,
+// (8+6) x (32+6) values per channel whatever s: a quarter of the staging at s = 2, and the
+// lanes of a wave read consecutive LDS words (with the full-resolution tile they were 2 words
+// apart: every read a two-way bank conflict).
 // ---------------------------------------------------------------------------------------
-#define CORR_CC 4
+#define CORR_CC 8
 
 template <int S>
 __global__ __launch_bounds__(256) void correlation7x7_kernel(const float* __restrict__ first, const float* __restrict__ second,
                                                              float* __restrict__ out, int C, int H, int W, int Ho, int Wo,
                                                              int first_div, int lrelu, int tiles_x, GridWalk gw) {
     constexpr int TH = 8, TW = 32;
-    constexpr int IH = (TH - 1) * S + 6 * S + 1, IW = (TW - 1) * S + 6 * S + 1;
+    constexpr int IH = TH + 6, IW = TW + 6;   // in units of s pixels
     __shared__ float bt[CORR_CC][IH * IW];
     const int tid = threadIdx.x;
     GRID_WALK_BEGIN(gw, bx, by, bz)
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(256) void correlation7x7_kernel(const float* __rest
         __syncthreads();
         for (int e = tid; e < IH * IW; e += 256) {
             const int r = e / IW, c = e - r * IW;
-            const int gy = iy0 + r, gx = ix0 + c;
+            const int gy = iy0 + r * S, gx = ix0 + c * S;
             const bool ok = (gy >= 0 && gy < H && gx >= 0 && gx < W);
             const long o = ok ? (long)gy * W + gx : 0;  // unconditional loads from a clamped address
 #pragma unroll
@@ -53,11 +56,11 @@ __global__ __launch_bounds__(256) void correlation7x7_kernel(const float* __rest
         for (int cc = 0; cc < CORR_CC; ++cc) {
             const float ta = A[(long)min(c0 + cc, C - 1) * H * W + (live ? (long)(oy * S) * W + ox * S : 0)];
             const float a = (live && c0 + cc < C) ? ta : 0.f;
-            const float* bp = &bt[cc][(py * S) * IW + px * S];
+            const float* bp = &bt[cc][py * IW + px];
 #pragma unroll
             for (int dy = 0; dy < 7; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 7; ++dx) acc[dy * 7 + dx] += a * bp[(dy * S) * IW + dx * S];
+                for (int dx = 0; dx < 7; ++dx) acc[dy * 7 + dx] += a * bp[dy * IW + dx];
         }
     }
     if (live) {
