@@ -48,7 +48,9 @@ def parse_args():
     ap.add_argument("--schedule", type=str, default=os.environ.get("CCVS_BENCH_SCHEDULE", "pipelined"), choices=["serial", "pipelined"],
                     help="serial: batches one after the other; pipelined: token loop of batch i+1 beside the decoder of batch i")
     ap.add_argument("--cu-limit", type=int, default=None, help="pipelined: CUs the decoder stream may occupy while token loops are in flight")
-    ap.add_argument("--lanes", type=int, default=None, help="pipelined: token loops (of consecutive batches) that run at the same time")
+    ap.add_argument("--lanes", type=int, default=None, help="pipelined: batches whose token loops run as ONE loop over their stacked rows (a token group)")
+    ap.add_argument("--chains", type=int, default=None, help="pipelined: token groups that run beside each other (one stream each)")
+    ap.add_argument("--ramp", type=str, default=None, help="pipelined: sizes of the first token groups, e.g. 1,2 (then --lanes)")
     ap.add_argument("--rec-pass", action="store_true", help="also run the reference's teacher-forced reconstruction decode (not counted)")
     return ap.parse_args()
 
@@ -321,9 +323,13 @@ def main():
         def run(first, batches):
             """K batches from resident inputs to all-gathered uint8 clips; returns the gathered clips of the last one."""
             if args.schedule == "pipelined":
-                res = gen.run_pipelined(iter(batches), first_iter=first, cu_limit=args.cu_limit, finish=finish, lanes=args.lanes)
+                ramp = tuple(int(v) for v in args.ramp.split(",") if v) if args.ramp is not None else None
+                res = gen.run_pipelined(iter(batches), first_iter=first, cu_limit=args.cu_limit, finish=finish, lanes=args.lanes, chains=args.chains,
+                                        ramp=ramp)
                 handles = [r["finished"] for r in res]
                 stages = gen.pipeline_stage_ms() if engine.is_main else {}
+                if engine.is_main:
+                    stages["timeline"] = gen.pipeline_timeline()
             else:
                 ops.CONV_CU_LIMIT = args.cu_limit or 0     # (experiments: the cost of capping the convolutions, in isolation)
                 handles, stages = [], {"encode": 0.0, "transformer": 0.0, "decode": 0.0}
@@ -379,8 +385,8 @@ def main():
             if alone:
                 shared = {"achieved": achieved, "frac": achieved / (BF16_MFMA_PEAK_TFLOPS if kind == "bf16x3" else FP32_MFMA_PEAK_TFLOPS),
                           "launches": n_conv, "avg_launch_us": 1e3 * conv_ms / max(n_conv, 1), "share_of_step_time": conv_ms * 1e-3 / elapsed,
-                          "note": f"HIP events around every convolution launch of the {args.steps} timed batches: the launches share the chip with the "
-                                  f"token loops of {gen.last_lanes} other batches"}
+                          "note": f"HIP events around every convolution launch of the {args.steps} timed batches: the launches share the chip with "
+                                  f"{gen.last_chains} token loops (each over the stacked rows of up to {gen.last_lanes} other batches)"}
                 n_conv, conv_flops, conv_ms, achieved = n_a, f_a, ms_a, alone
                 timer = timer_alone
             # bf16x3: three bf16 MFMA products per algorithmic fp32 product; peak = dense bf16 MFMA
@@ -398,14 +404,16 @@ def main():
                            "predicted_frames_per_clip": predicted,
                            "rec_pass": ("also run, not counted" if args.rec_pass else "off: the reference's extra teacher-forced reconstruction decode is not part of "
                                         "the synthesized-frames metric (SURVEY 8d)"), "sampling": f"top-k {xopt.top_k}, T={xopt.temperature}, noise={args.sample_noise}",
-                           "schedule": (f"pipelined: {gen.last_lanes + 1} batches in flight per GPU -- the token loops of batches i+1..i+{gen.last_lanes} on "
-                                        f"{gen.last_lanes} high-priority streams (shared weights, one KV cache each) beside the encoder/decoder of batch i"
+                           "schedule": (f"pipelined: up to {gen.last_lanes * gen.last_chains + 1} batches in flight per GPU -- {gen.last_chains} token loops on "
+                                        f"high-priority streams, each ONE loop over the stacked rows of {gen.last_lanes} consecutive batches (weights streamed "
+                                        f"once per token for all of them, per-batch KV rows and sampler words), beside the encoder/decoder of an earlier batch"
                                         + (f", whose kernels are capped to {gen.last_cu_limit} of {n_cu} CUs" if gen.last_cu_limit else "")
                                         + f"; every generate call is one batch of {args.batch} clips; "
                                         "K batches timed from resident inputs to gathered clips, fill and drain included") if args.schedule == "pipelined"
                                        else "serial: one batch at a time",
                            "parallelism": f"dp{world} (batch sharded, one RCCL all-gather of uint8 clips on a side stream)"},
-                "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
+                "stage_ms_per_step": {k: v / args.steps for k, v in stage.items() if k != "timeline"},
+                "timeline_ms": stage.get("timeline"),
                 "stage_note": "per-batch stage durations from HIP events on the stage's own stream" +
                               ("; in the pipelined schedule encode+decode (stream D) and the transformer stages (one stream per lane) overlap" if args.schedule == "pipelined" else ""),
                 "roofline": {"kernel": ("conv2d_bf16x3_pc_kernel<TW,MB,NTY> + conv2d_bf16x3_kernel<TW,MB> (every instantiation: all conv launches)"
@@ -429,22 +437,31 @@ def main():
                              "clock_note": "GRBM cycles / time = 2.0 GHz under this kernel (power-limited), i.e. a 2083 TF/s bf16 ceiling",
                              "share_of_step_time": (shared["share_of_step_time"] if shared else conv_ms * 1e-3 / elapsed)},
             }
-            # the token loop as a whole, in situ: weights once per token + the keys and values of every layer, against the HBM peak
+            # the token loop as a whole, in situ: weights ONCE per step of a token group + the keys and values of every batch in it,
+            # against the HBM peak
             net_t = gen.transformer_model.net_t
-            n_tok = (xopt.vid_len * 64 - xopt.cond_len) if args.config == "bair" else (xopt.vid_len * 64 - xopt.cond_len)
+            n_tok = xopt.vid_len * 64 - xopt.cond_len
             w_bytes = 4.0 * sum(p_.numel() for n_, p_ in net_t.named_parameters() if n_.startswith("blocks.") and p_.dim() == 2) + 4.0 * net_t.head.weight.numel()
             kv_bytes = 8.0 * args.batch * net_t.config.n_embd * len(net_t.blocks) * (xopt.cond_len + xopt.z_len) / 2
-            tok_ms = stage["transformer"] / args.steps / n_tok
+            if args.schedule == "pipelined":
+                groups = gen.pipeline_token_groups()
+                n_chains = gen.last_chains
+            else:
+                groups, n_chains = [(1, stage["transformer"] / args.steps)] * args.steps, 1
+            loop_ms = sum(ms for _, ms in groups)
+            loop_bytes = sum(n_tok * (w_bytes + g * kv_bytes) for g, _ in groups)
+            gbps = loop_bytes / (loop_ms * 1e-3) / 1e9
+            mean_group = sum(g for g, _ in groups) / len(groups)
             line["roofline_token_loop"] = {
-                "kernel": "token loop (ccvs_gpt_decode_step replayed as a hipGraph: 5 x n_layer + 3 launches per token)", "bound": "hbm",
-                "achieved": (w_bytes + kv_bytes) / (tok_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": (w_bytes + kv_bytes) / (tok_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "ms_per_token": tok_ms, "tokens_per_clip": n_tok,
-                "algorithmic_bytes_per_token": w_bytes + kv_bytes, "weights_bytes": w_bytes, "mean_kv_bytes": kv_bytes,
-                "concurrent_token_loops": gen.last_lanes if args.schedule == "pipelined" else 1,
-                "aggregate_frac": (gen.last_lanes if args.schedule == "pipelined" else 1) * (w_bytes + kv_bytes) / (tok_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "note": "HIP events on the token stream around the whole loop of the timed region (prefill of the conditioning frame included); in the "
-                        "pipelined schedule `frac` is ONE lane's stream while `concurrent_token_loops` lanes and the decoder share the memory system "
-                        "(aggregate_frac = lanes x frac)"}
+                "kernel": "token loop (ccvs_gpt_decode_step replayed as a hipGraph: 5 x n_layer + 3 launches per step; one step serves every batch of the token group)",
+                "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                "ms_per_step": loop_ms / (len(groups) * n_tok), "ms_per_token_per_batch": loop_ms / (sum(g for g, _ in groups) * n_tok),
+                "tokens_per_clip": n_tok, "batches_per_token_group": [g for g, _ in groups], "mean_batches_per_group": mean_group,
+                "algorithmic_bytes_per_step": w_bytes + mean_group * kv_bytes, "weights_bytes": w_bytes, "mean_kv_bytes_per_batch": kv_bytes,
+                "concurrent_token_loops": n_chains, "aggregate_frac": n_chains * gbps / HBM_PEAK_GBPS,
+                "note": "HIP events on each token stream around the whole loop of every token group of the timed region (prefill of the conditioning frame "
+                        "included); bytes = weights counted ONCE per step + mean KV bytes of every batch in the group; `frac` is ONE loop's stream while "
+                        "`concurrent_token_loops` loops and the decoder share the memory system (aggregate_frac = loops x frac)"}
             line["roofline_decode_kernels"] = decode_kernel_rooflines(gen, xopt, args.batch)
             if not args.no_cpu_baseline and args.config == "bair" and world == 1:   # rank 0 at N = 1 only
                 line["cpu_baseline"] = cpu_baseline(gen, opt)

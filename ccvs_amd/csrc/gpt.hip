@@ -11,10 +11,11 @@
 // are pre-summed by the host into pos_table once per call).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gpt_embed_kernel(const int64_t* __restrict__ idx, long idx_sB, const int32_t* __restrict__ pos_off,
-                                                        int pos0, const int32_t* __restrict__ pos_dev, int Tq,
+                                                        int pos0, const int32_t* __restrict__ pos_dev, int grp_rows, int Tq,
                                                         const float* __restrict__ tok, const float* __restrict__ pos,
                                                         float* __restrict__ x, long total, int C, int vocab) {
-    if (pos_dev) pos0 += *pos_dev;  // device-resident position: lets a captured hipGraph replay at advancing positions
+    // device-resident position: lets a captured hipGraph replay at advancing positions; with row groups (grp_rows > 0)
+    // batch row b reads the word of its group, pos_dev[b / grp_rows]
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long r = i / C;
         const int c = (int)(i - r * C);
@@ -22,7 +23,7 @@ __global__ __launch_bounds__(256) void gpt_embed_kernel(const int64_t* __restric
         const int tq = (int)(r - b * Tq);
         long t = idx[b * idx_sB + tq];
         t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
-        const long prow = (pos_off ? pos_off[b] : 0) + pos0 + tq;
+        const long prow = (pos_off ? pos_off[b] : 0) + pos0 + (pos_dev ? pos_dev[grp_rows > 0 ? b / grp_rows : 0] : 0) + tq;
         x[i] = tok[t * C + c] + pos[prow * C + c];
     }
 }
@@ -33,7 +34,7 @@ extern "C" int ccvs_gpt_embed(const int64_t* idx, int64_t idx_sB, const int32_t*
     CCVS_REQUIRE(B > 0 && Tq > 0 && C > 0 && vocab > 0 && (pos0 >= 0 || pos_dev), "ccvs_gpt_embed: empty tensor");
     const long total = (long)B * Tq * C;
     hipLaunchKernelGGL(gpt_embed_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, idx, (long)idx_sB, pos_off,
-                       pos0, pos_dev, Tq, tok_emb, pos_table, x, total, C, vocab);
+                       pos0, pos_dev, 0, Tq, tok_emb, pos_table, x, total, C, vocab);
     CCVS_CHECK_LAUNCH("ccvs_gpt_embed");
     return CCVS_OK;
 }
@@ -95,27 +96,81 @@ __device__ __forceinline__ void ln_accum(const float4& v, float& sx, float& sxx)
     sxx += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
 }
 
+__device__ __forceinline__ void ln_accum(const f32x4& v, float& sx, float& sxx) {
+#pragma clang fp contract(off)
+    sx += (v[0] + v[1]) + (v[2] + v[3]);
+    sxx += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+}
+
+// 16 bytes at descriptor `r`, per-lane byte offset `voff` + wave-uniform byte offset `soff` (buffer_load_dwordx4 ... offen)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
 struct Gemm16 {
     const float* x; long ldx;
     const float* w; const float* bias; const float* res; float* y; long ldy;
     int M, N, K, epi, ks;
     const float* ln_s; float ln_eps;
     float* kcache; float* vcache; int C, H, D, Tq, Tmax, pos0; const int32_t* pos_dev;
+    int grp_rows;      // > 0: batch row b takes its device-resident position from pos_dev[b / grp_rows] (row groups of a decode step)
     int kz;            // K slices across workgroups (gridDim.z); > 1 only with a workspace
     float* ws_slabs;   // [tile][kz][64 lanes][4] partial accumulators
     int* ws_count;     // [tile] arrival counters, zero between launches
 };
 
-#define GEMM_U 8  // K steps (of 16) whose loads are issued together
-#define GEMM_WS_TILES 128  // output tiles a workspace covers (split-K is only used when tiles <= this)
+#define GEMM_U 4  // K steps (of 16) whose loads are issued together (4 float4 of W + 4 of x per lane: the 48-VGPR budget)
+#define GEMM_U_RB 8  // the same for the prefill form (512 threads, its own CU)
+#define GEMM_WS_TILES 1024  // 16 x 16 output tiles a workspace covers (64 column tiles x 16 row blocks: every split-K launch fits)
+#define GEMM_DECODE_MAX_M 256  // up to this many rows the weight-stream kernel below runs; beyond, the prefill form
 
+// LayerNorm statistics -> (mean, rstd) and the epilogue of one output value: single definitions with floating-point
+// contraction off, so that every instantiation of the kernel below rounds identically (a row's result must not depend on
+// how many other rows share its launch: the grouped decode step is bit-identical to one step per batch).
+__device__ __forceinline__ void ln_finish(float a, float b, int K, float eps, float& mean, float& rstd) {
+#pragma clang fp contract(off)
+    mean = a / K;
+    const float var = fmaxf(b / K - mean * mean, 0.f);
+    rstd = rsqrtf(var + eps);
+}
+__device__ __forceinline__ float gemm_epilogue(float v, bool ln, float rstd, float mean, float sn, float bv, int epi, float rv) {
+#pragma clang fp contract(off)
+    if (ln) v = rstd * (v - mean * sn);
+    v += bv;
+    if (epi == 1) v = gelu_erf(v);
+    if (epi == 2) v += rv;
+    return v;
+}
+
+// The weight-stream kernel (M <= GEMM_DECODE_MAX_M rows: decode steps, small prefills).
+//
+// FOOTPRINT FIRST.  The decode step runs beside the frame decoder of another batch, whose convolution workgroups (8 waves x
+// 210-225 VGPRs, ~100 KB of LDS) hold every CU: two such waves per SIMD leave 48 VGPRs per lane and ~56 KB of LDS.  A
+// workgroup that fits into that remainder is dispatched at once next to the convolution; one that does not waits for a
+// convolution workgroup to retire (~100 us).  Measured with a chain of dependent 16 MB weight-stream launches beside the
+// real decoder (tools/chain_probe.py, profiles/r03_chain_probe.txt): 512 threads x 200 VGPRs 41 us per launch, 512 x 100
+// (the round-2 kernel) 16 us, 256 x 56 14 us, 256 x <= 48 VGPRs with <= 56 KB LDS 10 us (5.8 us alone).  Hence: 256 threads,
+// at most 48 VGPRs, a few KB of LDS -- bytes in flight per workgroup are what the registers allow (4 float4 of W and of x
+// per lane), and the launch gets its bandwidth from the NUMBER of workgroups.
+//   * workgroup = 16 rows x 16 columns, 4 waves = 4 K slices; each lane issues the float4 loads of a 64-deep K batch of W
+//     (row n = lane&15, k = k0+4*(lane>>4)+t) and of x (same k map, row = lane&15, served by L2) before the MFMAs of the batch;
+//   * no LDS staging, no barrier in the main loop; the K slices are summed through LDS in a fixed order (wave 0 first;
+//     bitwise reproducible, no float atomics); deep K (>= 2048) also splits over `kz` workgroups (last-arriver reduction);
+//   * more rows than 16 (the stacked rows of several batches in one decode step, ccvs_gpt_decode.groups) = more row blocks
+//     in gridDim.y: they run at the same time on other CUs and share the weight tile through L2 / the Infinity Cache.  A
+//     row's arithmetic depends on N and K only (K slicing, MFMA order, slab order, epilogue), never on M;
+//   * LayerNorm folded in algebraically and the K / V column blocks of the QKV projection scattered straight into the KV
+//     cache, as described above.
 // The operands of the address arithmetic come first and as plain kernel arguments: with -mllvm
 // -amdgpu-kernarg-preload-count they are delivered in SGPRs when the wave starts (gfx950 kernarg preload), so the weight
 // and activation loads of this latency-bound kernel go out without first waiting for a scalar load of the argument block.
-__global__ __launch_bounds__(512) void gemm16_kernel(const float* __restrict__ x_, const float* __restrict__ w_, long ldx_, int K_, int N_,
-                                                     int M_, int ks_, int kz_, Gemm16 p) {
-    __shared__ __attribute__((aligned(16))) float red[7 * 64 * 4];
-    __shared__ float stat[8 * 16 * 2];
+#define GEMM_WAVES 4
+__global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __restrict__ x_, const float* __restrict__ w_, long ldx_, int K_, int N_,
+                                                                int M_, int ks_, int kz_, Gemm16 p) {
+    __shared__ __attribute__((aligned(16))) float red[GEMM_WAVES * 64 * 4];
+    __shared__ float stat[GEMM_WAVES * 16 * 2];
     __shared__ float fin[16 * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
@@ -124,82 +179,60 @@ __global__ __launch_bounds__(512) void gemm16_kernel(const float* __restrict__ x
     const int kper = K_ / (ks_ * kz_);
     const int kbase = blockIdx.z * (K_ / kz_);
     const bool active = wave < ks_;
-    const float* wp = w_ + (long)nrow * K_ + kbase + (active ? wave : 0) * kper + 4 * g;
-    const float* xp = x_ + (long)mrow * ldx_ + kbase + (active ? wave : 0) * kper + 4 * g;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // Buffer loads: a wave-uniform 128-bit descriptor per tensor in SGPRs + ONE 32-bit byte offset per lane and stream (the
+    // K position goes into the scalar offset / the instruction's immediate) instead of 64-bit pointer pairs and their
+    // adds -- the 48-VGPR budget.  The launcher checks that both tensors stay below 2^31 bytes.
+    const unsigned koff = kbase + (active ? wave : 0) * kper + 4 * g;
+    const unsigned wofs = ((unsigned)nrow * (unsigned)K_ + koff) * 4u;
+    const unsigned xofs = ((unsigned)mrow * (unsigned)ldx_ + koff) * 4u;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w_), 0, N_ * K_ * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x_), 0, (int)(M_ * ldx_ * 4), 0x00020000);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float sx = 0.f, sxx = 0.f;
-
-    // first 128-deep batch of W (decode shapes have kper == 128: the workgroup's whole weight tile) goes out first
-    const bool full = active && kper >= 16 * GEMM_U;
-    float4 wv[GEMM_U], xv[GEMM_U];
-    if (full) {
-#pragma unroll
-        for (int u = 0; u < GEMM_U; ++u) wv[u] = *reinterpret_cast<const float4*>(wp + 16 * u);
-    }
-    // the finishing wave also fetches its epilogue operands now: after the K loop they would be a second
-    // dependent trip to memory (~1 us of a ~8 us kernel)
-    const int col = ncol0 + li;
-    float bv = 0.f, sn = 0.f, rv[4] = {0.f, 0.f, 0.f, 0.f};
-    int pos0 = p.pos0;
-    if (p.kcache && p.pos_dev) pos0 += *p.pos_dev;
-    if (wave == 0) {
-        const int colc = min(col, p.N - 1);
-        if (p.bias) bv = p.bias[colc];
-        if (p.ln_s) sn = p.ln_s[colc];
-        if (p.epi == 2) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rv[r] = p.res[(long)min(m0 + 4 * g + r, p.M - 1) * p.ldy + colc];
-        }
-    }
     if (active) {
-        // full batches: GEMM_U unconditional float4 loads of W and of x in flight per lane (no
-        // predicated loads -- hipcc would serialise them), then the MFMAs
+        // full batches: GEMM_U unconditional 16-byte loads of W and of x in flight per lane, then the MFMAs (one accumulator
+        // chain: 16 dependent MFMAs per batch cost a few cycles each, a second chain would cost 4-8 registers)
         int k0 = 0;
         for (; k0 + 16 * GEMM_U <= kper; k0 += 16 * GEMM_U) {
+            f32x4 wv[GEMM_U], xv[GEMM_U];
+#pragma unroll
+            for (int u = 0; u < GEMM_U; ++u) wv[u] = buf_load4(wr, wofs, k0 * 4 + 64 * u);
+#pragma unroll
+            for (int u = 0; u < GEMM_U; ++u) xv[u] = buf_load4(xr, xofs, k0 * 4 + 64 * u);
 #pragma unroll
             for (int u = 0; u < GEMM_U; ++u) {
-                if (k0 > 0) wv[u] = *reinterpret_cast<const float4*>(wp + k0 + 16 * u);
-                xv[u] = *reinterpret_cast<const float4*>(xp + k0 + 16 * u);
-            }
 #pragma unroll
-            for (int u = 0; u < GEMM_U; ++u) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].x, wv[u].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].y, wv[u].y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].z, wv[u].z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].w, wv[u].w, acc1, 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][t], wv[u][t], acc, 0, 0, 0);
                 if (p.ln_s) ln_accum(xv[u], sx, sxx);
             }
         }
         for (; k0 < kper; k0 += 16) {  // remainder (small K only)
-            const float4 w1 = *reinterpret_cast<const float4*>(wp + k0);
-            const float4 x1 = *reinterpret_cast<const float4*>(xp + k0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, w1.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, w1.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, w1.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, w1.w, acc1, 0, 0, 0);
+            const f32x4 w1 = buf_load4(wr, wofs, k0 * 4);
+            const f32x4 x1 = buf_load4(xr, xofs, k0 * 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[t], w1[t], acc, 0, 0, 0);
             if (p.ln_s) ln_accum(x1, sx, sxx);
         }
     }
-    f32x4 acc = acc0 + acc1;
     if (p.ln_s) {  // lanes li, li+16, li+32, li+48 hold the four k-groups of row li
         sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
         sxx += __shfl_xor(sxx, 16, 64); sxx += __shfl_xor(sxx, 32, 64);
         if (g == 0) { stat[(wave * 16 + li) * 2] = sx; stat[(wave * 16 + li) * 2 + 1] = sxx; }
     }
-    if (wave > 0) *reinterpret_cast<f32x4*>(red + ((wave - 1) * 64 + lane) * 4) = acc;
+    *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = acc;
     __syncthreads();
     if (p.ln_s && tid < 16) {
         float a = 0.f, b = 0.f;
-        for (int w = 0; w < 8; ++w) { a += stat[(w * 16 + tid) * 2]; b += stat[(w * 16 + tid) * 2 + 1]; }
-        const float mean = a / p.K;
-        const float var = fmaxf(b / p.K - mean * mean, 0.f);
+        for (int w = 0; w < GEMM_WAVES; ++w) { a += stat[(w * 16 + tid) * 2]; b += stat[(w * 16 + tid) * 2 + 1]; }
+        float mean, rstd;
+        ln_finish(a, b, p.K, p.ln_eps, mean, rstd);
         fin[tid * 2] = mean;
-        fin[tid * 2 + 1] = rsqrtf(var + p.ln_eps);
+        fin[tid * 2 + 1] = rstd;
     }
     __syncthreads();
     if (wave > 0) return;  // wave 0 finishes the tile
 #pragma unroll
-    for (int s = 0; s < 7; ++s) acc += *reinterpret_cast<const f32x4*>(red + (s * 64 + lane) * 4);
+    for (int s = 1; s < GEMM_WAVES; ++s) acc += *reinterpret_cast<const f32x4*>(red + (s * 64 + lane) * 4);
 
     bool finisher = true;
     if (p.kz > 1) {
@@ -231,23 +264,24 @@ __global__ __launch_bounds__(512) void gemm16_kernel(const float* __restrict__ x
     }
 
     // D[row = 4*g + r][col = li]
+    const int col = ncol0 + li;
     if (finisher && col < p.N) {
+        const float bv = p.bias ? p.bias[col] : 0.f;
+        const float sn = p.ln_s ? p.ln_s[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + 4 * g + r;
             if (row >= p.M) continue;
-            float v = acc[r];
-            if (p.ln_s) v = fin[(4 * g + r) * 2 + 1] * (v - fin[(4 * g + r) * 2] * sn);
-            v += bv;
-            if (p.epi == 1) v = gelu_erf(v);
-            if (p.epi == 2) v += rv[r];
+            const float rv = p.epi == 2 ? p.res[(long)row * p.ldy + col] : 0.f;
+            const float v = gemm_epilogue(acc[r], p.ln_s != nullptr, fin[(4 * g + r) * 2 + 1], fin[(4 * g + r) * 2], sn, bv, p.epi, rv);
             if (p.kcache && col >= p.C) {
                 const int cc = col - p.C;
                 float* cache = cc >= p.C ? p.vcache : p.kcache;
                 const int c2 = cc >= p.C ? cc - p.C : cc;
                 const int h = c2 / p.D, d = c2 - h * p.D;
                 const int b = row / p.Tq, t = row - b * p.Tq;
-                if (pos0 + t < p.Tmax) cache[(((long)b * p.H + h) * p.Tmax + pos0 + t) * p.D + d] = v;
+                const int pos = p.pos0 + (p.pos_dev ? p.pos_dev[p.grp_rows > 0 ? b / p.grp_rows : 0] : 0);
+                if (pos + t < p.Tmax) cache[(((long)b * p.H + h) * p.Tmax + pos + t) * p.D + d] = v;
             } else {
                 p.y[(long)row * p.ldy + col] = v;
             }
@@ -255,10 +289,9 @@ __global__ __launch_bounds__(512) void gemm16_kernel(const float* __restrict__ x
     }
 }
 
-// Row-blocked form for M > 16 (prefill, batches beyond 16): one workgroup computes RB row blocks of 16 against the SAME
-// 16 output columns, so a weight tile is fetched once per 16*RB rows instead of once per 16 (the plain kernel re-reads
-// W from L2 for every row block).  Same K slicing over the 8 waves, same MFMA order per row block and the same
-// slab summation order (wave 0 first), hence bit-identical to the plain kernel.  No split-K here (kz = 1).
+// Prefill form (M > GEMM_DECODE_MAX_M rows): one workgroup computes RB row blocks of 16 against the SAME 16 output columns,
+// so a weight tile is fetched once per 16*RB rows.  K sliced over the 8 waves only (kz = 1: with hundreds of row blocks
+// the chip is full without split-K), argument block read the ordinary way.
 template <int RB>
 __global__ __launch_bounds__(512) void gemm16_rb_kernel(Gemm16 p) {
     __shared__ __attribute__((aligned(16))) float red[RB * 8 * 64 * 4];
@@ -280,17 +313,17 @@ __global__ __launch_bounds__(512) void gemm16_rb_kernel(Gemm16 p) {
     for (int rb = 0; rb < RB; ++rb) { acc0[rb] = {0.f, 0.f, 0.f, 0.f}; acc1[rb] = {0.f, 0.f, 0.f, 0.f}; sx[rb] = 0.f; sxx[rb] = 0.f; }
     if (active) {
         int k0 = 0;
-        for (; k0 + 16 * GEMM_U <= kper; k0 += 16 * GEMM_U) {
-            float4 wv[GEMM_U];
+        for (; k0 + 16 * GEMM_U_RB <= kper; k0 += 16 * GEMM_U_RB) {
+            float4 wv[GEMM_U_RB];
 #pragma unroll
-            for (int u = 0; u < GEMM_U; ++u) wv[u] = *reinterpret_cast<const float4*>(wp + k0 + 16 * u);
+            for (int u = 0; u < GEMM_U_RB; ++u) wv[u] = *reinterpret_cast<const float4*>(wp + k0 + 16 * u);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                float4 xv[GEMM_U];
+                float4 xv[GEMM_U_RB];
 #pragma unroll
-                for (int u = 0; u < GEMM_U; ++u) xv[u] = *reinterpret_cast<const float4*>(xp[rb] + k0 + 16 * u);
+                for (int u = 0; u < GEMM_U_RB; ++u) xv[u] = *reinterpret_cast<const float4*>(xp[rb] + k0 + 16 * u);
 #pragma unroll
-                for (int u = 0; u < GEMM_U; ++u) {
+                for (int u = 0; u < GEMM_U_RB; ++u) {
                     acc0[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].x, wv[u].x, acc0[rb], 0, 0, 0);
                     acc1[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].y, wv[u].y, acc1[rb], 0, 0, 0);
                     acc0[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].z, wv[u].z, acc0[rb], 0, 0, 0);
@@ -328,10 +361,10 @@ __global__ __launch_bounds__(512) void gemm16_rb_kernel(Gemm16 p) {
         const int rb = tid >> 4, r = tid & 15;
         float a = 0.f, b = 0.f;
         for (int w = 0; w < 8; ++w) { a += stat[((rb * 8 + w) * 16 + r) * 2]; b += stat[((rb * 8 + w) * 16 + r) * 2 + 1]; }
-        const float mean = a / p.K;
-        const float var = fmaxf(b / p.K - mean * mean, 0.f);
+        float mean, rstd;
+        ln_finish(a, b, p.K, p.ln_eps, mean, rstd);
         fin[tid * 2] = mean;
-        fin[tid * 2 + 1] = rsqrtf(var + p.ln_eps);
+        fin[tid * 2 + 1] = rstd;
     }
     __syncthreads();
     if (wave >= RB) return;  // wave rb finishes row block rb
@@ -349,11 +382,8 @@ __global__ __launch_bounds__(512) void gemm16_rb_kernel(Gemm16 p) {
     for (int r = 0; r < 4; ++r) {
         const int row = m0 + 16 * rb + 4 * g + r;
         if (row >= p.M) continue;
-        float v = acc[r];
-        if (p.ln_s) v = fin[(rb * 16 + 4 * g + r) * 2 + 1] * (v - fin[(rb * 16 + 4 * g + r) * 2] * sn);
-        v += bv;
-        if (p.epi == 1) v = gelu_erf(v);
-        if (p.epi == 2) v += p.res[(long)row * p.ldy + col];
+        const float v = gemm_epilogue(acc[r], p.ln_s != nullptr, fin[(rb * 16 + 4 * g + r) * 2 + 1], fin[(rb * 16 + 4 * g + r) * 2], sn, bv, p.epi,
+                                      p.epi == 2 ? p.res[(long)row * p.ldy + col] : 0.f);
         if (p.kcache && col >= p.C) {
             const int cc = col - p.C;
             float* cache = cc >= p.C ? p.vcache : p.kcache;
@@ -374,13 +404,15 @@ static int getenv_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+// K slices across workgroups.  A function of N and K only -- never of M -- so that a row's K partition, hence its rounding,
+// does not depend on how many rows share the launch.
 static int gemm_kz(const Gemm16& g) {
     static int kz_max = -1;
     if (kz_max < 0) { const char* e = getenv("CCVS_GEMM_KZ_MAX"); kz_max = e ? atoi(e) : 4; }
-    const int tiles = cdiv(g.N, 16) * cdiv(g.M, 16);
+    const int tiles = cdiv(g.N, 16);
     int kz = 1;
     if (g.ws_slabs && !g.ln_s)
-        while (g.K >= 2048 && kz < kz_max && tiles * kz * 2 <= 256 && g.K % (16 * 8 * kz * 2) == 0 && tiles <= GEMM_WS_TILES) kz *= 2;
+        while (g.K >= 2048 && kz < kz_max && tiles * kz * 2 <= 256 && g.K % (16 * GEMM_WAVES * kz * 2) == 0) kz *= 2;
     return kz;
 }
 
@@ -389,15 +421,21 @@ static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
     if (!(g.M > 0 && g.N > 0 && g.K > 0)) { ccvs_set_error("%s: empty tensor", name); return CCVS_ERR_ARG; }
     if (g.K % 16 != 0 || g.ldx % 4 != 0) { ccvs_set_error("%s: K=%d must be a multiple of 16 (ldx %% 4 == 0)", name, g.K); return CCVS_ERR_ARG; }
     if (g.epi < 0 || g.epi > 2 || (g.epi == 2 && !g.res)) { ccvs_set_error("%s: bad epilogue", name); return CCVS_ERR_ARG; }
-    g.kz = gemm_kz(g);
-    g.ks = 8;
+    const bool decode_form = g.M <= GEMM_DECODE_MAX_M;
+    if (decode_form && ((long)g.N * g.K * 4 >= (1L << 31) || (long)g.M * g.ldx * 4 >= (1L << 31))) {
+        ccvs_set_error("%s: operand beyond 2^31 bytes (32-bit buffer offsets)", name);
+        return CCVS_ERR_ARG;
+    }
+    if (!decode_form && g.grp_rows > 0) { ccvs_set_error("%s: row groups need M <= %d", name, GEMM_DECODE_MAX_M); return CCVS_ERR_ARG; }
+    g.kz = decode_form ? gemm_kz(g) : 1;
+    if (g.kz > 1 && cdiv(g.N, 16) * cdiv(g.M, 16) > GEMM_WS_TILES) g.kz = 1;   // cannot happen for M <= 256 (kz > 1 needs <= 64 column tiles)
+    g.ks = decode_form ? GEMM_WAVES : 8;
     while (g.ks > 1 && g.K % (16 * g.ks * g.kz) != 0) g.ks >>= 1;
-    static const int rb_max = getenv_int("CCVS_GEMM_RB", 4);
-    // row-blocked only from 128 rows up (prefill): at M = 64 it is slower for deep K (64 workgroups walk K = 4096 alone)
-    if (g.kz == 1 && g.M >= 128 && rb_max >= 4)
+    if (!decode_form)
         hipLaunchKernelGGL((gemm16_rb_kernel<4>), dim3(cdiv(g.N, 16), cdiv(g.M, 64), 1), dim3(512), 0, st, g);
     else
-        hipLaunchKernelGGL(gemm16_kernel, dim3(cdiv(g.N, 16), cdiv(g.M, 16), g.kz), dim3(512), 0, st, g.x, g.w, g.ldx, g.K, g.N, g.M, g.ks, g.kz, g);
+        hipLaunchKernelGGL(gemm16_kernel, dim3(cdiv(g.N, 16), cdiv(g.M, 16), g.kz), dim3(64 * GEMM_WAVES), 0, st, g.x, g.w, g.ldx, g.K, g.N, g.M, g.ks,
+                           g.kz, g);
     CCVS_CHECK_LAUNCH(name);
     return CCVS_OK;
 }
@@ -649,18 +687,19 @@ __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __r
 // A key row of D floats is read by D/4 consecutive lanes as float4 (a wave-instruction covers
 // 64/(D/4) whole rows: 1 KiB, fully coalesced); the partial dots are summed across those lanes
 // with xor shuffles.  PV uses the same lane map (lane owns 4 head dims of one key slot); the
-// key slots of a wave and the 8 waves are reduced through LDS in a fixed order.
-// The kernel is a latency chain (L/256 batches of K, a softmax reduction, L/256 batches of V), so the
-// batches are double-buffered in registers -- batch i+1 is in flight while batch i is consumed -- and
-// the first V batch is requested before the softmax reduction starts.
+// key slots of a wave and the 4 waves are reduced through LDS in a fixed order.
+// Footprint (see gemm16_kernel): 256 threads, <= 48 VGPRs, LDS = scores + 4 KB -- the workgroup is dispatched next to a
+// convolution workgroup of the frame decoder instead of waiting for one to retire; a stream of this shape keeps 3.5 TB/s
+// beside the decoder (5.5 alone; tools/chain_probe.py).  Four key rows per lane are requested together (16 KB in flight
+// per workgroup); the first V batch is requested before the softmax reduction starts.
 template <int D>
-__global__ __launch_bounds__(512) void attention_decode_kernel(const float* __restrict__ q, long q_sB, const float* __restrict__ kc,
+__global__ __launch_bounds__(256) void attention_decode_kernel(const float* __restrict__ q, long q_sB, const float* __restrict__ kc,
                                                                const float* __restrict__ vc, float* __restrict__ out, int H, int pos0,
-                                                               const int32_t* __restrict__ pos_dev, int Tmax, float scale) {
+                                                               const int32_t* __restrict__ pos_dev, int grp_rows, int Tmax, float scale) {
     constexpr int LPK = D / 4;     // lanes per key row
     constexpr int KPI = 64 / LPK;  // key rows per wave-instruction
-    constexpr int NW = 8;
-    constexpr int AU = 8;          // key rows per lane whose loads are issued together (64 KiB in flight per workgroup and buffer)
+    constexpr int NW = 4;
+    constexpr int AU = 4;          // key rows per lane whose loads are issued together
     constexpr int BATCH = NW * KPI * AU;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* red = smem;                    // [16]
@@ -669,7 +708,7 @@ __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x;
     const int b = bh / H, h = bh - b * H;
-    if (pos_dev) pos0 += *pos_dev;
+    if (pos_dev) pos0 += pos_dev[grp_rows > 0 ? b / grp_rows : 0];   // row groups of a decode step: one cache length per group
     const int L = min(pos0 + 1, Tmax);
     const int kk = lane / LPK, d4 = lane - kk * LPK;
     const float* kbase = kc + (long)bh * Tmax * D + 4 * d4;
@@ -682,11 +721,11 @@ __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __re
     _Pragma("unroll") for (int u = 0; u < AU; ++u)                                                                       \
         dst[u] = *reinterpret_cast<const float4*>(base + (long)min((bi) * BATCH + jw + u * NW * KPI, L - 1) * D)
 
-    float4 ka[AU], kb[AU];
-    ATT_LOAD(ka, kbase, 0);
     const float4 qv = *reinterpret_cast<const float4*>(q + (long)b * q_sB + h * D + 4 * d4);
     float lmax = -INFINITY;
-    auto scores = [&](const float4 (&kv)[AU], int bi) {
+    for (int bi = 0; bi < nbatch; ++bi) {
+        float4 kv[AU];
+        ATT_LOAD(kv, kbase, bi);
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
             const int j = bi * BATCH + jw + u * NW * KPI;
@@ -699,17 +738,9 @@ __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __re
                 lmax = fmaxf(lmax, s);
             }
         }
-    };
-    for (int bi = 0; bi < nbatch; bi += 2) {
-        if (bi + 1 < nbatch) ATT_LOAD(kb, kbase, bi + 1);
-        scores(ka, bi);
-        if (bi + 1 < nbatch) {
-            if (bi + 2 < nbatch) ATT_LOAD(ka, kbase, bi + 2);
-            scores(kb, bi + 1);
-        }
     }
-    float4 va[AU], vb[AU];
-    ATT_LOAD(va, vbase, 0);  // in flight during the softmax reductions
+    float4 vv[AU];
+    ATT_LOAD(vv, vbase, 0);  // in flight during the softmax reductions
 
     lmax = wave_max(lmax);
     if (lane == 0) red[wave] = lmax;
@@ -732,20 +763,13 @@ __global__ __launch_bounds__(512) void attention_decode_kernel(const float* __re
     for (int w = 1; w < NW; ++w) tot += red[w];
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto weigh = [&](const float4 (&vv)[AU], int bi) {
+    for (int bi = 0; bi < nbatch; ++bi) {
+        if (bi > 0) ATT_LOAD(vv, vbase, bi);
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
             const int j = bi * BATCH + jw + u * NW * KPI;
             const float p = (j < L) ? ps[min(j, L - 1)] : 0.f;
             acc.x += p * vv[u].x; acc.y += p * vv[u].y; acc.z += p * vv[u].z; acc.w += p * vv[u].w;
-        }
-    };
-    for (int bi = 0; bi < nbatch; bi += 2) {
-        if (bi + 1 < nbatch) ATT_LOAD(vb, vbase, bi + 1);
-        weigh(va, bi);
-        if (bi + 1 < nbatch) {
-            if (bi + 2 < nbatch) ATT_LOAD(va, vbase, bi + 2);
-            weigh(vb, bi + 1);
         }
     }
 #undef ATT_LOAD
@@ -771,12 +795,12 @@ extern "C" int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const f
     const float scale = 1.0f / sqrtf((float)D);
     hipStream_t st = (hipStream_t)stream;
     if (Tq == 1) {
-        const size_t smem = (size_t)(16 + 8 * 256 + maxL) * sizeof(float);
+        const size_t smem = (size_t)(16 + 4 * 256 + maxL) * sizeof(float);
         CCVS_REQUIRE(smem <= 64 * 1024, "ccvs_attention: sequence too long for the LDS score buffer");
         const dim3 grid((unsigned)(B * H));
-        if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
-        else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
-        else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(512), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, Tmax, scale);
+        if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(256), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, 0, Tmax, scale);
+        else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(256), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, 0, Tmax, scale);
+        else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(256), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, 0, Tmax, scale);
     } else {
         const dim3 grid((unsigned)(B * H), (unsigned)cdiv(Tq, 128));
         if (D == 64) hipLaunchKernelGGL((attention_prefill_kernel<64>), grid, dim3(256), 0, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, pos_dev, Tmax, scale);
@@ -819,6 +843,7 @@ struct Advance {       // decode-step bookkeeping folded into the sampling kerne
     int rng;           // draw the Exp(1) noise here: Philox keyed by state[4..5], counter (element, state[6] + row, step = state[0], call = state[3])
     unsigned imm[5];   // rng == 2: immediate Philox words (key0, key1, global row of row 0, step, call) instead of `state`
     int* state;        // int32[8]: [0] completed steps, [2] arrival ticket of this kernel's rows, [3] call index, [4..5] Philox key, [6] global index of row 0
+    int grp_rows;      // > 0: rows [g * grp_rows, (g+1) * grp_rows) form group g with its own widx[g], len[g] and state[8g .. 8g+7]
 };
 
 // k-th largest key of xs[0..V) by a 4-pass radix-256 descent (LDS histogram + suffix scan per pass).
@@ -866,6 +891,11 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
     int* hist = (int*)(smem + V + 16); // [256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
+    // row group of this row: its own counters / Philox words; `brow` = the row's index inside the group
+    const int grp = adv.grp_rows > 0 ? b / adv.grp_rows : 0;
+    const int brow = b - grp * (adv.grp_rows > 0 ? adv.grp_rows : 0);
+    const int nrows = adv.grp_rows > 0 ? min(adv.grp_rows, (int)gridDim.x - grp * adv.grp_rows) : (int)gridDim.x;
+    if (adv.grp_rows > 0) { adv.state += 8 * grp; adv.widx += grp; adv.len += grp; }
     const float* lr = logits + (long)b * ld;
     float lmax = -INFINITY;
     for (int j = tid; j < V; j += 256) {
@@ -906,7 +936,7 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
         float p = xs[j] / tot;
         if (noise) p = p / noise[(long)b * V + j];
         else if (adv.rng) {
-            const float u = ((float)philox_first((unsigned)j, row0 + (unsigned)b, step, call, k0, k1) + 0.5f) * 2.3283064365386963e-10f;  // (0, 1]
+            const float u = ((float)philox_first((unsigned)j, row0 + (unsigned)brow, step, call, k0, k1) + 0.5f) * 2.3283064365386963e-10f;  // (0, 1]
             p = p / fmaxf(-logf(u), 1e-30f);
         }
         if (p > best) { best = p; bi = j; }
@@ -930,7 +960,7 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             const int ticket = __hip_atomic_fetch_add(adv.state + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ticket == (int)gridDim.x - 1) {
+            if (ticket == nrows - 1) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 *adv.widx += 1;
                 *adv.len += 1;
@@ -995,7 +1025,10 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream) {
     const int D = d->C / d->H;
     CCVS_REQUIRE(D == 64 || D == 32 || D == 16, "ccvs_gpt_decode_step: head dim %d unsupported (16, 32, 64)", D);
     CCVS_REQUIRE(d->temperature > 0.f, "ccvs_gpt_decode_step: bad temperature");
-    const size_t smem_att = (size_t)(16 + 8 * 256 + d->Tmax) * sizeof(float);
+    CCVS_REQUIRE(d->groups >= 0 && (d->groups <= 1 || d->B % d->groups == 0), "ccvs_gpt_decode_step: %d rows do not split into %d groups", d->B, d->groups);
+    CCVS_REQUIRE(d->B <= GEMM_DECODE_MAX_M, "ccvs_gpt_decode_step: at most %d rows per step", GEMM_DECODE_MAX_M);
+    const int grp_rows = d->groups > 1 ? d->B / d->groups : 0;   // 0: one group (widx / len / state are single words)
+    const size_t smem_att = (size_t)(16 + 4 * 256 + d->Tmax) * sizeof(float);
     const size_t smem_pick = (size_t)PICK_SMEM_WORDS(d->V) * sizeof(float);
     CCVS_REQUIRE(smem_att <= 64 * 1024, "ccvs_gpt_decode_step: sequence too long for the LDS score buffer");
     CCVS_REQUIRE(smem_pick <= 160 * 1024, "ccvs_gpt_decode_step: vocabulary %d too large", d->V);
@@ -1009,7 +1042,7 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream) {
     {   // embedding of the last picked token at row pos_off + *len
         const long total = (long)d->B * d->C;
         hipLaunchKernelGGL(gpt_embed_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, d->tok, 1L, (const int32_t*)nullptr, d->pos_off,
-                           (const int32_t*)d->len, 1, d->tok_emb, d->pos_table, d->x, total, d->C, d->vocab);
+                           (const int32_t*)d->len, grp_rows, 1, d->tok_emb, d->pos_table, d->x, total, d->C, d->vocab);
         CCVS_CHECK_LAUNCH("ccvs_gpt_decode_step(embed)");
     }
     float* ws_slabs = (float*)d->workspace;
@@ -1024,12 +1057,13 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream) {
         g.x = d->x; g.ldx = d->C; g.w = L.qkv_w; g.bias = L.qkv_b; g.y = d->q; g.ldy = d->C; g.M = d->B; g.N = 3 * d->C; g.K = d->C;
         g.ln_s = L.qkv_s; g.ln_eps = d->ln_eps;
         g.kcache = L.kcache; g.vcache = L.vcache; g.C = d->C; g.H = d->H; g.D = D; g.Tq = 1; g.Tmax = d->Tmax; g.pos0 = 0; g.pos_dev = d->len;
+        g.grp_rows = grp_rows;
         if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(qkv)")) != CCVS_OK) return rc;
         {   // attention over the cache
             const dim3 grid((unsigned)(d->B * d->H));
-            if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(512), smem_att, st, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, d->Tmax, scale);
-            else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(512), smem_att, st, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, d->Tmax, scale);
-            else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(512), smem_att, st, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, d->Tmax, scale);
+            if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(256), smem_att, st, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, grp_rows, d->Tmax, scale);
+            else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(256), smem_att, st, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, grp_rows, d->Tmax, scale);
+            else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(256), smem_att, st, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, grp_rows, d->Tmax, scale);
             CCVS_CHECK_LAUNCH("ccvs_gpt_decode_step(attention)");
         }
         g = Gemm16{};  // proj + residual (in place on x)
@@ -1054,7 +1088,7 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream) {
     {   // pick + bookkeeping
         Advance adv = {};
         adv.codes = d->codes; adv.codes_sB = (long)d->codes_sB; adv.widx = d->widx; adv.len = d->len;
-        adv.rng = (d->rng && !d->noise) ? 1 : 0; adv.state = d->state;
+        adv.rng = (d->rng && !d->noise) ? 1 : 0; adv.state = d->state; adv.grp_rows = grp_rows;
         hipLaunchKernelGGL(sample_topk_kernel, dim3(d->B), dim3(256), smem_pick, st, d->logits, (long)d->V, d->noise, d->tok, 1L, d->V,
                            d->top_k, d->temperature, adv);
         CCVS_CHECK_LAUNCH("ccvs_gpt_decode_step(pick)");

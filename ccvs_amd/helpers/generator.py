@@ -41,9 +41,8 @@ class Generator:
         self.timings = {}
         self.stft_model = None
         self.state_model = None
-        self._lanes, self._dec_stream, self._warm_lanes = None, None, set()
-        self._pipeline_primed = False
-        self.last_cu_limit, self.last_lanes = 0, 0
+        self._dec_stream, self._chains, self._warm_keys = None, [], set()
+        self.last_cu_limit, self.last_lanes, self.last_chains = 0, 0, 0
         for flag in ("layout", "deblurring"):
             if getattr(self.opt, flag, False):
                 raise NotImplementedError(f"--{flag} is not on the MI355X path (SURVEY 8f); --x_state / --x_stft [--keep_state] / --x_cat are")
@@ -249,49 +248,76 @@ class Generator:
         return out
 
     # ------------------------------------------------------------------ several batches in flight
-    def _token_lane(self, k):
-        """Token lane k: a Transformer wrapper that SHARES the parameters (and their packed forms) of self.transformer_model
-        but owns its KV cache, decode hipGraph, sampler state and stream, so that the token loops of different batches can
-        run at the same time.  Lane 0 is the model itself."""
+    def _seed_sampler_group(self, batch, iters, net_t):
+        """Sampler words of a token stage over the stacked rows of several batches (`iters`: their global iterations): one
+        (key, first global clip) pair per row group -- exactly the words each batch has when it runs alone."""
+        net_t.noise_key = [self.noise_key(i) for i in iters]
+        net_t.row_offset = [self.first_clip(batch)] * len(iters)
+        net_t.noise_call = 0
+
+    def _token_group_size(self, batch, lanes):
+        """Batches whose token loops run as ONE loop (`lanes`, capped): the stacked rows must fit one decode step (256 rows)
+        and be a few row blocks of the weight-stream GEMM at most (64 rows = one pass over the weights; more rows re-read them from
+        L2); host-drawn sampling noise is one generator stream per BATCH in the reference's order, so it is not stacked."""
+        opt = self.opt
+        if getattr(opt, "sample", False) and getattr(self.transformer_model, "sample_noise", "host") != "device":
+            return 1
+        if getattr(opt, "beam_size", None) is not None:
+            return 1
+        return max(1, min(int(lanes), 64 // max(batch, 1), 256 // max(batch, 1)))
+
+    def _token_chain(self, k):
+        """Token chain k: (Transformer, stream).  A chain runs one token group at a time; chains run beside each other.  Chain 0
+        is the model itself, the others are shallow copies that SHARE its parameters (and their packed forms) but own their
+        engine state -- KV caches, captured decode steps, sampler words."""
         import copy
-        if getattr(self, "_lanes", None) is None:
-            self._lanes = []
-        while len(self._lanes) <= k:
+        while len(self._chains) <= k:
             tr = self.transformer_model
-            if self._lanes:
+            if self._chains:
                 net = copy.copy(tr.net_t)                  # same Parameter objects / blocks, separate engine state
-                net._cache, net._graphs = None, {}
+                net.drop_engine_state()
                 lane = copy.copy(tr)
                 lane._modules = dict(tr._modules)
                 lane._modules["net_t"] = net
                 tr = lane
             dev = torch.device("cuda", torch.cuda.current_device())
             prio = int(os.environ.get("CCVS_PIPELINE_PRIORITIES", "-1,0").split(",")[0])
-            self._lanes.append((tr, torch.cuda.Stream(device=dev, priority=prio)))
-        return self._lanes[k]
+            self._chains.append((tr, torch.cuda.Stream(device=dev, priority=prio)))
+        return self._chains[k]
 
     @torch.no_grad()
-    def run_pipelined(self, batches, first_iter=0, cu_limit=None, finish=None, lanes=None):
+    def run_pipelined(self, batches, first_iter=0, cu_limit=None, finish=None, lanes=None, chains=None, ramp=None):
         """generate_vid over a sequence of batches with SEVERAL batches in flight on one GPU.  The token loop of a batch is a
-        latency-bound chain of ~120 small dependent launches per token that cannot fill the chip, the flow-guided decoder a
-        throughput-bound stream of large MFMA / HBM kernels: while stream D encodes and decodes batch i, the token loops of
-        batches i+1 .. i+L run on L high-priority streams ("lanes": shared weights, one KV cache and one captured decode
-        step each).  Per batch the work is exactly generate_vid's -- encode, crop, token synthesis, decode -- and so are
-        the results (same kernels, same per-clip noise; tests/test_pipeline_gpu.py checks bit-equality with the serial
-        schedule).
+        latency-bound chain of ~120 small dependent launches per token that streams every GPT weight once per token and cannot
+        fill the chip; the flow-guided decoder is a throughput-bound stream of large MFMA / HBM kernels.  So
 
-        `cu_limit` > 0 caps everything on D to that many CUs (`ccvs_stream_cu_limit`) while token loops are in flight, so
-        that their few-hundred-workgroup launches always find free CUs; it pays with ONE lane (the token loop is then the
-        longer stage), not with several (the decoder is), hence the default 0.
-        Every token stage is enqueued by its own worker thread: a hipGraph launch blocks the calling thread once the
-        stream's queue is full (a few dozen decode steps), and neither the decoder's launches nor the other lanes' may
-        wait behind that.  A lane runs one token stage at a time, batches take the lanes round-robin and are decoded in
-        order.  The very first batch of a Generator's first call runs alone (encode, tokens, decode from this thread, then
-        a wait): nothing is launched for the first time while a second thread is launching.
+          * the token loops of `lanes` consecutive batches run as ONE loop over their stacked rows ("token group": one KV cache
+            of lanes x B rows, one captured decode step, per-group sampler words -- `ccvs_gpt_decode.groups`): the weights are
+            streamed once per token for all of them instead of once per batch;
+          * `chains` such loops run beside each other on high-priority streams, each fed by its own worker thread (beside the
+            decoder a dependent launch waits longer for its memory: independent chains hide each other's latency);
+          * meanwhile stream D decodes the batches of the finished groups, in order, and encodes those of the groups to come
+            (chains + 1 groups ahead, so that a chain never waits for its encoder behind a decoder).
+        `ramp`: sizes of the first groups (e.g. (1, 2): the decoder gets its first batch after one short token stage instead
+        of idling through a full one); then every group has `lanes` batches.
+
+        Per batch the work is exactly generate_vid's -- encode, crop, token synthesis, decode -- and so are the results: a
+        row's arithmetic does not depend on the rows it shares a launch with and every batch keeps its own sampler words
+        (tests/test_pipeline_gpu.py checks bit-equality with the serial schedule).
+
+        `cu_limit` > 0 caps everything on D to that many CUs (`ccvs_stream_cu_limit`) while a token loop is in flight
+        (default 0).  A token stage is enqueued by a worker thread because a hipGraph launch blocks its caller once the
+        stream's queue is a few dozen steps deep, and the decoder's launches must not wait behind that.  Whenever a token
+        stage would have to capture its decode step (first use of a chain with a group size, changed weights or sampler),
+        the capture is done up front from this thread before the workers start (`warm_up`): graph capture and first-time
+        launches never race with launches of another thread, none falls into the steady state.  Every wait on a worker has a time
+        limit (`CCVS_PIPELINE_TIMEOUT`, 600 s) and raises with the stage and batches it was waiting for, after dumping every
+        thread's stack: the schedule cannot hang silently.
 
         batches: iterable of data dicts.  finish(i, out) -> anything: called on stream D when batch i's clip is decoded
         (pack / all-gather); its return values are collected.  Returns the list of per-batch results
         ({"fake", "enc_code", "finished", "index"}); the rec pass is not run here."""
+        import queue
         import threading
         from collections import deque
         opt = self.opt
@@ -299,152 +325,234 @@ class Generator:
             raise NotImplementedError("run_pipelined covers the plain synthesis schedule (use generate_vid for step_by_step / rec_only)")
         dev = torch.device("cuda", torch.cuda.current_device())
         if lanes is None:
-            lanes = int(os.environ.get("CCVS_PIPELINE_LANES", "3"))   # measured best on MI355X at BAIR size (2: -6 %, 4: -17 %)
+            lanes = int(os.environ.get("CCVS_PIPELINE_LANES", "3"))
+        if chains is None:
+            chains = int(os.environ.get("CCVS_PIPELINE_CHAINS", "2"))
+        if ramp is None:
+            ramp = tuple(int(v) for v in os.environ.get("CCVS_PIPELINE_RAMP", "").split(",") if v)
+        chains = max(1, chains)
         if getattr(self, "_dec_stream", None) is None:
             prio = [int(v) for v in os.environ.get("CCVS_PIPELINE_PRIORITIES", "-1,0").split(",")]   # (token streams, decode stream)
             self._dec_stream = torch.cuda.Stream(device=dev, priority=prio[1])
         s_dec = self._dec_stream
-        lane_list = [self._token_lane(k) for k in range(lanes)]
-        if cu_limit is None:   # 0 = no budget: with several lanes the decoder is the longer stage and any cap costs throughput
+        chain_list = [self._token_chain(k) for k in range(chains)]
+        if cu_limit is None:   # 0 = no budget
             cu_limit = int(os.environ.get("CCVS_PIPELINE_CU_LIMIT", "0"))
-        self.last_cu_limit, self.last_lanes = cu_limit, lanes
+        timeout = float(os.environ.get("CCVS_PIPELINE_TIMEOUT", "600"))
         entry = torch.cuda.current_stream()
         s_dec.wait_stream(entry)
-        for _, st in lane_list:
+        for _, st in chain_list:
             st.wait_stream(entry)
         results, timings = [], []
         it = iter(batches)
+        held = []         # a batch read ahead that did not fit its group (ragged size): first of the next group
         index = first_iter
+        n_groups = 0
         debug = os.environ.get("CCVS_PIPELINE_DEBUG", "0") == "1"
+        queues = [queue.Queue() for _ in range(chains)]
+        self.last_cu_limit, self.last_lanes, self.last_chains = cu_limit, lanes, chains
 
         def budget(n):   # CU budget of everything submitted to the decode stream from now on
             ops.stream_cu_limit(s_dec, n)
 
-        def start(data, i, lane):
-            """encode + crop on D; returns the job of batch i (its token stage is opened by `launch_tokens`)."""
-            ev = {k: torch.cuda.Event(enable_timing=True) for k in ("e0", "e1", "t0", "t1", "d0", "d1")}
-            with torch.cuda.stream(s_dec):
-                ev["e0"].record()
-                ws = self.condition(data)
-                ev["e1"].record()
-            for t in (ws["cropped"]["code"], ws["cropped"].get("cond_code"), ws["cropped"].get("state_code")):
-                if torch.is_tensor(t) and t.is_cuda:
-                    t.record_stream(lane_list[lane][1])
-            return {"i": i, "ws": ws, "ev": ev, "codes": None, "error": None, "thread": None, "batch": data["vid"].shape[0], "lane": lane}
+        def capture_key(chain, rows, groups):
+            """What a captured decode step depends on (the cache length follows from the options): such a key is warmed once."""
+            net = chain_list[chain][0].net_t
+            ver = sum(p_._version for p_ in net.parameters())
+            return (chain, rows, groups, opt.vid_len, opt.z_len, opt.cond_len, bool(opt.p2p), bool(opt.sample), opt.top_k, float(opt.temperature),
+                    chain_list[chain][0].sample_noise, ver)
 
-        def token_stage(job):
-            tr, s_tok = lane_list[job["lane"]]
-            try:
-                torch.cuda.set_device(dev)
-                with torch.cuda.stream(s_tok), torch.no_grad():
-                    s_tok.wait_event(job["ev"]["e1"])
-                    self._seed_sampler(job["batch"], job["i"], tr.net_t)
-                    job["ev"]["t0"].record()
-                    job["codes"] = tr(job["ws"]["cropped"], mode='inference', total_len=job["ws"]["total_len"])
-                    job["ev"]["t1"].record()
-            except BaseException as exc:   # re-raised by the main thread at the join
-                job["error"] = exc
-
-        def launch_tokens(job):
-            cold = [k for k in range(lanes) if k not in self._warm_lanes]
-            if cold:
-                # First use of a lane: its decode step is captured into a hipGraph, which must not race with HIP calls of other
-                # threads -- run the stage in this thread.  All cold lanes are warmed on THIS job (the others' result is
-                # discarded), so that a short warm-up phase covers every lane.
-                for k in cold:
-                    if k != job["lane"]:
-                        warm = dict(job, lane=k)
-                        token_stage(warm)
-                        if warm["error"] is not None:
-                            raise warm["error"]
-                        self._warm_lanes.add(k)
-                if job["lane"] in cold:
-                    token_stage(job)
-                    self._warm_lanes.add(job["lane"])
+        def worker(chain):
+            tr, s_tok = chain_list[chain]
+            torch.cuda.set_device(dev)
+            while True:
+                job = queues[chain].get()
+                if job is None:
                     return
-            job["thread"] = threading.Thread(target=token_stage, args=(job,), name=f"ccvs-tokens-{job['i']}")
-            job["thread"].start()
+                try:
+                    with torch.cuda.stream(s_tok), torch.no_grad():
+                        s_tok.wait_event(job["enc_done"])
+                        members = job["members"]
+                        tok_in = stack_inputs([m["ws"]["cropped"] for m in members])
+                        self._seed_sampler_group(job["batch"], [m["i"] for m in members], tr.net_t)
+                        job["t0"].record()
+                        out = tr(tok_in, mode='inference', total_len=job["total_len"])
+                        job["t1"].record()
+                        job["codes"] = out
+                except BaseException as exc:   # re-raised by the main thread when it collects the job
+                    job["error"] = exc
+                finally:
+                    tr.net_t.noise_key, tr.net_t.row_offset = None, 0
+                    job["done"].set()
 
-        def join_tokens(job):
-            if job["thread"] is not None:
-                job["thread"].join()
-                job["thread"] = None
+        def wait_job(job, what):
+            if not job["done"].wait(timeout):
+                import faulthandler
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                raise RuntimeError(f"run_pipelined: {what} of batches {[m['i'] for m in job['members']]} (chain {job['chain']}) was not enqueued within "
+                                   f"{timeout:.0f} s (stacks of all threads are on stderr)")
             if job["error"] is not None:
                 raise job["error"]
 
-        pending = deque()                 # jobs whose tokens are in flight / done, oldest first
-        lane_job = [None] * lanes         # last job given to each lane
-        n_started = 0
-        try:
-            while True:
-                t_round = time.perf_counter()
-                data = next(it, None)
-                if data is not None:
-                    lane = n_started % lanes
-                    budget(cu_limit if pending else 0)
-                    job = start(data, index, lane)
-                    index += 1
-                    n_started += 1
-                    if lane_job[lane] is not None:
-                        join_tokens(lane_job[lane])                 # all of its steps are enqueued: the lane's engine is free
-                    lane_job[lane] = job
-                    launch_tokens(job)
-                    pending.append(job)
-                    if len(pending) <= lanes and self._pipeline_primed:
-                        continue                                    # fill the lanes before the first decode
-                elif not pending:
+        def submit_group():
+            """Encode + crop the next group's batches on D and queue their token stage; None when the input is exhausted."""
+            nonlocal index, n_groups
+            members = []
+            group = None
+            while group is None or len(members) < group:
+                data = held.pop() if held else next(it, None)
+                if data is None:
                     break
-                t_enc = time.perf_counter()
+                if group is None:
+                    want = ramp[n_groups] if n_groups < len(ramp) else lanes
+                    group = self._token_group_size(data["vid"].shape[0], min(want, lanes))
+                elif data["vid"].shape[0] != members[0]["batch"]:
+                    held.append(data)         # a ragged batch starts the next group
+                    break
+                chain = n_groups % chains
+                ev = {k: torch.cuda.Event(enable_timing=True) for k in ("e0", "e1", "d0", "d1")}
+                with torch.cuda.stream(s_dec):
+                    ev["e0"].record()
+                    ws = self.condition(data)
+                    ev["e1"].record()
+                for t in (ws["cropped"]["code"], ws["cropped"].get("cond_code"), ws["cropped"].get("state_code")):
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(chain_list[chain][1])
+                members.append({"i": index, "ws": ws, "ev": ev, "batch": data["vid"].shape[0]})
+                index += 1
+            if not members:
+                return None
+            if any(m["ws"]["total_len"] != members[0]["ws"]["total_len"] for m in members):
+                raise RuntimeError("run_pipelined: the batches of a token group must share total_len")
+            chain = n_groups % chains
+            n_groups += 1
+            job = {"members": members, "batch": members[0]["batch"], "total_len": members[0]["ws"]["total_len"], "chain": chain,
+                   "enc_done": members[-1]["ev"]["e1"], "t0": torch.cuda.Event(enable_timing=True), "t1": torch.cuda.Event(enable_timing=True),
+                   "codes": None, "error": None, "done": threading.Event()}
+            queues[chain].put(job)
+            return job
+
+        def stack_inputs(cropped):
+            tok_in = {}
+            for key in ("code", "cond_code", "state_code", "vid_lbl", "delta_length_cond"):
+                if key in cropped[0]:
+                    tok_in[key] = cropped[0][key] if len(cropped) == 1 else torch.cat([c[key] for c in cropped], dim=0)
+            return tok_in
+
+        def warm_up():
+            """Capture the decode step of every (chain, group size) this run can use that is not captured yet, from this thread,
+            before any worker exists: first-time launches and graph captures never race with another thread's launches, and
+            no capture falls into the steady state.  The first batch is encoded once more for it; results are discarded."""
+            first = next(it, None)
+            if first is None:
+                return
+            held.append(first)
+            nb = first["vid"].shape[0]
+            sizes = sorted({self._token_group_size(nb, g) for g in range(1, lanes + 1)})
+            cold = [(c, g) for c in range(chains) for g in sizes if capture_key(c, nb * g, g) not in self._warm_keys]
+            if not cold:
+                return
+            with torch.cuda.stream(s_dec):
+                ws = self.condition({k: (v.clone() if torch.is_tensor(v) else v) for k, v in first.items()})
+            for c, g in cold:
+                tr, s_tok = chain_list[c]
+                s_tok.wait_stream(s_dec)
+                with torch.cuda.stream(s_tok):
+                    self._seed_sampler_group(nb, list(range(g)), tr.net_t)
+                    tr.net_t.warm_only = True
+                    try:
+                        tr(stack_inputs([ws["cropped"]] * g), mode='inference', total_len=ws["total_len"])
+                    finally:
+                        tr.net_t.warm_only = False
+                        tr.net_t.noise_key, tr.net_t.row_offset = None, 0
+                s_tok.synchronize()
+                self._warm_keys.add(capture_key(c, nb * g, g))
+            s_dec.wait_stream(s_tok)
+
+        warm_up()
+        threads = [threading.Thread(target=worker, args=(k,), name=f"ccvs-token-chain-{k}", daemon=True) for k in range(chains)]
+        for th in threads:
+            th.start()
+        pending = deque()
+        try:
+            for _ in range(chains + 1):
+                job = submit_group()
+                if job is not None:
+                    pending.append(job)
+            while pending:
+                t_round = time.perf_counter()
                 cur = pending.popleft()
-                join_tokens(cur)
+                wait_job(cur, "the token stage")
                 t_join = time.perf_counter()
-                s_dec.wait_event(cur["ev"]["t1"])
+                nxt = submit_group()
+                if nxt is not None:
+                    pending.append(nxt)
+                s_dec.wait_event(cur["t1"])
                 codes = cur["codes"]
-                state_code = codes.get("state_code")
-                if state_code is not None and 0 in state_code.size():
-                    state_code = None
-                for t in (codes["code"], state_code):
+                state_all = codes.get("state_code")
+                if state_all is not None and 0 in state_all.size():
+                    state_all = None
+                for t in (codes["code"], state_all):
                     if torch.is_tensor(t):
                         t.record_stream(s_dec)
-                budget(cu_limit if pending else 0)
-                with torch.cuda.stream(s_dec):
-                    cur["ev"]["d0"].record()
-                    fake = self.decode_codes(cur["ws"], codes["code"], state_code)
-                    cur["ev"]["d1"].record()
-                    done = finish(cur["i"], fake) if finish is not None else None
-                    for t in (fake["vid"], fake["code"]):   # handed to the caller's stream
-                        t.record_stream(entry)
+                nb = cur["batch"]
+                for k, m in enumerate(cur["members"]):
+                    budget(cu_limit if pending else 0)
+                    code = codes["code"][k * nb:(k + 1) * nb]
+                    state_code = state_all[k * nb:(k + 1) * nb] if state_all is not None else None
+                    with torch.cuda.stream(s_dec):
+                        m["ev"]["d0"].record()
+                        fake = self.decode_codes(m["ws"], code, state_code)
+                        m["ev"]["d1"].record()
+                        done = finish(m["i"], fake) if finish is not None else None
+                        for t in (fake["vid"], fake["code"]):   # handed to the caller's stream
+                            t.record_stream(entry)
+                    results.append({"fake": fake, "enc_code": m["ws"]["encoded"]["code"], "finished": done, "index": m["i"]})
+                    timings.append(dict(m["ev"], t0=cur["t0"], t1=cur["t1"], group=len(cur["members"])))
+                    m["ws"] = None
                 if debug:
-                    print(f"[pipeline] batch {cur['i']}: host ms -- encode(next) enqueue {1e3 * (t_enc - t_round):.0f}, wait for its token stage to be "
-                          f"enqueued {1e3 * (t_join - t_enc):.0f}, decode enqueue {1e3 * (time.perf_counter() - t_join):.0f}", file=sys.stderr, flush=True)
-                results.append({"fake": fake, "enc_code": cur["ws"]["encoded"]["code"], "finished": done, "index": cur["i"]})
-                timings.append(cur["ev"])
-                cur["ws"] = None
-                if not self._pipeline_primed:
-                    # The very first batch of this Generator ran alone, enqueued by this thread, and is waited for here:
-                    # every kernel of the path has been launched once (code objects loaded, function attributes and the
-                    # library's lazily built tables set, graphs captured) before a second host thread starts launching.
-                    s_dec.synchronize()
-                    self._pipeline_primed = True
+                    print(f"[pipeline] batches {[m['i'] for m in cur['members']]} (chain {cur['chain']}): host ms -- wait for the token stage to be "
+                          f"enqueued {1e3 * (t_join - t_round):.0f}, encode(next group) + decode enqueue {1e3 * (time.perf_counter() - t_join):.0f}",
+                          file=sys.stderr, flush=True)
         finally:
-            for job in list(pending) + [j for j in lane_job if j is not None]:
-                if job.get("thread") is not None and job["thread"].is_alive():
-                    job["thread"].join()
+            for q_ in queues:
+                q_.put(None)
+            for th in threads:
+                th.join(timeout)
             budget(0)
         entry.wait_stream(s_dec)
-        for _, st in lane_list:
+        for _, st in chain_list:
             entry.wait_stream(st)
         self._pipeline_events = timings
         return results
 
     def pipeline_stage_ms(self):
-        """Per-batch encode / transformer / decode milliseconds of the last run_pipelined (they overlap in time)."""
+        """Encode / transformer / decode milliseconds of the last run_pipelined, summed over its batches (the stages overlap in
+        time).  A token stage serves the `group` batches of its token group at once: each is charged 1 / group of it."""
         torch.cuda.synchronize()
         out = {"encode": 0.0, "transformer": 0.0, "decode": 0.0}
         for ev in self._pipeline_events:
             out["encode"] += ev["e0"].elapsed_time(ev["e1"])
-            out["transformer"] += ev["t0"].elapsed_time(ev["t1"])
+            out["transformer"] += ev["t0"].elapsed_time(ev["t1"]) / ev["group"]
             out["decode"] += ev["d0"].elapsed_time(ev["d1"])
+        return out
+
+    def pipeline_timeline(self):
+        """Per batch of the last run_pipelined: milliseconds since the first encode started at which its encode, token stage and
+        decode began and ended (HIP events on the stages' own streams) -- where the schedule's bubbles are."""
+        torch.cuda.synchronize()
+        base = self._pipeline_events[0]["e0"]
+        return [{k: round(base.elapsed_time(ev[k]), 1) for k in ("e0", "e1", "t0", "t1", "d0", "d1")} | {"group": ev["group"]}
+                for ev in self._pipeline_events]
+
+    def pipeline_token_groups(self):
+        """[(batches in the group, milliseconds of its token stage)] of the last run_pipelined, one entry per token group."""
+        torch.cuda.synchronize()
+        seen, out = set(), []
+        for ev in self._pipeline_events:
+            if id(ev["t0"]) not in seen:
+                seen.add(id(ev["t0"]))
+                out.append((ev["group"], ev["t0"].elapsed_time(ev["t1"])))
         return out
 
     def _step_by_step(self, data, cropped, crop_prop, total_len, cond_len):
@@ -522,9 +630,7 @@ def save_video_batch(vid, bs, global_iter, path, fps, normalize, imagenet_norm, 
     if is_layout:
         raise NotImplementedError("layout colour maps are not on the MI355X path (SURVEY 8f)")
     if normalize and imagenet_norm:
-        mean = torch.tensor([0.485, 0.456, 0.406], device=vid.device).view(1, 1, 3, 1, 1)
-        std = torch.tensor([0.229, 0.224, 0.225], device=vid.device).view(1, 1, 3, 1, 1)
-        u8 = ops.pack_u8((vid * std + mean).contiguous(), 0.0, 1.0)
+        u8 = ops.pack_u8_norm(vid, (0.229, 0.224, 0.225), (0.485, 0.456, 0.406))   # generator.py:303-305, same op order
     elif normalize:
         u8 = ops.pack_u8(vid.contiguous(), float(span[0]), float(span[1]))
     else:

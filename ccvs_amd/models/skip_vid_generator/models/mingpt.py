@@ -145,32 +145,71 @@ class GPT(nn.Module):
         self.block_size = config.block_size + (1 if config.use_start_token else 0) + (1 if config.use_lbl else 0)   # mingpt.py:171
         self.apply(self._init_weights)
         self.config = config
-        self._cache = None
-        self._graphs = {}
+        self._cache = None      # the engine state in use: one of `_caches`
+        self._caches = {}       # per batch size (a group of several generation batches is one more batch size)
         # in-kernel sampling noise (Philox): key words, global index of batch row 0 and a per-call counter.  `noise_key`
         # None draws a fresh key from torch's generator per call (honours torch.manual_seed); the Generator sets a key
         # derived from (seed, iteration) plus the rank's first clip, so sampled tokens do not depend on the world size.
+        # ROW GROUPS: when the batch is the rows of several generation batches stacked (`Generator.run_pipelined`: one
+        # token loop, i.e. one pass over the weights per token, for all of them), `noise_key` and `row_offset` are lists with
+        # one entry per group of `batch / len(list)` consecutive rows: every batch keeps the words it has when run alone.
         self.noise_key = None
         self.row_offset = 0
         self.noise_call = 0
+        # warm_only: the decode steps of a call are CAPTURED (KV cache allocated, descriptor built, hipGraphs recorded) but not
+        # replayed -- `Generator.run_pipelined` prepares every (token chain, group size) this way before its worker threads start
+        self.warm_only = False
+
+    @property
+    def _graphs(self):
+        return self._cache["graphs"]
+
+    def n_groups(self):
+        """Row groups of the next call (1 unless the Generator stacked several batches)."""
+        return len(self.noise_key) if isinstance(self.noise_key, list) else 1
+
+    def drop_engine_state(self):
+        """Free every KV cache / captured decode step (they are rebuilt on the next call)."""
+        self._cache, self._caches = None, {}
 
     def _philox_words(self):
-        """(key0, key1, row0, call) of this generate() call."""
+        """[(key0, key1, row0, call)] of this generate() call, one tuple per row group."""
         if self.noise_key is None:
             k = torch.randint(0, 2**32, (2,), dtype=torch.int64).tolist()
-            return int(k[0]), int(k[1]), int(self.row_offset), 0
+            return [(int(k[0]), int(k[1]), int(self.row_offset), 0)]
         call = self.noise_call
         self.noise_call += 1
-        return int(self.noise_key[0]) & 0xffffffff, int(self.noise_key[1]) & 0xffffffff, int(self.row_offset), call
+        if isinstance(self.noise_key, list):
+            assert isinstance(self.row_offset, list) and len(self.row_offset) == len(self.noise_key)
+            return [(int(k[0]) & 0xffffffff, int(k[1]) & 0xffffffff, int(r), call) for k, r in zip(self.noise_key, self.row_offset)]
+        return [(int(self.noise_key[0]) & 0xffffffff, int(self.noise_key[1]) & 0xffffffff, int(self.row_offset), call)]
 
     def _set_decode_state(self, words):
-        """Device-resident `state` of ccvs_gpt_decode: counters zeroed, Philox words in place (one upload)."""
-        st = torch.zeros(8, dtype=torch.int64)
+        """Device-resident `state` of ccvs_gpt_decode ([groups][8]): counters zeroed, Philox words in place (one upload)."""
+        c = self._cache
+        st = torch.zeros(c["G"], 8, dtype=torch.int64)
         if words is not None:
-            k0, k1, row0, call = words
-            st[3], st[4], st[5], st[6] = call, k0, k1, row0
+            assert len(words) == c["G"], (len(words), c["G"])
+            for g, (k0, k1, row0, call) in enumerate(words):
+                st[g, 3], st[g, 4], st[g, 5], st[g, 6] = call, k0, k1, row0
         st = torch.where(st >= 2**31, st - 2**32, st).to(torch.int32)
-        self._cache["state"].copy_(st, non_blocking=True)
+        c["state"].copy_(st, non_blocking=True)
+
+    def _pick(self, logits, sampler, noise, out, words, step):
+        """One eager pick for all rows: `ops.sample_topk` per row group when the noise is drawn in the kernel (each group has
+        its own Philox words `words[g]`; `step` = (step word, call-word mask))."""
+        if words is None:
+            return ops.sample_topk(logits, sampler["top_k"], sampler["temperature"], noise=noise, out=out)
+        b = logits.shape[0]
+        n = len(words)
+        assert b % n == 0
+        per = b // n
+        if out is None:
+            out = torch.empty(b, dtype=torch.int64, device=logits.device)
+        for g, (k0, k1, row0, call) in enumerate(words):
+            ops.sample_topk(logits[g * per:(g + 1) * per], sampler["top_k"], sampler["temperature"], out=out[g * per:(g + 1) * per],
+                            philox=(k0, k1, row0, step[0], call | step[1]))
+        return out
 
     def get_block_size(self):
         return self.block_size
@@ -294,25 +333,30 @@ class GPT(nn.Module):
             assert max_len <= self.block_size, "Cannot forward, model block size is exhausted."  # mingpt.py:299
         dev = self.tok_emb.weight.device
         d = cfg.n_embd // cfg.n_head
-        c = self._cache
-        if c is None or c["B"] != batch or c["T"] < max_len or c["dev"] != dev:
-            self._graphs = {}  # captured graphs hold the old buffers
+        groups = self.n_groups()
+        assert batch % groups == 0, f"{batch} rows do not split into {groups} row groups"
+        c = self._caches.get(batch)
+        if c is None or c["T"] < max_len or c["dev"] != dev or c["G"] != groups:
+            # (captured graphs live in the cache dict: they go with the buffers they hold)
+            if c is None and len(self._caches) >= 8:
+                self._caches.pop(next(iter(self._caches)))   # a handful of batch sizes at most: drop the oldest
             C, V = cfg.n_embd, self.head.weight.shape[0]
             f32 = dict(dtype=torch.float32, device=dev)
             kc = [torch.empty(batch, cfg.n_head, max_len, d, **f32) for _ in range(cfg.n_layer)]
             vc = [torch.empty(batch, cfg.n_head, max_len, d, **f32) for _ in range(cfg.n_layer)]
-            c = self._cache = {
-                "B": batch, "T": max_len, "dev": dev, "k": kc, "v": vc,
-                "len_dev": torch.zeros(1, dtype=torch.int32, device=dev),      # cache positions filled
-                "widx": torch.zeros(1, dtype=torch.int32, device=dev),         # column of `codes` the next token goes to
+            c = self._caches[batch] = {
+                "B": batch, "G": groups, "T": max_len, "dev": dev, "k": kc, "v": vc,
+                "len_dev": torch.zeros(groups, dtype=torch.int32, device=dev),  # cache positions filled, per row group (they advance together)
+                "widx": torch.zeros(groups, dtype=torch.int32, device=dev),     # column of `codes` the next token goes to
                 "tok": torch.zeros(batch, 1, dtype=torch.int64, device=dev),   # last sampled token
                 "codes": torch.zeros(batch, max_len, dtype=torch.int64, device=dev),
                 # scratch of ccvs_gpt_decode_step
                 "x": torch.empty(batch, C, **f32), "q": torch.empty(batch, C, **f32), "att": torch.empty(batch, C, **f32),
                 "h": torch.empty(batch, 4 * C, **f32), "logits": torch.empty(batch, V, **f32), "noise": torch.empty(batch, V, **f32),
-                "state": torch.zeros(8, dtype=torch.int32, device=dev),    # [0] steps done, [4..5] Philox key (ccvs_hip.h)
-                "desc": None,
+                "state": torch.zeros(groups, 8, dtype=torch.int32, device=dev),    # per group: [0] steps done, [4..5] Philox key (ccvs_hip.h)
+                "desc": None, "graphs": {},
             }
+        self._cache = c
         c["len"] = 0
         c["stream"] = bool(stream)
         if stream:
@@ -324,7 +368,7 @@ class GPT(nn.Module):
             c["pos_table"].copy_(table)   # same storage: captured graphs keep pointing at it
         else:
             c["pos_table"] = table.contiguous().clone()
-            c["desc"], self._graphs = None, {}
+            c["desc"], c["graphs"] = None, {}
         c["frame_pos0"] = 0
         return c
 
@@ -458,20 +502,21 @@ class GPT(nn.Module):
                                    fc_w=fw, fc_b=fb, fc_s=fs, fc2_w=blk.mlp[3].weight, fc2_b=blk.mlp[3].bias,
                                    kcache=c["k"][i], vcache=c["v"][i]))
             desc = ops.GptDecodeStep(
-                layers, B=c["B"], C=cfg.n_embd, H=cfg.n_head, Tmax=c["T"], ln_eps=self.ln_f.eps,
+                layers, B=c["B"], groups=c["G"], C=cfg.n_embd, H=cfg.n_head, Tmax=c["T"], ln_eps=self.ln_f.eps,
                 tok_emb=self._token_table(), pos_table=c["pos_table"], pos_off=-c["frame_pos0"], head=(hw, hb, hs),
                 tok=c["tok"], codes=c["codes"], widx=c["widx"], length=c["len_dev"],
                 x=c["x"], q=c["q"], att=c["att"], h=c["h"], logits=c["logits"],
                 noise=c["noise"] if (sampler["sample"] and not device_rng) else None, rng=device_rng,
                 top_k=sampler["top_k"], temperature=sampler["temperature"], state=c["state"])
             c["desc"] = (key, desc)
-            self._graphs = {}   # captured graphs replay the OLD descriptor's pointers (packed weights are freed with it)
+            c["graphs"] = {}   # captured graphs replay the OLD descriptor's pointers (packed weights are freed with it)
         return c["desc"][1]
 
-    def _emit(self, logits, sampler, noise, col, philox=None):
-        """Pick the next token from `logits` into c['tok'] and store it in column `col` of c['codes']."""
+    def _emit(self, logits, sampler, noise, col, words=None, step=None):
+        """Pick the next token from `logits` into c['tok'] and store it in column `col` of c['codes'] (`words`, `step`: in-kernel
+        noise, see `_pick`)."""
         c = self._cache
-        ops.sample_topk(logits, sampler["top_k"], sampler["temperature"], noise=noise, out=c["tok"], philox=philox)
+        self._pick(logits, sampler, noise, c["tok"].view(-1), words, step)
         c["codes"][:, col] = c["tok"][:, 0]
         c["widx"].fill_(col + 1)
 
@@ -494,6 +539,10 @@ class GPT(nn.Module):
         several steps is just the step captured several times; it costs the host 1/GRAPH_STEPS of the launches -- the token
         stages of several batches are enqueued by concurrent host threads) and of the one-step graph for the remainder."""
         k = self.GRAPH_STEPS
+        if self.warm_only:
+            self._decode_graph(sampler, key + (k,), steps=k)
+            self._decode_graph(sampler, key)
+            return
         if n >= 2 * k:
             long_graph = self._decode_graph(sampler, key + (k,), steps=k)
             for _ in range(n // k):
@@ -583,14 +632,14 @@ class GPT(nn.Module):
             return torch.cat(cols, dim=1)
 
         def draw(kind, width, pick):
-            """(noise, philox) of eager pick number `pick`: in-kernel Philox with the call word's top bit set (the captured
+            """(noise, words, step) of eager pick number `pick`: in-kernel Philox with the call word's top bit set (the captured
             steps use the plain call word and their own step counter), or host noise."""
             smp = state_sampler if kind else sampler
             if not smp["sample"]:
-                return None, None
+                return None, None, None
             if device_noise:
-                return None, (words[0], words[1], words[2], pick, words[3] | 0x80000000)
-            return host_noise(b, width).to(dev, non_blocking=True), None
+                return None, words, (pick, 0x80000000)
+            return host_noise(b, width).to(dev, non_blocking=True), None, None
 
         logits = self.prefill(self._stream_rows(code, state_code), cond_idx, delta_length_cond)
         fed = slen(n_code, n_state)
@@ -617,15 +666,15 @@ class GPT(nn.Module):
                 lg = logits[:, :state_sampler["vocab"]].contiguous()
                 if trace is not None:
                     trace.append(lg.clone())
-                nz, ph = draw(1, lg.shape[1], i)
-                tok = ops.sample_topk(lg, state_sampler["top_k"], state_sampler["temperature"], noise=nz, philox=ph)
+                nz, wd, stp = draw(1, lg.shape[1], i)
+                tok = self._pick(lg, state_sampler, nz, None, wd, stp)
                 state_buf[:, n_state] = tok
                 n_state += 1
             else:
                 if trace is not None:
                     trace.append(logits.clone())
-                nz, ph = draw(0, logits.shape[1], i)
-                ops.sample_topk(logits, sampler["top_k"], sampler["temperature"], noise=nz, out=c["tok"], philox=ph)
+                nz, wd, stp = draw(0, logits.shape[1], i)
+                self._pick(logits, sampler, nz, c["tok"].view(-1), wd, stp)
                 frame_codes[:, n_code] = c["tok"][:, 0]
                 n_code += 1
             i += 1
@@ -664,13 +713,13 @@ class GPT(nn.Module):
             lg = logits[:, :state_sampler["vocab"]].contiguous() if is_state else logits
             if trace is not None:
                 trace.append(lg.clone())
-            nz, ph = None, None
+            nz, wd, stp = None, None, None
             if smp["sample"]:
                 if device_noise:
-                    ph = (words[0], words[1], words[2], i, words[3] | 0x80000000)
+                    wd, stp = words, (i, 0x80000000)
                 else:
                     nz = host_noise(b, lg.shape[1]).to(dev, non_blocking=True)
-            tok = ops.sample_topk(lg, smp["top_k"], smp["temperature"], noise=nz, philox=ph).view(b, 1).to(torch.int64)
+            tok = self._pick(lg, smp, nz, None, wd, stp).view(b, 1).to(torch.int64)
             if is_state:
                 state_code = torch.cat((state_code, tok), dim=1)
             else:
@@ -710,7 +759,7 @@ class GPT(nn.Module):
         c["len_dev"].fill_(n_pre + n_cond + t0)
         self._set_decode_state(words)     # the step counter (a Philox counter word) restarts with the call
         if device_rng:                    # first pick: step word 0xffffffff (the decode steps count 0, 1, ...)
-            self._emit(logits, sampler, None, t0, philox=(words[0], words[1], words[2], 0xffffffff, words[3]))
+            self._emit(logits, sampler, None, t0, words=words, step=(0xffffffff, 0))
         else:
             self._emit(logits, sampler, host_noise(b, logits.shape[1]).to(logits.device, non_blocking=True) if sample else None, t0)
 

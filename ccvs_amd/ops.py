@@ -549,7 +549,7 @@ class GptDecodeStep:
     `launch()` enqueues one whole decode step on the current stream."""
 
     def __init__(self, layers, B, C, H, Tmax, ln_eps, tok_emb, pos_table, pos_off, head, tok, codes, widx, length,
-                 x, q, att, h, logits, noise, top_k, temperature, state, rng=False):
+                 x, q, att, h, logits, noise, top_k, temperature, state, rng=False, groups=1):
         hw, hb, hs = head
         keep = [tok_emb, pos_table, hw, hb, hs, tok, codes, widx, length, x, q, att, h, logits, noise, state]
         for t in keep:
@@ -558,7 +558,9 @@ class GptDecodeStep:
         f32 = [tok_emb, pos_table, hw, hb, hs, x, q, att, h, logits] + ([noise] if noise is not None else [])
         assert all(t.dtype == torch.float32 and t.is_contiguous() for t in f32)
         assert tok.dtype == torch.int64 and tok.numel() == B and tok.is_contiguous() and codes.dtype == torch.int64 and codes.stride(1) == 1
-        assert widx.dtype == torch.int32 and length.dtype == torch.int32 and state.dtype == torch.int32 and state.numel() >= 8
+        assert widx.dtype == torch.int32 and length.dtype == torch.int32 and state.dtype == torch.int32
+        assert groups >= 1 and B % groups == 0 and widx.numel() == groups and length.numel() == groups and state.numel() == 8 * groups
+        assert widx.is_contiguous() and length.is_contiguous() and state.is_contiguous()
         arr = (_lib.GptLayer * len(layers))()
         for i, lay in enumerate(layers):
             for name, t in lay.items():
@@ -583,6 +585,7 @@ class GptDecodeStep:
         d.rng = 1 if (rng and noise is None) else 0
         d.top_k, d.temperature = 0 if top_k is None else int(top_k), float(temperature)
         d.workspace, d.state = _p(self.ws), _p(state)
+        d.groups = groups
         self.desc, self._arr, self._keep = d, arr, keep
 
     def launch(self):
@@ -595,6 +598,21 @@ def stream_cu_limit(stream, cu_limit):
     (0: no budget)."""
     L = _lib.load()
     _lib.check(L.ccvs_stream_cu_limit(C.c_void_p(stream.cuda_stream), int(cu_limit)), "ccvs_stream_cu_limit")
+
+
+def pack_u8_norm(vid, std, mean):
+    """[..., 3, H, W] fp32 -> [..., H, W, 3] uint8 with the imagenet de-normalisation of helpers/generator.py:303-305 in front:
+    v*std[c], + mean[c], clamp(0, 1), x255, truncate (each step rounded on its own: byte-exact with the reference's ops)."""
+    _need_gpu(vid)
+    vid = vid.contiguous()
+    lead = vid.shape[:-3]
+    h, w = vid.shape[-2:]
+    n = int(math.prod(lead)) if len(lead) else 1
+    out = torch.empty(*lead, h, w, 3, dtype=torch.uint8, device=vid.device)
+    s3, m3 = (C.c_float * 3)(*[float(v) for v in std]), (C.c_float * 3)(*[float(v) for v in mean])
+    L = _lib.load()
+    _lib.check(L.ccvs_pack_u8_norm(_p(vid), _p(out), n, h, w, s3, m3, _stream()), "ccvs_pack_u8_norm")
+    return out
 
 
 def pack_u8(vid, lo=-1.0, hi=1.0):

@@ -245,7 +245,7 @@ int ccvs_sample_topk(const float* logits, int64_t ld, const float* noise, int64_
 int ccvs_sample_topk_philox(const float* logits, int64_t ld, int64_t* out, int64_t out_stride, int32_t B, int32_t V, int32_t top_k,
                             float temperature, uint32_t key0, uint32_t key1, uint32_t row0, uint32_t step, uint32_t call, void* stream);
 
-/* One whole KV-cached decode step of the sampling loop (transformer_model.py:395-409 calling
+/* One whole KV-cached decode step of the sampling loop (transformer_model.py:343-350,395-409 calling
  * mingpt.py:219-305 for ONE new position): embed `tok` -> n_layer x [ln1+QKV+cache | attention |
  * proj+res | ln2+fc+GELU | fc2+res] -> ln_f+head -> get_icode pick -> codes[b][*widx] = tok[b] = pick;
  * ++*widx; ++*len; ++state[0].  5*n_layer+3 launches on `stream`.  All per-step state is device-resident,
@@ -279,6 +279,14 @@ typedef struct ccvs_gpt_decode {
     int32_t top_k; float temperature;
     void* workspace;                    /* ccvs_gemm_workspace_bytes(), zeroed once */
     int32_t* state;
+    /* Row groups (0 or 1: none).  groups > 1: the B rows are `groups` equal blocks of B / groups consecutive rows -- the clips of
+     * `groups` generation batches whose token loops advance in ONE step: every weight matrix is streamed once per step for
+     * all of them (the GEMMs run B rows against one pass over W), while everything that belongs to a batch stays per
+     * group: widx, len are int32[groups], state is int32[groups][8] (own step counter, call index, Philox key and first
+     * global clip index), each group's cache rows are written and attended at its own length, and the last row of a GROUP
+     * to be picked advances that group's words.  A row's arithmetic does not depend on the rows it shares a step with:
+     * the result is bit-identical to `groups` separate steps (tests/test_pipeline_gpu.py).  B <= 256. */
+    int32_t groups;
 } ccvs_gpt_decode;
 int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream);
 
@@ -289,13 +297,18 @@ int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream);
  * ccvs_conv_desc.cu_limit to n.  Used by the two-batches-in-flight schedule: the frame decoder of batch i (this budget) runs
  * beside the token loop of batch i+1 (a chain of ~120 small dependent launches per token on a high-priority stream, which
  * needs free CUs the moment each launch arrives).  Results do not depend on the budget.  Host state: one table of at most
- * 16 (stream, budget) pairs, to be written by the thread that drives the device. */
+ * 16 (stream, budget) pairs behind a mutex; a budget of 0 removes the stream's entry. */
 int ccvs_stream_cu_limit(void* stream, int32_t cu_limit);
 
 /* ---- output stage ---------------------------------------------------------------------
  * save_video_batch's clamp / rescale / x255 / uint8 / channels-last pack
  * (helpers/generator.py:306-309).  vid [N,3,H,W] fp32 in [lo,hi] -> out [N,H,W,3] u8. */
 int ccvs_pack_u8(const float* vid, uint8_t* out, int64_t N, int32_t H, int32_t W, float lo, float hi, void* stream);
+/* The imagenet_norm branch of the same stage (helpers/generator.py:303-305,309): vid *= std; vid += mean; clamp(0, 1);
+ * x255; truncate -- each step rounded to fp32 on its own like the reference's separate tensor ops (byte-exact).
+ * std3 / mean3: HOST pointers to the three per-channel constants. */
+int ccvs_pack_u8_norm(const float* vid, uint8_t* out, int64_t N, int32_t H, int32_t W, const float* std3, const float* mean3,
+                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert sorted(built_lib.EXPORTS) == declared, "ccvs_amd/lib.py EXPORTS out of sync with the header"
     built_lib.load()
     handle.ccvs_abi_version.restype = ctypes.c_int
-    assert handle.ccvs_abi_version() == 2
+    assert handle.ccvs_abi_version() == 3
 
 
 def test_conv_desc_layout_matches_c(built_lib, tmp_path):
@@ -51,6 +51,24 @@ def test_conv_desc_layout_matches_c(built_lib, tmp_path):
     out = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     assert out[0] == ctypes.sizeof(built_lib.ConvDesc)
     assert out[1:] == [getattr(built_lib.ConvDesc, f).offset for f in fields]
+
+
+def test_gpt_decode_layout_matches_c(built_lib, tmp_path):
+    """The ctypes mirrors of ccvs_gpt_decode (incl. the row-group field) and ccvs_gpt_layer match the C structs."""
+    progs = []
+    for cname, cls in (("ccvs_gpt_decode", built_lib.GptDecode), ("ccvs_gpt_layer", built_lib.GptLayer), ("ccvs_ctx_list", built_lib.CtxList)):
+        fields = [f[0] for f in cls._fields_]
+        prog = f'printf("%zu", sizeof({cname}));\n' + "".join(f'printf(" %zu", offsetof({cname}, {f}));\n' for f in fields) + 'printf("\\n");\n'
+        progs.append((cls, fields, prog))
+    c = tmp_path / "g.c"
+    c.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ccvs_hip.h"\nint main(){' + "".join(p for _, _, p in progs) + "return 0;}\n")
+    exe = tmp_path / "g"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    lines = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    for (cls, fields, _), line in zip(progs, lines):
+        out = [int(v) for v in line.split()]
+        assert out[0] == ctypes.sizeof(cls), cls
+        assert out[1:] == [getattr(cls, f).offset for f in fields], cls
 
 
 def test_no_cpu_fallback(built_lib):

@@ -383,7 +383,7 @@ def test_gpt_decode_step_matches_per_op_engine(ops):
             p.data.add_(0.05 * torch.randn_like(p))
         code = torch.randint(0, 200, (16, 16), device="cuda")
         n_new = 600 if n_embd == 256 else 100   # 600: several double-buffered K/V batches in the attention kernel
-        net._cache, net._graphs = None, {}
+        net.drop_engine_state()
         got_graph = net.generate(code, n_new, sample=False, top_k=10).cpu()
         got_eager = net.generate(code, n_new, sample=False, top_k=10, use_graph=False).cpu()
         net.begin(16, 16 + n_new)
@@ -502,8 +502,9 @@ def test_conv_packed_activation_chain(ops):
 
 
 def test_gemm_row_blocked_matches_plain(ops):
-    """M >= 128 runs the row-blocked GEMM kernel (weight tile fetched once per 64 rows): every 16-row slice equals the
-    plain M = 16 launch bit for bit, with and without the folded LayerNorm, GELU / residual epilogues and ragged M, N."""
+    """Up to 256 rows the weight-stream kernel runs (one workgroup per 16 rows x 16 columns): every 16-row slice equals the
+    plain M = 16 launch bit for bit, with and without the folded LayerNorm, GELU / residual epilogues and ragged M, N.  Beyond
+    256 rows the prefill form runs (row-blocked, 8 K slices instead of 4: another summation order): equal to rounding."""
     torch.manual_seed(9)
     for m, n, k in ((128, 320, 256), (150, 200, 128), (260, 1024, 512), (64, 48, 64)):
         x = torch.randn(m, k).cuda()
@@ -518,7 +519,10 @@ def test_gemm_row_blocked_matches_plain(ops):
             part = [ops.gemm_nt(xs, w, b), ops.gemm_nt(xs, w, b, ops.EPI_RESIDUAL, residual=res[r0:r0 + 16].contiguous()),
                     ops.gemm_ln(xs, *packed, epilogue=ops.EPI_GELU)]
             for f, q in zip(full, part):
-                assert torch.equal(f[r0:r0 + 16], q)
+                if m <= 256:
+                    assert torch.equal(f[r0:r0 + 16], q)
+                else:
+                    close(f[r0:r0 + 16], q, 2e-5)
         want = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x, (k,), gam, bet) @ w.t() + b)
         close(full[2], want, 5e-4)
 

@@ -1,5 +1,5 @@
-"""-m gpu: Generator.run_pipelined (two batches in flight: decoder of batch i on one stream, token loop of batch i+1 on a
-high-priority stream, convolutions capped to a share of the CUs) must give exactly what the serial schedule gives."""
+"""-m gpu: Generator.run_pipelined (several batches in flight: the decoder of one batch on one stream, ONE token loop over the
+stacked rows of the next `lanes` batches on a high-priority stream) must give exactly what the serial schedule gives."""
 import pytest
 import torch
 
@@ -8,8 +8,9 @@ from tests.test_e2e_gpu import tiny, TINY_ARGV  # noqa: F401  (fixture)
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("sample,cu_limit,lanes", [(False, 0, 1), (True, 6, 2), (True, 200, 3)])
-def test_pipelined_equals_serial(tiny, sample, cu_limit, lanes):
+@pytest.mark.parametrize("sample,cu_limit,lanes,chains,ramp", [(False, 0, 1, 1, ()), (True, 6, 2, 1, ()), (True, 200, 3, 2, ()), (True, 0, 2, 2, (1,)),
+                                                               (True, 0, 1, 3, ())])
+def test_pipelined_equals_serial(tiny, sample, cu_limit, lanes, chains, ramp):
     from ccvs_amd.helpers.generator import Generator
     from ccvs_amd import ops
     xopt = tiny["xopt"]
@@ -22,7 +23,7 @@ def test_pipelined_equals_serial(tiny, sample, cu_limit, lanes):
         batches = [gen.synthetic_batch(2, seed=80 + i)["vid"] for i in range(5)]
         serial = [gen.generate_vid({"vid": b.clone()}, global_iter=10 + i) for i, b in enumerate(batches)]
         packed = []
-        res = gen.run_pipelined(({"vid": b.clone()} for b in batches), first_iter=10, cu_limit=cu_limit, lanes=lanes,
+        res = gen.run_pipelined(({"vid": b.clone()} for b in batches), first_iter=10, cu_limit=cu_limit, lanes=lanes, chains=chains, ramp=ramp,
                                 finish=lambda i, fake: packed.append((i, ops.pack_u8(fake["vid"]))))
         torch.cuda.synchronize()
         assert [r["index"] for r in res] == [10, 11, 12, 13, 14] and [i for i, _ in packed] == [10, 11, 12, 13, 14]
@@ -35,9 +36,80 @@ def test_pipelined_equals_serial(tiny, sample, cu_limit, lanes):
             assert not torch.equal(res[0]["fake"]["code"], res[1]["fake"]["code"])
         ms = gen.pipeline_stage_ms()
         assert all(v > 0 for v in ms.values())
+        sizes = [g for g, _ in gen.pipeline_token_groups()]
+        assert sum(sizes) == 5 and max(sizes) <= lanes and (not ramp or sizes[0] == ramp[0])
     finally:
         xopt.sample, xopt.rec_pass = False, True
         tiny["tr"].sample_noise = old_noise
+
+
+def test_decode_gemm_rows_do_not_depend_on_the_launch():
+    """The weight-stream GEMM (`gemm16_kernel<RB>`): a row's result is the same bits whether it is computed in a launch of
+    16 rows (RB = 1) or stacked with the rows of other batches (RB = 2, 3, 4, two workgroup rows): plain, split-K (K = 4096),
+    LayerNorm-folded + GELU and the QKV form with its cache scatter, ragged row counts included."""
+    from ccvs_amd import ops
+    g = torch.Generator().manual_seed(5)
+    C, F = 256, 1024
+    x = torch.randn(80, C, generator=g).cuda()
+    h = torch.randn(80, 4096, generator=g).cuda()
+    w_proj, b_proj = (torch.randn(C, C, generator=g) * 0.05).cuda(), torch.randn(C, generator=g).cuda()
+    w_fc2, b_fc2 = (torch.randn(C, 4096, generator=g) * 0.02).cuda(), torch.randn(C, generator=g).cuda()
+    w_fc, b_fc = (torch.randn(F, C, generator=g) * 0.05).cuda(), torch.randn(F, generator=g).cuda()
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    fc_packed = ops.pack_ln_linear(w_fc, b_fc, gamma, beta)
+    w_qkv, b_qkv = (torch.randn(3 * C, C, generator=g) * 0.05).cuda(), torch.randn(3 * C, generator=g).cuda()
+    qkv_packed = ops.pack_ln_linear(w_qkv, b_qkv, gamma, beta)
+    H, Tmax = 4, 8
+    for m in (16, 23, 32, 48, 64, 80):
+        xs, hs = x[:m], h[:m]
+        whole = [ops.gemm_nt(xs, w_proj, b_proj, ops.EPI_RESIDUAL, residual=xs),
+                 ops.gemm_nt(hs, w_fc2, b_fc2, ops.EPI_RESIDUAL, residual=xs),
+                 ops.gemm_ln(xs, *fc_packed, epilogue=ops.EPI_GELU)]
+        kc, vc = torch.zeros(m, H, Tmax, C // H, device="cuda"), torch.zeros(m, H, Tmax, C // H, device="cuda")
+        whole.append(ops.gemm_ln_qkv(xs, *qkv_packed, kc, vc, m, 1, 3))
+        whole += [kc, vc]
+        for lo in range(0, m, 16):
+            hi = min(lo + 16, m)
+            part = [ops.gemm_nt(xs[lo:hi], w_proj, b_proj, ops.EPI_RESIDUAL, residual=xs[lo:hi]),
+                    ops.gemm_nt(hs[lo:hi], w_fc2, b_fc2, ops.EPI_RESIDUAL, residual=xs[lo:hi]),
+                    ops.gemm_ln(xs[lo:hi], *fc_packed, epilogue=ops.EPI_GELU)]
+            kc1, vc1 = torch.zeros(hi - lo, H, Tmax, C // H, device="cuda"), torch.zeros(hi - lo, H, Tmax, C // H, device="cuda")
+            part.append(ops.gemm_ln_qkv(xs[lo:hi], *qkv_packed, kc1, vc1, hi - lo, 1, 3))
+            part += [kc1, vc1]
+            for a, b in zip(whole, part):
+                assert torch.equal(a[lo:hi], b), (m, lo)
+        want = torch.nn.functional.gelu(torch.nn.functional.layer_norm(xs, (C,), gamma, beta) @ w_fc.t() + b_fc)
+        assert (whole[2] - want).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("batch,groups,sample", [(16, 3, True), (5, 3, True), (24, 2, True), (16, 4, False)])
+def test_grouped_token_loop_equals_per_batch(batch, groups, sample):
+    """`ccvs_gpt_decode.groups`: the token loops of several batches as ONE loop over their stacked rows (weights streamed once
+    per token for all of them) give each batch exactly the tokens of its own loop -- per-group Philox words, cache lengths and
+    counters; 5 rows per group puts two groups into one 16-row tile."""
+    from ccvs_amd.models.skip_vid_generator.models import mingpt
+    torch.manual_seed(11)
+    net = mingpt.GPT(vocab_size=200, block_size=400, num_blocks=25, n_layer=3, n_head=4, n_embd=256, emb_mode="temporal", shape=(4, 4)).cuda()
+    for p in net.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    codes = [torch.randint(0, 200, (batch, 16), device="cuda") for _ in range(groups)]
+    keys = [(0x1234567 + 977 * g, 0xabcdef01 ^ (g << 7)) for g in range(groups)]
+    n_new = 150
+    alone = []
+    for g in range(groups):
+        net.noise_key, net.row_offset, net.noise_call = keys[g], 32, 0
+        alone.append(net.generate(codes[g], n_new, sample=sample, top_k=20).clone())
+    net.noise_key, net.row_offset, net.noise_call = list(keys), [32] * groups, 0
+    stacked = net.generate(torch.cat(codes), n_new, sample=sample, top_k=20)
+    eager = None
+    net.noise_call = 0
+    eager = net.generate(torch.cat(codes), n_new, sample=sample, top_k=20, use_graph=False)
+    net.noise_key, net.row_offset = None, 0
+    for g in range(groups):
+        assert torch.equal(stacked[g * batch:(g + 1) * batch], alone[g]), f"group {g} of the stacked loop differs from its own loop"
+        assert torch.equal(eager[g * batch:(g + 1) * batch], alone[g])
+    if sample:
+        assert not torch.equal(alone[0][:, 16:], alone[1][:, 16:])
 
 
 def test_conv_cu_limit_is_bit_identical():

@@ -17,7 +17,7 @@ code = torch.randint(0, 1024, (batch, 64), device="cuda")
 modes = [m for m in os.environ.get("MODES", "1,0").split(",")]
 for pipe in modes:
     mingpt.DECODE_PIPELINE = pipe == "1"
-    net._cache, net._graphs = None, {}
+    net.drop_engine_state()
     out = net.generate(code, 8, sample=True, top_k=100)  # capture
     torch.cuda.synchronize()
     t0 = time.perf_counter()

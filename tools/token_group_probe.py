@@ -63,7 +63,7 @@ with torch.no_grad():
     net = gen.transformer_model.net_t
     for rows in rows_list:
         cond = torch.randint(0, 1024, (rows, 512), generator=torch.Generator().manual_seed(3)).cuda()   # mid-clip context length
-        net._cache, net._graphs = None, {}
+        net.drop_engine_state()
         with torch.cuda.stream(s_bg):
             net.generate(cond, 16, sample=True, top_k=100, noise="device")      # capture
             s_bg.synchronize()

@@ -18,7 +18,7 @@ net = mingpt.GPT(vocab_size=1024, block_size=1024, num_blocks=16, n_layer=24, n_
 
 def lane_of(n):
     c = copy.copy(n)
-    c._cache, c._graphs = None, {}
+    c.drop_engine_state()
     return c
 
 
