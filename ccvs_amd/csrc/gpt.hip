@@ -104,8 +104,9 @@ __device__ __forceinline__ void ln_accum(const f32x4& v, float& sx, float& sxx) 
 
 // 16 bytes at descriptor `r`, per-lane byte offset `voff` + wave-uniform byte offset `soff` (buffer_load_dwordx4 ... offen)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int AUX = 0>   // AUX = 2: non-temporal (streamed once: do not displace what other kernels keep in L2 / the Infinity Cache)
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
     return __builtin_bit_cast(f32x4, v);
 }
 
@@ -167,6 +168,7 @@ __device__ __forceinline__ float gemm_epilogue(float v, bool ln, float rstd, flo
 // -amdgpu-kernarg-preload-count they are delivered in SGPRs when the wave starts (gfx950 kernarg preload), so the weight
 // and activation loads of this latency-bound kernel go out without first waiting for a scalar load of the argument block.
 #define GEMM_WAVES 4
+template <int WNT>   // WNT = 2: weights with the non-temporal policy
 __global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __restrict__ x_, const float* __restrict__ w_, long ldx_, int K_, int N_,
                                                                 int M_, int ks_, int kz_, Gemm16 p) {
     __shared__ __attribute__((aligned(16))) float red[GEMM_WAVES * 64 * 4];
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __
         for (; k0 + 16 * GEMM_U <= kper; k0 += 16 * GEMM_U) {
             f32x4 wv[GEMM_U], xv[GEMM_U];
 #pragma unroll
-            for (int u = 0; u < GEMM_U; ++u) wv[u] = buf_load4(wr, wofs, k0 * 4 + 64 * u);
+            for (int u = 0; u < GEMM_U; ++u) wv[u] = buf_load4<WNT>(wr, wofs, k0 * 4 + 64 * u);
 #pragma unroll
             for (int u = 0; u < GEMM_U; ++u) xv[u] = buf_load4(xr, xofs, k0 * 4 + 64 * u);
 #pragma unroll
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __
             }
         }
         for (; k0 < kper; k0 += 16) {  // remainder (small K only)
-            const f32x4 w1 = buf_load4(wr, wofs, k0 * 4);
+            const f32x4 w1 = buf_load4<WNT>(wr, wofs, k0 * 4);
             const f32x4 x1 = buf_load4(xr, xofs, k0 * 4);
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[t], w1[t], acc, 0, 0, 0);
@@ -406,6 +408,12 @@ static int getenv_int(const char* name, int dflt) {
 
 // K slices across workgroups.  A function of N and K only -- never of M -- so that a row's K partition, hence its rounding,
 // does not depend on how many rows share the launch.
+// Cache policy of the decode step's once-read streams (CCVS_DECODE_NT: bit 0 = keys / values of the attention, bit 1 = weights)
+static int decode_nt() {
+    static const int v = getenv_int("CCVS_DECODE_NT", 1);
+    return v;
+}
+
 static int gemm_kz(const Gemm16& g) {
     static int kz_max = -1;
     if (kz_max < 0) { const char* e = getenv("CCVS_GEMM_KZ_MAX"); kz_max = e ? atoi(e) : 4; }
@@ -433,8 +441,11 @@ static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
     while (g.ks > 1 && g.K % (16 * g.ks * g.kz) != 0) g.ks >>= 1;
     if (!decode_form)
         hipLaunchKernelGGL((gemm16_rb_kernel<4>), dim3(cdiv(g.N, 16), cdiv(g.M, 64), 1), dim3(512), 0, st, g);
+    else if (decode_nt() & 2)
+        hipLaunchKernelGGL(gemm16_kernel<2>, dim3(cdiv(g.N, 16), cdiv(g.M, 16), g.kz), dim3(64 * GEMM_WAVES), 0, st, g.x, g.w, g.ldx, g.K, g.N, g.M, g.ks,
+                           g.kz, g);
     else
-        hipLaunchKernelGGL(gemm16_kernel, dim3(cdiv(g.N, 16), cdiv(g.M, 16), g.kz), dim3(64 * GEMM_WAVES), 0, st, g.x, g.w, g.ldx, g.K, g.N, g.M, g.ks,
+        hipLaunchKernelGGL(gemm16_kernel<0>, dim3(cdiv(g.N, 16), cdiv(g.M, 16), g.kz), dim3(64 * GEMM_WAVES), 0, st, g.x, g.w, g.ldx, g.K, g.N, g.M, g.ks,
                            g.kz, g);
     CCVS_CHECK_LAUNCH(name);
     return CCVS_OK;
@@ -683,6 +694,13 @@ __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __r
     }
 }
 
+// 16 bytes, optionally with the non-temporal policy (a stream read once: keys / values of a decode step)
+template <bool NT>
+__device__ __forceinline__ f32x4 ld_f4(const float* p) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(p);
+    return NT ? __builtin_nontemporal_load(q) : *q;
+}
+
 // Decode form (Tq = 1): one workgroup per (batch, head) streams that head's K and V rows once.
 // A key row of D floats is read by D/4 consecutive lanes as float4 (a wave-instruction covers
 // 64/(D/4) whole rows: 1 KiB, fully coalesced); the partial dots are summed across those lanes
@@ -692,7 +710,7 @@ __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __r
 // convolution workgroup of the frame decoder instead of waiting for one to retire; a stream of this shape keeps 3.5 TB/s
 // beside the decoder (5.5 alone; tools/chain_probe.py).  Four key rows per lane are requested together (16 KB in flight
 // per workgroup); the first V batch is requested before the softmax reduction starts.
-template <int D>
+template <int D, bool NT>
 __global__ __launch_bounds__(256) void attention_decode_kernel(const float* __restrict__ q, long q_sB, const float* __restrict__ kc,
                                                                const float* __restrict__ vc, float* __restrict__ out, int H, int pos0,
                                                                const int32_t* __restrict__ pos_dev, int grp_rows, int Tmax, float scale) {
@@ -719,17 +737,17 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const float* __re
     // unconditional loads from clamped rows (predicated loads would serialise)
 #define ATT_LOAD(dst, base, bi)                                                                                          \
     _Pragma("unroll") for (int u = 0; u < AU; ++u)                                                                       \
-        dst[u] = *reinterpret_cast<const float4*>(base + (long)min((bi) * BATCH + jw + u * NW * KPI, L - 1) * D)
+        dst[u] = ld_f4<NT>(base + (long)min((bi) * BATCH + jw + u * NW * KPI, L - 1) * D)
 
     const float4 qv = *reinterpret_cast<const float4*>(q + (long)b * q_sB + h * D + 4 * d4);
     float lmax = -INFINITY;
     for (int bi = 0; bi < nbatch; ++bi) {
-        float4 kv[AU];
+        f32x4 kv[AU];
         ATT_LOAD(kv, kbase, bi);
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
             const int j = bi * BATCH + jw + u * NW * KPI;
-            float s = kv[u].x * qv.x + kv[u].y * qv.y + kv[u].z * qv.z + kv[u].w * qv.w;
+            float s = kv[u][0] * qv.x + kv[u][1] * qv.y + kv[u][2] * qv.z + kv[u][3] * qv.w;
 #pragma unroll
             for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
             s *= scale;
@@ -739,7 +757,7 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const float* __re
             }
         }
     }
-    float4 vv[AU];
+    f32x4 vv[AU];
     ATT_LOAD(vv, vbase, 0);  // in flight during the softmax reductions
 
     lmax = wave_max(lmax);
@@ -769,7 +787,7 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const float* __re
         for (int u = 0; u < AU; ++u) {
             const int j = bi * BATCH + jw + u * NW * KPI;
             const float p = (j < L) ? ps[min(j, L - 1)] : 0.f;
-            acc.x += p * vv[u].x; acc.y += p * vv[u].y; acc.z += p * vv[u].z; acc.w += p * vv[u].w;
+            acc.x += p * vv[u][0]; acc.y += p * vv[u][1]; acc.z += p * vv[u][2]; acc.w += p * vv[u][3];
         }
     }
 #undef ATT_LOAD
@@ -783,6 +801,12 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const float* __re
         out[(long)b * (H * D) + h * D + tid] = o / tot;
     }
 }
+
+#define ATT_DECODE_LAUNCH(Dv, grid_, smem_, ...)                                                                       \
+    do {                                                                                                               \
+        if (decode_nt() & 1) hipLaunchKernelGGL((attention_decode_kernel<Dv, true>), grid_, dim3(256), smem_, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((attention_decode_kernel<Dv, false>), grid_, dim3(256), smem_, st, __VA_ARGS__);     \
+    } while (0)
 
 extern "C" int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const float* kcache, const float* vcache, float* out, int32_t B,
                               int32_t H, int32_t Tq, int32_t pos0, const int32_t* pos_dev, int32_t Tmax, int32_t D, void* stream) {
@@ -798,9 +822,9 @@ extern "C" int ccvs_attention(const float* q, int64_t q_sB, int64_t ldq, const f
         const size_t smem = (size_t)(16 + 4 * 256 + maxL) * sizeof(float);
         CCVS_REQUIRE(smem <= 64 * 1024, "ccvs_attention: sequence too long for the LDS score buffer");
         const dim3 grid((unsigned)(B * H));
-        if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(256), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, 0, Tmax, scale);
-        else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(256), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, 0, Tmax, scale);
-        else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(256), smem, st, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, 0, Tmax, scale);
+        if (D == 64) ATT_DECODE_LAUNCH(64, grid, smem, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, 0, Tmax, scale);
+        else if (D == 32) ATT_DECODE_LAUNCH(32, grid, smem, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, 0, Tmax, scale);
+        else ATT_DECODE_LAUNCH(16, grid, smem, q, (long)q_sB, kcache, vcache, out, H, pos0, pos_dev, 0, Tmax, scale);
     } else {
         const dim3 grid((unsigned)(B * H), (unsigned)cdiv(Tq, 128));
         if (D == 64) hipLaunchKernelGGL((attention_prefill_kernel<64>), grid, dim3(256), 0, st, q, (long)q_sB, (long)ldq, kcache, vcache, out, H, Tq, pos0, pos_dev, Tmax, scale);
@@ -1061,9 +1085,9 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream) {
         if ((rc = launch_gemm16(g, st, "ccvs_gpt_decode_step(qkv)")) != CCVS_OK) return rc;
         {   // attention over the cache
             const dim3 grid((unsigned)(d->B * d->H));
-            if (D == 64) hipLaunchKernelGGL((attention_decode_kernel<64>), grid, dim3(256), smem_att, st, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, grp_rows, d->Tmax, scale);
-            else if (D == 32) hipLaunchKernelGGL((attention_decode_kernel<32>), grid, dim3(256), smem_att, st, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, grp_rows, d->Tmax, scale);
-            else hipLaunchKernelGGL((attention_decode_kernel<16>), grid, dim3(256), smem_att, st, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, grp_rows, d->Tmax, scale);
+            if (D == 64) ATT_DECODE_LAUNCH(64, grid, smem_att, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, grp_rows, d->Tmax, scale);
+            else if (D == 32) ATT_DECODE_LAUNCH(32, grid, smem_att, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, grp_rows, d->Tmax, scale);
+            else ATT_DECODE_LAUNCH(16, grid, smem_att, d->q, (long)d->C, L.kcache, L.vcache, d->att, d->H, 0, (const int32_t*)d->len, grp_rows, d->Tmax, scale);
             CCVS_CHECK_LAUNCH("ccvs_gpt_decode_step(attention)");
         }
         g = Gemm16{};  // proj + residual (in place on x)
