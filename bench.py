@@ -41,7 +41,8 @@ def parse_args():
                     help="timed batches (default 20: ~30 s; the fill and drain of the pipelined schedule are inside the timed region and weigh 1/K)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU (weak scaling)")
-    ap.add_argument("--config", type=str, default="bair", choices=["bair", "kinetics"])
+    ap.add_argument("--config", type=str, default="bair", choices=["bair", "kinetics", "bair-p2p", "drums"],
+                    help="bair = BASELINE.json configs[1] (the metric); kinetics / bair-p2p / drums = configs[2] / [3] / [4] at their real geometry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-noise", type=str, default="device", choices=["device", "host"])
     ap.add_argument("--conv-precision", type=str, default=None, choices=["bf16x3", "f32"])
@@ -51,34 +52,60 @@ def parse_args():
     ap.add_argument("--lanes", type=int, default=None, help="pipelined: batches whose token loops run as ONE loop over their stacked rows (a token group)")
     ap.add_argument("--chains", type=int, default=None, help="pipelined: token groups that run beside each other (one stream each)")
     ap.add_argument("--ramp", type=str, default=None, help="pipelined: sizes of the first token groups, e.g. 1,2 (then --lanes)")
+    ap.add_argument("--no-strict-f32", action="store_true", help="skip the exact-fp32-convolution leg reported as strict_f32 (2 serial batches after the timed region)")
     ap.add_argument("--rec-pass", action="store_true", help="also run the reference's teacher-forced reconstruction decode (not counted)")
     return ap.parse_args()
 
 
-def supervise(args, cmd, env):
-    """Run the measuring process(es) `cmd` as a child of this one -- which never touches the GPU -- with a time limit, relay
-    the JSON line, and start them again if they do not finish: once more without the host-side cpu_baseline leg, then also
-    with the serial schedule.  One
-    default run in some dozens on this pool's boxes stopped making progress in a state that could not be reproduced under
-    a stack-dumping watchdog; a measurement that may never return is not one, so the limit is part of the harness.  The
-    line then says so (`supervisor.attempts`, `supervisor.note`)."""
+def _kill_tree(proc, grace=10.0):
+    """Stop `proc` and EVERY descendant.  torch.distributed.run starts each rank in a session of its own, so killing the agent's
+    process group leaves hung ranks behind -- holding the GPUs and the write end of our stdout pipe.  SIGTERM goes to the
+    direct child first (torchrun forwards it and reaps its workers); whatever of the tree is still alive after the grace
+    period is SIGKILLed (the descendants are listed BEFORE anything is signalled: orphans cannot be found afterwards)."""
     import signal
+    import psutil
+    try:
+        tree = psutil.Process(proc.pid).children(recursive=True)
+    except psutil.Error:
+        tree = []
+    try:
+        proc.send_signal(signal.SIGTERM)
+    except OSError:
+        pass
+    deadline = time.time() + grace
+    while time.time() < deadline and (proc.poll() is None or any(p_.is_running() for p_ in tree)):
+        time.sleep(0.1)
+    for p_ in tree:
+        try:
+            p_.kill()
+        except psutil.Error:
+            pass
+    if proc.poll() is None:
+        proc.kill()
+
+
+def supervise(args, cmd, env):
+    """Run the measuring process(es) `cmd` as a child of this one -- which never touches the GPU -- under a time limit and relay
+    the JSON line.  The schedule itself cannot hang silently any more (every wait in Generator.run_pipelined has a time limit
+    and raises); this limit is the harness's own backstop against anything else (a box whose host stalls, a dead RCCL rank).
+    A child that runs into it is stopped with all its descendants and the SAME measurement is started once more, without the
+    host-side cpu_baseline leg (the one part whose duration the GPU does not decide); the line then says so
+    (`supervisor.attempts`, `supervisor.note`).  What is measured never changes between attempts."""
     import subprocess
     limit = float(os.environ.get("CCVS_BENCH_TIME_LIMIT", 600 + 12 * (args.steps + args.warmup)))
     notes = []
-    for attempt in range(1, 4):
-        extra = []
-        if attempt >= 2 and not args.no_cpu_baseline:
-            extra += ["--no-cpu-baseline"]      # the host-side leg is the one part whose duration the GPU does not decide
-        if attempt == 3 and args.schedule == "pipelined":
-            extra += ["--schedule", "serial"]
+    for attempt in range(1, 3):
+        extra = ["--no-cpu-baseline"] if attempt >= 2 and not args.no_cpu_baseline else []
         proc = subprocess.Popen(cmd + extra, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
         try:
             out, _ = proc.communicate(timeout=limit)
         except subprocess.TimeoutExpired:
-            os.killpg(proc.pid, signal.SIGKILL)
-            proc.communicate()
-            notes.append(f"attempt {attempt} killed after {limit:.0f} s without a result")
+            _kill_tree(proc, grace=float(os.environ.get("CCVS_BENCH_KILL_GRACE", "10")))
+            try:
+                proc.communicate(timeout=10)
+            except subprocess.TimeoutExpired:   # an orphan still holds the pipe: stop reading
+                proc.stdout.close()
+            notes.append(f"attempt {attempt} stopped after {limit:.0f} s without a result")
             print(f"bench.py: {notes[-1]}", file=sys.stderr)
             continue
         lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
@@ -107,6 +134,8 @@ def launch_ranks(args):
         return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this host driver
+    if args.gpus > 1:   # N ranks share the host: a few intra-op threads each (the 1 + chains launch threads per rank are extra)
+        env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 8) // (2 * args.gpus)))))
     env["CCVS_BENCH_CHILD"] = "1"
     if args.gpus == 1 and os.environ.get("CCVS_BENCH_FORCE_LAUNCHER") != "1":
         return supervise(args, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env)
@@ -119,12 +148,12 @@ def launch_ranks(args):
 
 
 def build_generator(args):
-    from ccvs_amd.tools.options import Options, BAIR_ARGV, KINETICS_ARGV
+    from ccvs_amd.tools.options import Options, BAIR_ARGV, KINETICS_ARGV, BAIR_P2P_ARGV, DRUMS_ARGV
     from ccvs_amd.helpers.generator import Generator
-    argv = list(BAIR_ARGV if args.config == "bair" else KINETICS_ARGV)
+    argv = list({"bair": BAIR_ARGV, "kinetics": KINETICS_ARGV, "bair-p2p": BAIR_P2P_ARGV, "drums": DRUMS_ARGV}[args.config])
     # the teacher-forced "rec" decode of the REAL codes is not part of the metric (synthesized frames only)
     argv += ["--batch_size_vid", str(args.batch), "--x_sample_noise", args.sample_noise, "--rec_pass", "true" if args.rec_pass else "false"]
-    opt = Options().parse(load_qvid_generator=True, load_transformer=True, argv=argv)
+    opt = Options().parse(load_qvid_generator=True, load_transformer=True, load_stft_ae=(args.config == "drums"), argv=argv)
     torch.manual_seed(0)  # reference initialisers under seed 0
     with contextlib.redirect_stdout(sys.stderr):   # "Loading untrained ... net": stdout carries the ONE JSON line only
         gen = Generator(opt).build_models()
@@ -146,75 +175,80 @@ def calibrate_codebook(gen, data):
 
 
 def cpu_baseline(gen, opt):
-    """The oracle (CPU restatement of the reference algorithm, incl. its no-KV-cache token loop)
-    timed on this host on a BOUNDED sample of config 1 (BAIR, batch 1) and extrapolated:
-    encoder on 1 frame, decoder on 1 frame with k=1 and k=3 contexts, GPT forward at
-    T = 64 / 384 / 704 / 1023, integrated over the 960-token loop and the 15-frame decode loop."""
+    """The oracle (CPU restatement of the reference algorithm, incl. its no-KV-cache token loop) timed on this host on a
+    BOUNDED sample of config 1 (BAIR, batch 1) and extrapolated to one clip: encoder on 1 frame, decoder on 1 frame with k = 1
+    and k = 3 contexts, GPT forward at five sequence lengths, integrated over the 960-token loop and the 15-frame decode loop.
+    The GPU box's host is shared, so the sample defends itself: the thread count is chosen by a short sweep (the fastest of
+    8 / 16 / 32 / 64 / all cores on one mid-size GPT forward), every quantity is the MEDIAN of three calls, the load average
+    is reported, and the figure is marked `unreliable` when the quadratic fit of the GPT times misses a sample by more than 10 %."""
+    import statistics
+    import numpy as np
     from oracle import ccvs_oracle as O
     qopt, xopt = opt["qvid_generator"], opt["transformer"]
     cpu = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
     nets = {"e": cpu(gen.vid_model.net_e), "q": cpu(gen.vid_model.net_q), "g": cpu(gen.vid_model.net_g),
             "t": cpu(gen.transformer_model.net_t)}
-    cores = torch.get_num_threads()
+    all_cores = os.cpu_count() or torch.get_num_threads()
     g = torch.Generator().manual_seed(1)
     frame = torch.rand(1, 1, 3, qopt.max_dim, qopt.max_dim, generator=g) * 2 - 1
     t_all = time.perf_counter()
-    # The sample is bounded in TIME as well: the GPU box's host is shared, and on a loaded host the same calls were seen to take
-    # 5x longer (148 s instead of 30 s).  Every measurement runs once; it is repeated (the faster of two is kept: the first
-    # call of a kind also pays one-time allocator / thread-pool costs) only while less than half of the budget is spent, and
-    # the fourth GPT length is dropped when the budget is gone (three points still fix the quadratic).
-    budget = float(os.environ.get("CCVS_CPU_BASELINE_BUDGET", "40"))
-    repeats = []
+    load0 = os.getloadavg()
+    budget = float(os.environ.get("CCVS_CPU_BASELINE_BUDGET", "60"))   # seconds; past it the repeats are dropped (median of what was taken)
 
-    def timed(fn):
-        t0 = time.perf_counter()
-        fn()
-        best = time.perf_counter() - t0
-        if time.perf_counter() - t_all < 0.5 * budget:
+    def timed(fn, reps=3):
+        ts = []
+        for _ in range(reps):
             t0 = time.perf_counter()
             fn()
-            best = min(best, time.perf_counter() - t0)
-            repeats.append(2)
-        else:
-            repeats.append(1)
-        return best
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_all > budget:
+                break
+        return statistics.median(ts), len(ts)
 
+    calls = 0
     with torch.no_grad():
         O.encoder_forward(nets["e"], qopt, frame[:, :, :, :64, :64])  # untimed warm-up (thread pool, allocator)
-        t0 = time.perf_counter()
+        idx_probe = torch.randint(0, xopt.z_num, (1, 384), generator=g)
+        sweep = {}
+        for nthr in sorted({n for n in (8, 16, 32, 64, all_cores) if n <= all_cores}):
+            torch.set_num_threads(nthr)
+            O.gpt_forward(nets["t"], xopt, idx_probe[:, :64])
+            t0 = time.perf_counter()
+            O.gpt_forward(nets["t"], xopt, idx_probe)
+            sweep[nthr] = time.perf_counter() - t0
+        cores = min(sweep, key=sweep.get)
+        torch.set_num_threads(cores)
+        t_enc, n = timed(lambda: O.qvid_encode(nets, qopt, frame)); calls += n
         enc = O.qvid_encode(nets, qopt, frame)
-        t_enc = time.perf_counter() - t0
         z = enc["z"]
         ctx = [f for f in enc["inter"]]
-        t_dec1 = timed(lambda: O.decoder_forward(nets["g"], qopt, z, [ctx]))
-        t0 = time.perf_counter()
-        O.decoder_forward(nets["g"], qopt, z, [ctx, ctx, ctx])
-        t_dec3 = time.perf_counter() - t0
+        t_dec1, n = timed(lambda: O.decoder_forward(nets["g"], qopt, z, [ctx])); calls += n
+        t_dec3, n = timed(lambda: O.decoder_forward(nets["g"], qopt, z, [ctx, ctx, ctx]), reps=2); calls += n
         t_dec2 = 0.5 * (t_dec1 + t_dec3)   # linear in the number of contexts
         ts = {}
-        for T in (64, 1023, 384, 704):      # least-squares quadratic through the cache lengths sampled
-            if T == 704 and time.perf_counter() - t_all > budget:
-                continue
+        for T in (64, 1023, 512, 256, 768):      # least-squares quadratic through the lengths sampled (ends first: they fix the fit)
             idx = torch.randint(0, xopt.z_num, (1, T), generator=g)
-            ts[T] = timed(lambda: O.gpt_forward(nets["t"], xopt, idx))
+            ts[T], n = timed(lambda: O.gpt_forward(nets["t"], xopt, idx)); calls += n
         ts = dict(sorted(ts.items()))
     # decode: frame with k contexts costs a + b*k ; 1 cond frame (k=1) + 15 frames with k = 1..15
     b = max(t_dec2 - t_dec1, 0.0)
     a = max(t_dec1 - b, 0.0)
     t_decode = (a + b) + sum(a + b * k for k in range(1, 16)) + 15 * t_enc          # + 15 re-encodes
     # GPT: least-squares quadratic t(T) over the samples, summed over T = 64 .. 1023 (one full forward per new token)
-    import numpy as np
     tt, yy = np.array(list(ts.keys()), dtype=np.float64), np.array(list(ts.values()))
     coef = np.polyfit(tt, yy, 2)
     t_gpt = float(sum(np.polyval(coef, T) for T in range(64, 1024)))
     fit_err = float(np.max(np.abs(np.polyval(coef, tt) / yy - 1.0)))
     t_encode = 16 * t_enc
     total = t_encode + t_gpt + t_decode
-    return {"value": 15.0 / total, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": (f"oracle on BAIR batch 1, extrapolated from {time.perf_counter() - t_all:.1f}s of CPU work: encoder 1 frame "
-                       f"{t_enc:.2f}s, decoder 1 frame k=1 {t_dec1:.2f}s / k=3 {t_dec3:.2f}s, GPT forward T={'/'.join(str(k) for k in ts)} "
-                       f"{'/'.join(f'{v:.2f}' for v in ts.values())}s ({sum(repeats)} timed calls in a {budget:.0f} s budget; least-squares quadratic, worst relative residual "
-                       f"{100 * fit_err:.0f}%) -> clip = encode {t_encode:.0f}s + no-cache token loop "
+    load1 = os.getloadavg()
+    return {"value": 15.0 / total, "unit": "frames/s", "cores": cores, "kind": "port", "unreliable": bool(fit_err > 0.10),
+            "threads_swept": {str(k): round(v, 3) for k, v in sweep.items()}, "host_cores": all_cores,
+            "load_average": {"before": [round(v, 1) for v in load0], "after": [round(v, 1) for v in load1]},
+            "sample": (f"oracle on BAIR batch 1, extrapolated from {time.perf_counter() - t_all:.1f}s of CPU work on {cores} threads (fastest of the sweep; "
+                       f"{all_cores} host cores): medians of up to 3 calls -- encoder 1 frame {t_enc:.2f}s, decoder 1 frame k=1 {t_dec1:.2f}s / k=3 {t_dec3:.2f}s, "
+                       f"GPT forward T={'/'.join(str(k) for k in ts)} {'/'.join(f'{v:.2f}' for v in ts.values())}s ({calls} timed calls; least-squares "
+                       f"quadratic, worst relative residual {100 * fit_err:.0f}%) -> clip = encode {t_encode:.0f}s + no-cache token loop "
                        f"{t_gpt:.0f}s + decode {t_decode:.0f}s")}
 
 
@@ -289,7 +323,9 @@ def conv_traffic(args, kind, launches):
 
 def main():
     args = parse_args()
-    if "WORLD_SIZE" not in os.environ and os.environ.get("CCVS_BENCH_CHILD") != "1" and os.environ.get("CCVS_BENCH_SUPERVISE", "1") != "0":
+    profiled = bool(os.environ.get("ROCP_TOOL_LIBRARIES")) or "rocprof" in os.environ.get("LD_PRELOAD", "")   # under rocprofv3: measure in THIS process
+    if ("WORLD_SIZE" not in os.environ and os.environ.get("CCVS_BENCH_CHILD") != "1" and os.environ.get("CCVS_BENCH_SUPERVISE", "1") != "0"
+            and not (profiled and args.gpus == 1)):
         # invoked bare: the measurement runs in child process(es) under a time limit (CCVS_BENCH_FORCE_LAUNCHER=1 takes the
         # torch.distributed.run path with one rank, which exercises the N-rank launch on a one-GPU box)
         sys.exit(launch_ranks(args))
@@ -307,11 +343,15 @@ def main():
         gen.engine = engine
         lo, _ = engine.shard_batch(args.batch * world)
         xopt = opt["transformer"]
-        predicted = xopt.vid_len - xopt.cond_len // 64
+        predicted = xopt.vid_len - xopt.cond_len // 64 - (1 if xopt.p2p else 0)   # p2p: the last frame is the given end frame
         dev = torch.device("cuda", torch.cuda.current_device())
 
         def make_batch(step):
-            return {"vid": gen.synthetic_batch(args.batch, seed=1 + step, first_clip=lo)["vid"].to(dev)}
+            data = {"vid": gen.synthetic_batch(args.batch, seed=1 + step, first_clip=lo)["vid"].to(dev)}
+            if xopt.stft:   # audio-conditioned: one 64 x 16 spectrogram frame per video frame (a_stft_shape 8 2 after three stride-2 levels)
+                g_ = torch.Generator().manual_seed(77 + step)
+                data["stft"] = (torch.rand(args.batch, xopt.vid_len, 1, 64, 16, generator=g_) * 2 - 1).to(dev)
+            return data
 
         # the same clips on every rank (global clips 0-1 of seed 1): the codebook scale, hence the replica, is identical everywhere
         calibrate_codebook(gen, {"vid": gen.synthetic_batch(2, seed=1, first_clip=0)["vid"].to(dev)})
@@ -359,6 +399,13 @@ def main():
         ops.KERNEL_TIMER = None
         assert clips.shape[0] == args.batch * world
 
+        # per-rank stage times (rank order) for the line: which rank, and which stage of it, bounds a multi-GPU run
+        rank_stages = [{k: v / args.steps for k, v in stage.items() if k != "timeline"}]
+        if engine.distributed:
+            import torch.distributed as dist
+            gathered = [None] * world
+            dist.all_gather_object(gathered, rank_stages[0])
+            rank_stages = gathered
         alone = None
         if engine.is_main and args.schedule == "pipelined":
             # the same convolution launches with the chip to themselves (one more batch, serial schedule, outside the timed
@@ -393,14 +440,20 @@ def main():
             peak = BF16_MFMA_PEAK_TFLOPS if kind == "bf16x3" else FP32_MFMA_PEAK_TFLOPS
             products = 3 if kind == "bf16x3" else 1
             line = {
-                "metric": ("synthesized frames/sec (BAIR 256x256, cond=1, pred=15), whole job" if args.config == "bair" else
-                           "synthesized frames/sec (Kinetics-600 64x64, cond=5, pred=11), whole job"), "value": frames / elapsed,
+                "metric": {"bair": "synthesized frames/sec (BAIR 256x256, cond=1, pred=15), whole job",
+                           "kinetics": "synthesized frames/sec (Kinetics-600 64x64, cond=5, pred=11), whole job",
+                           "bair-p2p": "synthesized frames/sec (BAIR 256x256 point-to-point, start + end frame given, 14 interpolated), whole job",
+                           "drums": "synthesized frames/sec (AudioSet-Drums 128x128, audio-conditioned, cond=15, pred=30), whole job"}[args.config],
+                "value": frames / elapsed,
                 "unit": "frames/s", "per_gpu": frames / elapsed / world, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32 (convolutions as split-bf16 x3 on bf16 MFMA, fp32 accumulate)" if kind == "bf16x3" else "f32",
                 "data": "synthetic",
-                "config": {"workload": "BAIR 256x256 1->15 frames, batch 16 per GPU (BASELINE.json configs[1])" if args.config == "bair"
-                           else "Kinetics-600 64x64 5->11 frames", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                "config": {"workload": {"bair": "BAIR 256x256 1->15 frames, batch 16 per GPU (BASELINE.json configs[1])",
+                                        "kinetics": "Kinetics-600 64x64 5->11 frames (BASELINE.json configs[2])",
+                                        "bair-p2p": "BAIR 256x256 point-to-point, 14 interpolated frames (BASELINE.json configs[3], scripts/bairhd/save_videos_p2p.sh)",
+                                        "drums": "AudioSet-Drums 128x128 audio-conditioned, 15 -> 30 frames, STFT tokens given (BASELINE.json configs[4], "
+                                                 "scripts/drums/save_videos_audio_on.sh)"}[args.config], "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                            "predicted_frames_per_clip": predicted,
                            "rec_pass": ("also run, not counted" if args.rec_pass else "off: the reference's extra teacher-forced reconstruction decode is not part of "
                                         "the synthesized-frames metric (SURVEY 8d)"), "sampling": f"top-k {xopt.top_k}, T={xopt.temperature}, noise={args.sample_noise}",
@@ -440,7 +493,8 @@ def main():
             # the token loop as a whole, in situ: weights ONCE per step of a token group + the keys and values of every batch in it,
             # against the HBM peak
             net_t = gen.transformer_model.net_t
-            n_tok = xopt.vid_len * 64 - xopt.cond_len
+            n_tok = predicted * 64    # frame tokens sampled per clip (drums: the window slides, so every slide also re-prefills ~1200 tokens;
+                                      # the byte count below is the plain loop's and only approximate for that config)
             w_bytes = 4.0 * sum(p_.numel() for n_, p_ in net_t.named_parameters() if n_.startswith("blocks.") and p_.dim() == 2) + 4.0 * net_t.head.weight.numel()
             kv_bytes = 8.0 * args.batch * net_t.config.n_embd * len(net_t.blocks) * (xopt.cond_len + xopt.z_len) / 2
             if args.schedule == "pipelined":
@@ -458,11 +512,37 @@ def main():
                 "ms_per_step": loop_ms / (len(groups) * n_tok), "ms_per_token_per_batch": loop_ms / (sum(g for g, _ in groups) * n_tok),
                 "tokens_per_clip": n_tok, "batches_per_token_group": [g for g, _ in groups], "mean_batches_per_group": mean_group,
                 "algorithmic_bytes_per_step": w_bytes + mean_group * kv_bytes, "weights_bytes": w_bytes, "mean_kv_bytes_per_batch": kv_bytes,
-                "concurrent_token_loops": n_chains, "aggregate_frac": n_chains * gbps / HBM_PEAK_GBPS,
+                "concurrent_token_loops": n_chains, "aggregate_frac": n_chains * gbps / HBM_PEAK_GBPS, "approximate": args.config == "drums",
                 "note": "HIP events on each token stream around the whole loop of every token group of the timed region (prefill of the conditioning frame "
                         "included); bytes = weights counted ONCE per step + mean KV bytes of every batch in the group; `frac` is ONE loop's stream while "
                         "`concurrent_token_loops` loops and the decoder share the memory system (aggregate_frac = loops x frac)"}
             line["roofline_decode_kernels"] = decode_kernel_rooflines(gen, xopt, args.batch)
+            line["multi_gpu"] = {"rccl_ranks": (torch.distributed.get_world_size() if engine.distributed else 1), "backend": engine.backend if engine.distributed else None,
+                                 "stage_ms_per_step_by_rank": rank_stages,
+                                 "host_threads_per_rank": {"torch_intra_op": torch.get_num_threads(), "launch_threads": 1 + (gen.last_chains if args.schedule == "pipelined" else 0)},
+                                 "scaling_curve": "not measured by this run: one line per N; the driver derives efficiency from the N = 1, 2, 4, 8 lines (tools/scale_sweep.sh runs them)"}
+            if args.config == "bair" and world == 1 and not args.conv_precision and not args.no_strict_f32:
+                # the same path with EXACT fp32 convolutions (v_mfma_f32_32x32x2_f32 instead of the split-bf16 products), serial
+                # schedule, outside the timed region: what the arithmetic choice of `dtype` buys, in the driver's own line
+                ops.CONV_PRECISION = "f32"
+                try:
+                    gen.generate_vid(make_batch(3000), 3000)
+                    t32 = ops.KernelTimer()
+                    torch.cuda.synchronize()
+                    ops.KERNEL_TIMER = t32
+                    t0 = time.perf_counter()
+                    for i in range(2):
+                        gen.generate_vid(make_batch(3001 + i), 3001 + i)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    ops.KERNEL_TIMER = None
+                    n32, f32flops, ms32 = t32.summary("conv2d_f32")
+                    tf = f32flops / (ms32 * 1e-3) / 1e12 if ms32 > 0 else 0.0
+                    line["strict_f32"] = {"frames_per_s": predicted * args.batch * 2 / dt, "schedule": "serial, 2 batches after one untimed", "conv_tflops": tf,
+                                          "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS, "conv_launches": n32}
+                finally:
+                    ops.CONV_PRECISION = kind
+                    ops.KERNEL_TIMER = None
             if not args.no_cpu_baseline and args.config == "bair" and world == 1:   # rank 0 at N = 1 only
                 line["cpu_baseline"] = cpu_baseline(gen, opt)
             print(json.dumps(line))

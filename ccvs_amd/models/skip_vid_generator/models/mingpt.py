@@ -783,6 +783,8 @@ class GPT(nn.Module):
         n_pre = self.n_prefix()
         assert t_cond + n_pre + idx.shape[1] <= self.block_size, "Cannot forward, model block size is exhausted."  # mingpt.py:299
         if 0 not in state_idx.size():
+            if n_pre:   # same combination, same answer as generate(): not on the path, never a misleading assert
+                raise NotImplementedError("label / start tokens together with an ancillary token stream")
             state_idx = state_idx[:, :self.config.num_blocks * self.config.state_size].to(idx.device)
             rows = self._stream_rows(idx, state_idx)
             self.begin(idx.shape[0], t_cond + rows.shape[1], stream=True, n_state_front=state_idx.shape[1])

@@ -172,8 +172,11 @@ class Transformer(torch.nn.Module):
         if add_len <= 0:
             return code, state_code
         net = self.net_t
+        if net.config.use_lbl:
+            raise NotImplementedError("beam search with a class-label token: the reference's expansion (transformer_model.py:361) "
+                                      "does not replicate vid_lbl and fails too")
         rows = code.repeat_interleave(beam, dim=0).contiguous()            # row b * beam + i = hypothesis i of clip b
-        net.begin(bs * beam, t0 + add_len)
+        net.begin(bs * beam, net.n_prefix() + t0 + add_len)                 # (a start token occupies one more cache position)
         logits = net.prefill(rows)                                           # identical for the beam rows of a clip
         icode, log_p = self.get_icode(logits[::beam].unsqueeze(1), opt.temperature, opt.top_k, opt.sample, n=beam)   # [bs, beam]
         rows = torch.cat((rows, icode.reshape(-1, 1)), dim=1)

@@ -223,3 +223,23 @@ KINETICS_ARGV = ["--name", "kinetics", "--dataset", "kinetics600", "--max_dim", 
                  "--q_necf", "256", "--q_necf_mult", "1", "1", "2", "2", "--q_enc_model", "skipgan", "--q_dec_model", "skipgan",
                  "--q_use_inter", "--q_inter_p", "0.75", "--x_z_num", "16384", "--x_z_len", "1024", "--x_n_layer", "24",
                  "--x_n_head", "16", "--x_n_embd", "1024", "--x_z_chunk", "64", "--x_emb_mode", "temporal"]
+
+# BASELINE.json configs[3]: the reference's point-to-point launch line (scripts/bairhd/save_videos_p2p.sh:7-22; training-only
+# flags dropped): start frame + end frame given, 14 frames interpolated.
+BAIR_P2P_ARGV = list(BAIR_ARGV) + ["--x_p2p", "--p2p_len", "16"]
+
+# BASELINE.json configs[4]: the reference's audio-conditioned launch line (scripts/drums/save_videos_audio_on.sh:9-23; training-only
+# flags dropped): 128x128 / 5 levels, 45 frames from 15 conditioning frames, the 16 STFT tokens of every frame given
+# (--keep_state), a 1280-token window of 16 x (16 + 64) that slides by one frame, the first 8 ring slots pinned.
+# (sic) the script passes --dataset "drum", which matches no preset of tools/options.py:431-439 ("drums": aspect_ratio 1, fps 30);
+# the preset's name is used here -- 8 x 8 tokens per frame need the square 128 x 128 frames.
+DRUMS_ARGV = ["--name", "drums", "--dataset", "drums", "--max_dim", "128", "--vid_len", "45", "--x_cond_len", "960",
+              "--x_sample", "--x_top_k", "100", "--x_temperature", "1.0", "--keep_state",
+              "--q_skip_context"] + [str(i) for i in range(1, 16)] + ["--q_skip_memory", "15", "--q_keep_first", "--q_n_first", "8",
+              "--q_z_num", "1024", "--q_z_size", "512", "--q_z_shape", "8", "8", "--q_use_enc", "--q_use_dec",
+              "--q_necf", "128", "--q_necf_mult", "1", "1", "2", "2", "4", "--q_enc_model", "skipgan", "--q_dec_model", "skipgan",
+              "--q_use_inter", "--q_inter_p", "0.75",
+              "--a_stft_num", "1024", "--a_stft_size", "512", "--a_stft_hsize", "512", "--a_stft_shape", "8", "2",
+              "--x_z_num", "1024", "--x_z_len", "1280", "--x_n_layer", "24", "--x_n_head", "16", "--x_n_embd", "1024", "--x_z_chunk", "80",
+              "--x_num_blocks", "16", "--x_state_num", "1024", "--x_state_size", "16", "--x_stft", "--x_emb_mode", "temporal"]
+

@@ -265,6 +265,25 @@ def test_vq_golden(ops, gold, name):
     close(emb, torch.from_numpy(gold[f"vq/{name}/embed"]).permute(0, 3, 1, 2), 0)
 
 
+def test_embed_gather_every_code(ops):
+    """ccvs_embed_gather alone (VectorQuantizer.embed_code + the transposes of QVidModel.decode, quantize.py:76-83): every code
+    value of the Kinetics codebook (n_e = 16384) in a ragged [N, HW] layout equals the oracle's row gather bit for bit, and
+    codes outside [0, n_e) read the nearest valid row (the reference would raise; a device kernel must not fault)."""
+    g = torch.Generator().manual_seed(12)
+    n_e, c, hw = 16384, 24, 37
+    cb = torch.randn(n_e, c, generator=g)
+    n = -(-n_e // hw) + 2
+    code = torch.cat([torch.randperm(n_e, generator=g), torch.randint(0, n_e, (n * hw - n_e,), generator=g)])
+    z = ops.embed_gather(code.cuda(), cb.cuda(), n, hw).cpu()                       # [n, C, hw]
+    want = O.embed_code(code.view(n, hw), cb).permute(0, 2, 1)                        # [n, hw, C] -> [n, C, hw]
+    assert torch.equal(z, want)
+    bad = code.clone()
+    bad[::7] = n_e + 5
+    bad[3::11] = -4
+    zb = ops.embed_gather(bad.cuda(), cb.cuda(), n, hw).cpu()
+    assert torch.equal(zb, O.embed_code(bad.clamp(0, n_e - 1).view(n, hw), cb).permute(0, 2, 1))
+
+
 def test_vq_bair_shape(ops):
     torch.manual_seed(1)
     z = torch.randn(32, 512, 8, 8) * 0.3
