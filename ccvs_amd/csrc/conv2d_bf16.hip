@@ -339,8 +339,9 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
             ve[j] = vr * IWS + 4 * vq;
         }
     }
-    f32x4 xv[NI][VEC ? 8 : 1];
-    int xvc0 = -1;  // first channel of the chunk held in xv; -1: nothing
+    // two register sets: a chunk's activation loads are requested TWO chunks before they are converted (see the staging loop)
+    f32x4 xv[2][NI][VEC ? 8 : 1];
+    int xvc0[2] = {-1, -1};  // first channel of the chunk held in each set; -1: nothing
     int wofs[CB_WR];  // lane part of the weight address (uint4 units): tap column, half, hi|lo, cout
 #pragma unroll
     for (int i = 0; i < CB_WR; ++i) {
@@ -404,33 +405,33 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
             if (rtw + NPW * i < wunits)
                 __builtin_amdgcn_global_load_lds((glb_void*)(base + wofs[i]), (lds_void*)(dst + rw * 64 + NPW * i), 16, 0, 0);
     };
-    auto load_xv = [&](int c_) {
-        xvc0 = c_ * CB_CC;
+    auto load_xv = [&](int set, int c_) {   // `set` is a compile-time constant at every call site
+        xvc0[set] = c_ * CB_CC;
         if (ablate & 16) return;
-        const bool full = xvc0 + CB_CC <= cin_;
+        const bool full = xvc0[set] + CB_CC <= cin_;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
 #pragma unroll
             for (int i = 0; i < (VEC ? 8 : 1); ++i) {
-                const int c = full ? xvc0 + i : min(xvc0 + 8 * vh[j] + i, cin_ - 1) - 8 * vh[j];
-                xv[j][i] = *reinterpret_cast<const f32x4*>(vptr[j] + (long)c * in_sC);
+                const int c = full ? xvc0[set] + i : min(xvc0[set] + 8 * vh[j] + i, cin_ - 1) - 8 * vh[j];
+                xv[set][j][i] = *reinterpret_cast<const f32x4*>(vptr[j] + (long)c * in_sC);
             }
         }
     };
-    auto store_xv = [&](uint4* dst) {
-        if (xvc0 < 0) return;
+    auto store_xv = [&](int set, uint4* dst) {
+        if (xvc0[set] < 0) return;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             if (!vitem[j]) continue;
-            const bool plain = vin[j] && (xvc0 + CB_CC <= cin_);
+            const bool plain = vin[j] && (xvc0[set] + CB_CC <= cin_);
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
                 float v[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = xv[j][VEC ? i : 0][px];
+                for (int i = 0; i < 8; ++i) v[i] = xv[set][j][VEC ? i : 0][px];
                 if (!plain) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = (vin[j] && xvc0 + 8 * vh[j] + i < cin_) ? v[i] : 0.f;
+                    for (int i = 0; i < 8; ++i) v[i] = (vin[j] && xvc0[set] + 8 * vh[j] + i < cin_) ? v[i] : 0.f;
                 }
                 uint4 hi, lo;
                 if (ablate & 8) {
@@ -506,8 +507,8 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
             dma_x(0, in_buf);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (xrole) {
-            load_xv(0);
-            store_xv(in_buf);
+            load_xv(0, 0);
+            store_xv(0, in_buf);
         } else if (!VEC) {
             for (int j = 0; j < NE; ++j) {
                 const int o = pix_offset(j);
@@ -539,21 +540,41 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
             }
         }
     } else if (producer && VEC) {
-        // chunk c is requested at step (c-2, 0) and converted + stored at step (c-1, 0), a whole chunk later; these are
-        // the wave's only outstanding loads.  Requests past the end re-read the last chunk (and are never stored).
+        // Chunk c is requested at step (c-3, 0) and converted + stored at step (c-1, 0), TWO chunks later, from one of two
+        // register sets (the loop is unrolled by two so that the sets stay statically indexed); these are the wave's only
+        // outstanding loads.  One chunk of lead (3 steps of a 128-cout layer, but only ~1.5 us of a 64-cout one) is less than
+        // a load takes once the token loops of other batches share the memory system, and the MFMA waves then wait at the
+        // chunk's first barrier; the staging role has the registers to spare (the kernel's allocation is the MFMA role's).
+        // Requests past the end re-read the last chunk (and are never stored).
         // The step barrier of the staging waves is a RAW s_barrier behind an LDS-only wait: __syncthreads() also drains
         // vmcnt, i.e. it would make the wave sit at the first barrier of a chunk until the global loads it has just requested
-        // for the chunk after next have landed -- and the MFMA waves with it.  The loads stay in flight across the three
-        // barriers; hipcc waits for them where their registers are first read (store_xv, a chunk later).
+        // have landed -- and the MFMA waves with it.  The loads stay in flight across the barriers; hipcc waits for them
+        // where their registers are first read (store_xv, two chunks later).
         constexpr int NTYc = VEC ? NTY : 1;
         const bool work = !(ablate & (1 | 256));   // 256: weights still arrive, activations are not staged
         const bool drain = ablate & 64;   // experiments: the old __syncthreads() steps
-        if (work) load_xv(min(1, nchunks - 1));
+        const bool deep = !(ablate & 2048);   // 2048: one chunk of lead (the round-2 schedule)
+        if (work) {
+            load_xv(0, min(1, nchunks - 1));
+            if (deep) load_xv(1, min(2, nchunks - 1));
+        }
         __syncthreads();
-        for (int ci = 0; ci < nchunks; ++ci) {
-            if (work) {
-                if (ci + 1 < nchunks) store_xv(in_buf + ((ci + 1) & 1) * in_sz);
-                load_xv(min(ci + 2, nchunks - 1));
+        for (int ci = 0; ci < nchunks; ci += 2) {
+            if (work) {   // set 0 holds chunk ci + 1
+                if (ci + 1 < nchunks) store_xv(0, in_buf + ((ci + 1) & 1) * in_sz);
+                if (deep) load_xv(0, min(ci + 3, nchunks - 1));
+                else load_xv(1, min(ci + 2, nchunks - 1));
+            }
+#pragma unroll
+            for (int a = 0; a < NTYc; ++a) {
+                if (drain) __syncthreads();
+                else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            if (ci + 1 >= nchunks) break;
+            if (work) {   // set 1 holds chunk ci + 2
+                if (ci + 2 < nchunks) store_xv(1, in_buf + ((ci + 2) & 1) * in_sz);
+                if (deep) load_xv(1, min(ci + 4, nchunks - 1));
+                else load_xv(0, min(ci + 3, nchunks - 1));
             }
 #pragma unroll
             for (int a = 0; a < NTYc; ++a) {
@@ -561,7 +582,7 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
                 else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (never stored) request
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (never stored) requests
     } else if (producer) {
       int ci = -1, a = nt - 1;
       for (int s = -1; s < nsteps; ++s) {
