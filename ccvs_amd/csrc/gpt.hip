@@ -1036,6 +1036,99 @@ extern "C" int ccvs_sample_topk_philox(const float* logits, int64_t ld, int64_t*
 }
 
 // ---------------------------------------------------------------------------------------
+// get_icode with n picks per row (the proposals of beam search, transformer_model.py:358-391,395-409): temperature, top-k
+// mask, softmax, then the n best of p (sample = False: torch.topk) or of p / Exp(1) noise (sample = True: what
+// torch.multinomial(p, n) without replacement computes), best first, ties to the lowest index; also log p of every pick.
+// One workgroup per row: probabilities and scores in LDS, n rounds of a block-wide argmax.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_topn_kernel(const float* __restrict__ logits, long ld, const float* __restrict__ noise,
+                                                          int64_t* __restrict__ out_idx, float* __restrict__ out_logp, int V, int top_k,
+                                                          float temperature, int n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                       // [V] scaled logits, then probabilities
+    float* sc = smem + V;                   // [V] scores the picks are taken from
+    float* redf = smem + 2 * V;             // [4]
+    int* redj = (int*)(smem + 2 * V + 4);   // [4]
+    int* wtot = (int*)(smem + 2 * V + 8);   // [4]
+    int* sel = (int*)(smem + 2 * V + 12);   // [2]
+    int* hist = (int*)(smem + 2 * V + 16);  // [256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float* lr = logits + (long)b * ld;
+    float lmax = -INFINITY;
+    for (int j = tid; j < V; j += 256) {
+        const float v = lr[j] / temperature;
+        xs[j] = v;
+        lmax = fmaxf(lmax, v);
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) redf[wave] = lmax;
+    __syncthreads();
+    const float gmax = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    unsigned thr = 0u;
+    if (top_k > 0 && top_k < V) thr = kth_largest_key(xs, V, top_k, hist, wtot, sel, tid);
+    float lsum = 0.f;
+    for (int j = tid; j < V; j += 256) {
+        const float e = (fkey(xs[j]) >= thr) ? expf(xs[j] - gmax) : 0.f;
+        xs[j] = e;
+        lsum += e;
+    }
+    lsum = wave_sum(lsum);
+    __syncthreads();
+    if (lane == 0) redf[wave] = lsum;
+    __syncthreads();
+    const float tot = ((redf[0] + redf[1]) + redf[2]) + redf[3];
+    for (int j = tid; j < V; j += 256) {
+        const float p = xs[j] / tot;
+        xs[j] = p;
+        sc[j] = noise ? p / noise[(long)b * V + j] : p;
+    }
+    __syncthreads();
+    for (int r = 0; r < n; ++r) {
+        float best = -1.f;
+        int bi = 0x7fffffff;
+        for (int j = tid; j < V; j += 256) {
+            const float v = sc[j];
+            if (v > best) { best = v; bi = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { redf[wave] = best; redj[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (redf[w] > best || (redf[w] == best && redj[w] < bi)) { best = redf[w]; bi = redj[w]; }
+            bi = min(bi, V - 1);
+            out_idx[(long)b * n + r] = bi;
+            out_logp[(long)b * n + r] = logf(xs[bi]);
+            sc[bi] = -2.f;   // taken
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int ccvs_sample_topn(const float* logits, int64_t ld, const float* noise, int64_t* out_idx, float* out_logp, int32_t B, int32_t V,
+                                int32_t top_k, float temperature, int32_t n, void* stream) {
+    CCVS_REQUIRE(logits && out_idx && out_logp, "ccvs_sample_topn: null pointer");
+    CCVS_REQUIRE(B > 0 && V > 0 && temperature > 0.f && n >= 1 && n <= V, "ccvs_sample_topn: bad arguments");
+    const size_t smem = (size_t)(2 * V + 16 + 256) * sizeof(float);
+    CCVS_REQUIRE(smem <= 160 * 1024, "ccvs_sample_topn: vocabulary %d too large", V);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)sample_topn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sample_topn_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, logits, (long)ld, noise, out_idx, out_logp, V, top_k,
+                       temperature, n);
+    CCVS_CHECK_LAUNCH("ccvs_sample_topn");
+    return CCVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // One decode step: the launch sequence of ccvs_gpt_embed / ccvs_gemm_ln_qkv / ccvs_attention /
 // ccvs_gemm_nt / ccvs_gemm_ln / ccvs_sample_topk for a single new position, 5 * n_layer + 3 launches
 // on one stream, every per-step quantity device-resident (hipGraph-capturable).

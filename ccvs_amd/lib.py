@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libccvs_hip.so")
 EXPORTS = [
     "ccvs_last_error", "ccvs_abi_version", "ccvs_conv2d", "ccvs_conv2d_bf16x3", "ccvs_upfirdn2d", "ccvs_dwconvT4x4s2",
     "ccvs_correlation7x7", "ccvs_backwarp", "ccvs_backwarp_ctx", "ccvs_backwarp_proj_ctx", "ccvs_warp_fuse_blend", "ccvs_warp_fuse_blend_ctx", "ccvs_tap_shift_add", "ccvs_vq_argmin", "ccvs_embed_gather",
-    "ccvs_gpt_embed", "ccvs_layernorm", "ccvs_gemm_workspace_bytes", "ccvs_gemm_nt", "ccvs_gemm_ln", "ccvs_gemm_ln_qkv", "ccvs_attention", "ccvs_kv_append", "ccvs_sample_topk", "ccvs_sample_topk_philox",
+    "ccvs_gpt_embed", "ccvs_layernorm", "ccvs_gemm_workspace_bytes", "ccvs_gemm_nt", "ccvs_gemm_ln", "ccvs_gemm_ln_qkv", "ccvs_attention", "ccvs_kv_append", "ccvs_sample_topk", "ccvs_sample_topk_philox", "ccvs_sample_topn",
     "ccvs_gpt_decode_step", "ccvs_pack_u8", "ccvs_pack_u8_norm", "ccvs_stream_cu_limit",
 ]
 
@@ -108,6 +108,7 @@ def load():
         "ccvs_kv_append": [vp, vp, i64, i64, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp],
         "ccvs_sample_topk": [vp, i64, vp, vp, i64, i32, i32, i32, f32, vp],
         "ccvs_sample_topk_philox": [vp, i64, vp, i64, i32, i32, i32, f32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp],
+        "ccvs_sample_topn": [vp, i64, vp, vp, vp, i32, i32, i32, f32, i32, vp],
         "ccvs_gpt_decode_step": [C.POINTER(GptDecode), vp],
         "ccvs_pack_u8": [vp, vp, i64, i32, i32, f32, f32, vp],
         "ccvs_pack_u8_norm": [vp, vp, i64, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp],

@@ -76,40 +76,42 @@ class Transformer(torch.nn.Module):
         out[out < v[..., [-1]]] = -float('Inf')
         return out
 
+    def token_windows(self, total_len):
+        """The sliding token windows behind the first one (transformer_model.py:301-326): window w starts w frames into the
+        clip and produces one more chunk of `z_chunk` tokens -- fewer for the last.  Yields (frames to drop in front, tokens to
+        add or None for a full chunk)."""
+        produced, w = self.opt.z_len, 1
+        while produced < total_len:
+            step = min(self.opt.z_chunk, total_len - produced)
+            yield w, (step if step < self.opt.z_chunk else None)
+            produced += step
+            w += 1
+
     @torch.no_grad()
     def generate_fake(self, code, state_code, cond_code, delta_length_cond, vid_lbl, total_len, show_progress=False):
-        """transformer_model.py:263-328, including the sliding token window for total_len > z_len (each slide restarts
-        positions at 0, so the window is re-prefilled) and the ancillary (state / STFT) stream bookkeeping."""
+        """transformer_model.py:263-328.  Up to `z_len` tokens are one `fill_code`; beyond that the token window slides by one
+        frame per chunk (`token_windows`): every window restarts its positions at 0, so the kept part is re-prefilled, and the
+        conditioning prefix moves one frame closer (`delta_length_cond - 1` per window).  The ancillary (state / STFT) stream
+        slides with its frames."""
         opt = self.opt
-        use_state = 0 not in state_code.size()
+        has_state = 0 not in state_code.size()
         n_cond = cond_code.size(1) if 0 not in cond_code.size() else 0
-        if total_len is None:
-            code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl)
-            return {"code": code, "state_code": state_code}
-        total_len = int(total_len)
-        if total_len <= opt.z_len:
-            add_len = total_len - code.size(1) - n_cond
-            add_len -= min(state_code.size(1), opt.state_size * opt.num_blocks) if use_state else 0
+        n_state_known = min(state_code.size(1), opt.state_size * opt.num_blocks) if has_state else 0
+        if total_len is None or int(total_len) <= opt.z_len:
+            add_len = None if total_len is None else int(total_len) - code.size(1) - n_cond - n_state_known
             code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl, add_len=add_len)
             return {"code": code, "state_code": state_code}
-        code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl)
-        curr_len = opt.z_len
-        i = 1
-        while curr_len < total_len:
-            add_len = total_len - curr_len if total_len - curr_len < opt.z_chunk else None
+        code, state_code = self.fill_code(code, state_code, cond_code, delta_length_cond, vid_lbl)   # the first window, filled
+        for w, add_len in self.token_windows(int(total_len)):
             if n_cond:
                 delta_length_cond = delta_length_cond - 1
-            tmp_state_code = state_code[:, i * self.state_size:] if use_state else state_code
-            tmp_code = code[:, i * self.size:]
-            pred_code, pred_state_code = self.fill_code(tmp_code, tmp_state_code, cond_code, delta_length_cond, vid_lbl, add_len=add_len)
-            delta_code = pred_code.size(1) - tmp_code.size(1)
-            code = torch.cat([code, pred_code[:, -delta_code:]], dim=1)
-            if use_state:
-                delta_state_code = pred_state_code.size(1) - tmp_state_code.size(1)
-                if delta_state_code > 0:
-                    state_code = torch.cat([state_code, pred_state_code[:, -delta_state_code:]], dim=1)
-            curr_len += add_len if add_len is not None else opt.z_chunk
-            i += 1
+            win_code = code[:, w * self.size:]
+            win_state = state_code[:, w * self.state_size:] if has_state else state_code
+            out_code, out_state = self.fill_code(win_code, win_state, cond_code, delta_length_cond, vid_lbl, add_len=add_len)
+            grown = out_code.size(1) - win_code.size(1)
+            code = torch.cat([code, out_code[:, -grown:]], dim=1)   # (sic) grown == 0 would append the whole window: `[-0:]`, as upstream (:311-312)
+            if has_state and out_state.size(1) > win_state.size(1):
+                state_code = torch.cat([state_code, out_state[:, win_state.size(1):]], dim=1)
         return {"code": code, "state_code": state_code}
 
     def _noise(self, b, v, device):
@@ -201,24 +203,9 @@ class Transformer(torch.nn.Module):
 
     @torch.no_grad()
     def get_icode(self, logits, temperature, top_k, sample, n=1):
-        """transformer_model.py:395-409: logits [B,T,V] -> (icode [B,n], log p [B,n]).  n = 1 is the fused pick kernel; n > 1
-        (beam-search proposals) = `torch.topk` of the probabilities, or of probabilities / Exp(1) noise -- what
-        `torch.multinomial(probs, n)` without replacement computes -- with the noise drawn like the n = 1 case."""
-        if n != 1:
-            last = logits[:, -1] / temperature
-            if top_k is not None:
-                last = self.top_k_logits(last, top_k)
-            probs = torch.softmax(last, dim=-1)
-            if sample:
-                icode = torch.topk(probs / self._noise(last.shape[0], last.shape[1], last.device), k=n, dim=-1)[1]
-            else:
-                icode = torch.topk(probs, k=n, dim=-1)[1]
-            return icode, torch.log(torch.gather(probs, 1, icode))
+        """transformer_model.py:395-409: logits [B,T,V] -> (icode [B,n], log p [B,n]) in one kernel (`ccvs_sample_topn`):
+        temperature, top-k mask, softmax, the n best of the probabilities -- or of probabilities / Exp(1) noise, which is what
+        `torch.multinomial(probs, n)` without replacement computes, the noise drawn like the single pick's -- and their log p."""
         last = logits[:, -1].contiguous()
         noise = self._noise(last.shape[0], last.shape[1], last.device) if sample else None
-        icode = ops.sample_topk(last, top_k, temperature, noise=noise).view(-1, 1)
-        scaled = last / temperature
-        if top_k is not None:
-            scaled = self.top_k_logits(scaled, top_k)
-        ilog_p = torch.log(torch.gather(torch.softmax(scaled, dim=-1), 1, icode))
-        return icode, ilog_p
+        return ops.sample_topn(last, top_k, temperature, n, noise=noise)

@@ -544,6 +544,22 @@ def sample_topk(logits, top_k, temperature, noise=None, out=None, philox=None):
     return out
 
 
+def sample_topn(logits, top_k, temperature, n, noise=None):
+    """logits [B,V] -> (picks int64 [B,n], log p float [B,n]): the n best of the top-k softmax (noise None) or of probs / noise
+    (torch.multinomial without replacement), best first (`ccvs_sample_topn`: the proposals of beam search)."""
+    _need_gpu(logits, noise)
+    b, v = logits.shape
+    assert logits.stride(1) == 1 and 1 <= n <= v
+    if noise is not None:
+        assert noise.shape == (b, v) and noise.is_contiguous()
+    idx = torch.empty(b, n, dtype=torch.int64, device=logits.device)
+    logp = torch.empty(b, n, dtype=torch.float32, device=logits.device)
+    L = _lib.load()
+    _lib.check(L.ccvs_sample_topn(_p(logits), logits.stride(0), _p(noise), _p(idx), _p(logp), b, v, 0 if top_k is None else int(top_k),
+                                  float(temperature), int(n), _stream()), "ccvs_sample_topn")
+    return idx, logp
+
+
 class GptDecodeStep:
     """A filled `ccvs_gpt_decode` descriptor (include/ccvs_hip.h) plus the tensors it points at.
     `launch()` enqueues one whole decode step on the current stream."""

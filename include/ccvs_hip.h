@@ -245,6 +245,13 @@ int ccvs_sample_topk(const float* logits, int64_t ld, const float* noise, int64_
 int ccvs_sample_topk_philox(const float* logits, int64_t ld, int64_t* out, int64_t out_stride, int32_t B, int32_t V, int32_t top_k,
                             float temperature, uint32_t key0, uint32_t key1, uint32_t row0, uint32_t step, uint32_t call, void* stream);
 
+/* get_icode with n picks per row and their log-probabilities: the proposals of beam search (transformer_model.py:358-391 calling
+ * :395-409 with n = beam_size).  noise == NULL: the n most probable tokens (torch.topk(probs, n)); noise [B,V] ~ Exp(1): the n
+ * largest of probs / noise, i.e. torch.multinomial(probs, n) without replacement.  Best first, ties to the lowest index.
+ * out_idx int64 [B,n], out_logp float [B,n] = log(probs[pick]).  2 V floats of LDS: V <= ~20000. */
+int ccvs_sample_topn(const float* logits, int64_t ld, const float* noise, int64_t* out_idx, float* out_logp, int32_t B, int32_t V,
+                     int32_t top_k, float temperature, int32_t n, void* stream);
+
 /* One whole KV-cached decode step of the sampling loop (transformer_model.py:343-350,395-409 calling
  * mingpt.py:219-305 for ONE new position): embed `tok` -> n_layer x [ln1+QKV+cache | attention |
  * proj+res | ln2+fc+GELU | fc2+res] -> ln_f+head -> get_icode pick -> codes[b][*widx] = tok[b] = pick;

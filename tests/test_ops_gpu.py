@@ -391,6 +391,31 @@ def test_gpt_embed_pack(ops):
     assert torch.equal(ops.pack_u8(vid.cuda()).cpu(), O.pack_u8(vid))
 
 
+@pytest.mark.parametrize("V,n,top_k", [(1024, 4, 100), (16384, 3, 50), (200, 5, None)])
+def test_sample_topn_vs_oracle(ops, V, n, top_k):
+    """ccvs_sample_topn (the n proposals of beam search + their log p, get_icode with n > 1, transformer_model.py:395-409):
+    greedy = torch.topk of the top-k softmax; sampled = torch.multinomial(probs, n) without replacement under the same seed
+    (the Exp(1) stream it consumes); log p within float rounding; n = 1 agrees with the single-pick kernel."""
+    g = torch.Generator().manual_seed(21)
+    B = 6
+    logits = torch.randn(B, 1, V, generator=g) * 2
+    lg = logits[:, -1].contiguous().cuda()
+    for temperature in (1.0, 0.7):
+        idx, logp = ops.sample_topn(lg, top_k, temperature, n)
+        want_idx, probs = O.get_icode(logits, temperature, top_k, False, n=n)
+        assert torch.equal(idx.cpu(), want_idx)
+        close(logp, torch.log(torch.gather(probs, 1, want_idx)), 1e-5)
+        torch.manual_seed(33)
+        want_idx, probs = O.get_icode(logits, temperature, top_k, True, n=n)
+        torch.manual_seed(33)
+        noise = torch.empty(B, V).exponential_(1)
+        idx, logp = ops.sample_topn(lg, top_k, temperature, n, noise=noise.cuda())
+        assert torch.equal(idx.cpu(), want_idx), (V, n, top_k, temperature)
+        close(logp, torch.log(torch.gather(probs, 1, want_idx)), 1e-5)
+        one, _ = ops.sample_topn(lg, top_k, temperature, 1, noise=noise.cuda())
+        assert torch.equal(one[:, 0], ops.sample_topk(lg, top_k, temperature, noise=noise.cuda()))
+
+
 def test_gpt_decode_step_matches_per_op_engine(ops):
     """ccvs_gpt_decode_step (hipGraph replay and eager) == prefill + step() + argmax through the per-op entry points, bit for bit."""
     from ccvs_amd.models.skip_vid_generator.models import mingpt

@@ -48,3 +48,26 @@ def test_gpt_spatio_temporal_and_flat_positions(ref):
             idx = torch.randint(0, 30, (2, 21))
             cfg = O.namespace(z_shape=[4, 4], emb_mode=mode, n_layer=1, n_head=2, z_len=48)
             assert (gpt(idx) - O.gpt_forward(gpt.state_dict(), cfg, idx)).abs().max() < 1e-6
+
+
+def test_output_stage_vs_reference_save_video_batch(ref, tmp_path):
+    """The oracle's output stage (clamp / rescale / x255 / uint8, the imagenet de-normalisation branch, the 3x3 state marker)
+    against the reference's own `save_video_batch` (helpers/generator.py:285-333), with `torchvision.io.write_video` replaced
+    by a recorder: byte for byte, including a marker clipped at the frame border."""
+    import importlib
+    import torchvision
+    g = importlib.import_module("helpers.generator")
+    got = []
+    torchvision.io.write_video = lambda fn, v, fps: got.append((os.path.basename(fn), v.clone()))
+    g.torchvision = torchvision
+    vid = torch.rand(2, 3, 3, 64, 64, generator=torch.Generator().manual_seed(1)) * 2.4 - 1.2
+    state = torch.tensor([[[0.5, 0.25]] * 3, [[0.999, 0.0]] * 3])      # the second marker sits in a corner: clipped cross
+    g.save_video_batch(vid.clone(), 2, 3, str(tmp_path), 4, True, False, [-1, 1], "bair", state=state)
+    assert [n for n, _ in got] == ["vid_00006.mp4", "vid_00007.mp4"]
+    assert torch.equal(torch.stack([v for _, v in got]), O.mark_state(O.pack_u8(vid), state, "bair"))
+    got.clear()
+    g.save_video_batch(vid.clone(), 2, 0, str(tmp_path), 4, True, False, [-1, 1], "bairhd")
+    assert torch.equal(torch.stack([v for _, v in got]), O.pack_u8(vid))
+    got.clear()
+    g.save_video_batch(vid.clone(), 2, 0, str(tmp_path), 4, True, True, [-1, 1], "kinetics600")
+    assert torch.equal(torch.stack([v for _, v in got]), O.pack_u8_imagenet(vid))
