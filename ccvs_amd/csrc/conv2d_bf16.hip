@@ -233,8 +233,16 @@ __global__ __launch_bounds__(64 * NW) void conv2d_bf16x3_kernel(ConvK p, const u
 // Stride-2 layers and halo tiles that do not fit the double buffer use the synchronous kernel above.
 // ---------------------------------------------------------------------------------------
 // (MB = 2 compiled for 4 waves per SIMD -- two workgroups per CU, 17 VGPRs spilled -- measured 236 vs 246 TFLOP/s on 128->64 3x3 at 256^2: not kept)
-template <int TW, int MB, int NTY>
-__global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
+// PP = pixel blocks (of 32) per MFMA wave: 2 = the 256-pixel tile; 4 = a 512-pixel tile (TW x 512/TW), for layers with <= 64
+// output channels.  Their MFMA waves are LDS-READ bound: with two pixel blocks a tap costs 2 MB + 4 operand reads for 6 MB
+// MFMAs -- 0.67 reads per MFMA at MB = 2 against 0.5 at MB = 4, each read 8 cycles of the CU's LDS bandwidth against 32
+// cycles of one SIMD's matrix pipe, four SIMDs wide (the ablation with no staging at all still takes 6.7 of 9.25 ms on
+// 128->64 3x3, 2.4x its pure MFMA time).  Four pixel blocks held in registers against the same weight fragments bring a
+// 64-channel layer to the read intensity of a 128-channel one (2 MB + 8 reads for 12 MB MFMAs) at the same accumulator
+// count (MB x PP x 16 = 128).  VEC staging only (dense stride-1 rows), two activation items per staging thread.
+template <int TW, int MB, int NTY, int PP = 2>
+__global__ __launch_bounds__(512, (MB == 1 && PP == 2) ? 4 : 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
+    static_assert(PP == 2 || (PP == 4 && NTY > 0 && MB == 2), "the 512-pixel tile exists for the VEC staging mode and 64 output channels");
     constexpr bool VEC = NTY > 0;
     // NTY == -8: the input is a packed split-bf16 activation (P8: [N][C/8][hi|lo][H][W] x 8 bf16, written by the epilogue of
     // the producing convolution): its halo tile is already in the LDS image's format, so the staging waves only issue
@@ -242,7 +250,8 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
     constexpr bool P8IN = NTY == -8;
     constexpr bool DMAW = VEC || P8IN;   // weights by LDS-DMA from the MFMA waves
     constexpr int CB_XQ = (NTY == -2) ? 2 : 1;  // scalar staging: halo-tile pixel passes per thread and step (passes <= CB_XQ * nt)
-    constexpr int TH = 256 / TW;
+    constexpr int NPIX = 128 * PP;        // pixels of the tile: 4 MFMA waves x PP blocks of 32
+    constexpr int TH = NPIX / TW;
     constexpr int NT = 32 * MB;
     constexpr int NP = 256;               // staging threads (waves 4-7)
     constexpr int NPW = 256;              // ... all of which stage weights
@@ -316,8 +325,8 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
         for (int jj = 0; jj < NE; ++jj) o = (j == jj) ? offs[jj] : o;
         return o;
     };
-    // VEC item of this thread: half vh (8 channels), tile row vr, float4 column vq
-    constexpr int NI = 1;
+    // VEC item(s) of this thread: half vh (8 channels), tile row vr, float4 column vq
+    constexpr int NI = PP / 2;
     bool vitem[NI], vin[NI];
     int ve[NI], vh[NI];
     const float* vptr[NI];
@@ -485,19 +494,19 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
     };
 
     // ---- consumer state ---------------------------------------------------------------------
-    int bofs[2];
+    int bofs[PP];
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-        const int pj = (rw * 2 + pp) * 32 + (lane & 31);
+    for (int pp = 0; pp < PP; ++pp) {
+        const int pj = (rw * PP + pp) * 32 + (lane & 31);
         const int prow = pj / TW, pcol = pj - prow * TW;
         bofs[pp] = prow * ay.s * IWS + pcol * ax.s + xsh;
     }
     const int khalf = lane >> 5;
-    f32x16 acc[MB][2];
+    f32x16 acc[MB][PP];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp)
+        for (int pp = 0; pp < PP; ++pp)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][pp][r] = 0.f;
 
@@ -619,6 +628,55 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
         if (s >= 0 && !(ablate & 2)) {
             const uint4* it0 = in_buf + (ci & 1) * in_sz + (khalf * 2) * plane + (ay.d0 + a * ay.dd - ay.lo) * IWS;
             const uint4* wt0 = w_buf + (s & 1) * w_sz + (khalf * 2) * NT + (lane & 31);
+            if constexpr (PP == 4) {
+                // Four pixel blocks of a tap stay in registers (fq); the weight fragments of the tap's MB output-channel blocks
+                // sit in one of two sets (fw): the next tap's are read above the current tap's 12 MB MFMAs (the tap loop is
+                // unrolled by two so that the sets stay statically indexed).  There is no second set for the pixels: in the
+                // pass over the LAST channel block each pixel block is re-read for the next tap right after its last MFMA --
+                // 9 to 0 MFMAs before the next tap needs it, the earliest-needed block first.
+                const int ntx = ax.nt, xd0 = ax.d0 - ax.lo, xdd = ax.dd;
+                bf16x8 fq[4][2], fw[2][MB][2];
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    fq[pp][0] = __builtin_bit_cast(bf16x8, it0[xd0 + bofs[pp]]);
+                    fq[pp][1] = __builtin_bit_cast(bf16x8, it0[xd0 + plane + bofs[pp]]);
+                }
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    fw[0][m][0] = __builtin_bit_cast(bf16x8, wt0[m * 32]);
+                    fw[0][m][1] = __builtin_bit_cast(bf16x8, wt0[NT + m * 32]);
+                }
+#define CB_TAP4(CUR, tb, more)                                                                                         \
+    {                                                                                                                  \
+        const uint4* itn_ = it0 + (xd0 + ((tb) + 1) * xdd);                                                            \
+        if (more) {                                                                                                    \
+            const uint4* wtn_ = wt0 + ((tb) + 1) * 4 * NT;                                                             \
+            _Pragma("unroll") for (int m = 0; m < MB; ++m) {                                                           \
+                fw[(CUR) ^ 1][m][0] = __builtin_bit_cast(bf16x8, wtn_[m * 32]);                                        \
+                fw[(CUR) ^ 1][m][1] = __builtin_bit_cast(bf16x8, wtn_[NT + m * 32]);                                   \
+            }                                                                                                          \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        _Pragma("unroll") for (int m = 0; m < MB; ++m) {                                                               \
+            _Pragma("unroll") for (int pp = 0; pp < 4; ++pp) {                                                         \
+                acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[CUR][m][1], fq[pp][0], acc[m][pp], 0, 0, 0);   \
+                acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[CUR][m][0], fq[pp][1], acc[m][pp], 0, 0, 0);   \
+                acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[CUR][m][0], fq[pp][0], acc[m][pp], 0, 0, 0);   \
+                if (m == MB - 1 && (more)) {                                                                           \
+                    fq[pp][0] = __builtin_bit_cast(bf16x8, itn_[bofs[pp]]);                                            \
+                    fq[pp][1] = __builtin_bit_cast(bf16x8, itn_[plane + bofs[pp]]);                                    \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+                int tb = 0;
+                for (; tb + 2 <= ntx; tb += 2) {
+                    CB_TAP4(0, tb, true)
+                    CB_TAP4(1, tb + 1, (tb + 2 < ntx))
+                }
+                if (tb < ntx) { CB_TAP4(0, tb, false) }
+#undef CB_TAP4
+            } else {
             // Software-pipelined fragment reads: the ds_reads of the NEXT 32-cout block (and, on a tap's last block,
             // of the next tap's pixels) are issued before the current block's 6 MFMAs, into the other register
             // set -- hipcc does not do this by itself and the lone MFMA wave of a SIMD then idles a full LDS
@@ -666,6 +724,7 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
 #undef CB_LD_B
 #undef CB_LD_A
 #undef CB_TAP
+            }
         }
         __syncthreads();
         if (++a == nt) { a = 0; ++ci; }
@@ -682,13 +741,13 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
         for (int m = 0; m < MB; ++m) {
             if (!producer) {
 #pragma unroll
-                for (int pp = 0; pp < 2; ++pp)
+                for (int pp = 0; pp < PP; ++pp)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * 256 + (rw * 2 + pp) * 32 + (lane & 31)] = acc[m][pp][r];
+                        stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * NPIX + (rw * PP + pp) * 32 + (lane & 31)] = acc[m][pp][r];
             }
             __syncthreads();
-            if (p.out_p8) {
+            if (PP == 2 && p.out_p8) {   // (packed output: 256-pixel tiles only; the launcher never pairs it with PP = 4)
                 // packed output: a thread takes one pixel x 8 output channels of the staged 32 x 256 block, applies the
                 // epilogue, splits to hi / lo and writes two 16-byte units (lanes = consecutive pixels: coalesced)
                 uint4* y4 = reinterpret_cast<uint4*>(p.y);
@@ -723,15 +782,15 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
                 continue;
             }
 #pragma unroll
-            for (int i = 0; i < (2048 + 255 + NP) / (256 + NP); ++i) {
+            for (int i = 0; i < (8 * NPIX + 255 + NP) / (256 + NP); ++i) {
                 const int idx4 = tid + (256 + NP) * i;
-                if (idx4 >= 2048) break;
-                const int col = idx4 >> 6, px = (idx4 & 63) * 4;
+                if (idx4 >= 8 * NPIX) break;
+                const int col = idx4 / (NPIX / 4), px = (idx4 % (NPIX / 4)) * 4;
                 const int co = n0 + m * 32 + col;
                 const int prow = px / TW, pcol = px - prow * TW;
                 const int vy = ty * TH + prow, vx = tx * TW + pcol;
                 if (co < p.Cout && vy < ay.V && vx < ax.V) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(stage + col * 256 + px);
+                    const float4 a4 = *reinterpret_cast<const float4*>(stage + col * NPIX + px);
                     float v[4] = {a4.x, a4.y, a4.z, a4.w};
                     const float bv = p.bias ? p.bias[co] : 0.f;
                     const long opix = (long)vy * p.Wout + vx;
@@ -772,8 +831,8 @@ __global__ __launch_bounds__(512, MB == 1 ? 4 : 2) void conv2d_bf16x3_pc_kernel(
         }
     } else if (!producer) {
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-        const int pj = (rw * 2 + pp) * 32 + (lane & 31);
+    for (int pp = 0; pp < PP; ++pp) {
+        const int pj = (rw * PP + pp) * 32 + (lane & 31);
         const int prow = pj / TW, pcol = pj - prow * TW;
         const int vy = ty * TH + prow, vx = tx * TW + pcol;
         if (vy >= ay.V || vx >= ax.V) continue;
@@ -887,6 +946,36 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, int CinG, int
     const bool vec_ok = !k.transposed && k.stride == 1 && k.Win % 4 == 0 && k.in_sC % 4 == 0 && k.in_sN % 4 == 0 &&
                         (reinterpret_cast<uintptr_t>(k.x) & 15) == 0 && TW >= 16 && halo_h * nq * 2 <= 256 && ntx_max <= (MB == 1 ? 9 : 3) &&
                         (k.kh == 1 || k.kh == 3) && !(ablate & 4);
+    if constexpr (TW == 32 && MB == 2) {
+        // the 512-pixel tile (PP = 4, 16 x 32): 64 output channels, VEC staging, at least two tile rows of work.  Measured per
+        // shape on a BAIR decode (tools/conv_shape_census.py): 128->64 3x3 at 256^2 253 -> 282 TFLOP/s; the 32-channel layers
+        // (MB = 1: four workgroups per CU hide each other's latency with the 256-pixel tile, one with this one) LOSE -- 64->32
+        // 204 -> 156, the 1 x 9 heads 159 -> 120 -- and stay on the 256-pixel tile.
+        static const int pp4 = getenv("CCVS_CONV_PP4") ? atoi(getenv("CCVS_CONV_PP4")) : 1;
+        const int th4 = 16, halo_h4 = (th4 - 1) + k.kh;
+        const size_t smem_4 = (size_t)(2 * 4 * halo_h4 * (nq * 4 + 1) + 2 * ntx_max * 4 * NT) * 16;
+        if (pp4 && vec_ok && !k.out_p8 && k.Hout >= 2 * th4 && halo_h4 * nq * 2 <= 512 && smem_4 <= 156 * 1024 && smem_4 >= (size_t)32 * 512 * 4) {
+            k.tiles_y = cdiv(k.Hout, th4);
+            const dim3 grid4(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
+            const long total4 = (long)grid4.x * grid4.y * grid4.z;
+            // (one launch over the whole chip; with a CU budget the 256-pixel form below runs in chunks)
+            if (k.cu_limit <= 0) {
+                k.nwork = 0; k.work0 = 0; k.gx = (int)grid4.x; k.gy = (int)grid4.y;
+                k.xcd_chunk = (xcd_aware && total4 % 8 == 0 && total4 >= 64) ? (int)(total4 / 8) : 0;
+                static bool attr4 = false;
+                if (!attr4) {
+                    (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    attr4 = true;
+                }
+                if (k.kh == 3) hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 3, 4>), grid4, dim3(512), smem_4, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
+                else hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, 1, 4>), grid4, dim3(512), smem_4, st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
+                CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
+                return CCVS_OK;
+            }
+            k.tiles_y = k_in.tiles_y;
+        }
+    }
     if (vec_ok) {
         const size_t smem_v = (size_t)(2 * 4 * halo_h * (nq * 4 + 1) + 2 * ntx_max * 4 * NT) * 16;
         if (smem_v <= 156 * 1024) {

@@ -121,6 +121,41 @@ def test_conv_oracle_shapes(ops, cin, cout, k, stride, hw):
     close(got, want)
 
 
+@pytest.mark.parametrize("cin,cout,k,kw,hw", [(128, 64, 3, 3, (48, 64)), (64, 32, 3, 3, (40, 36)), (32, 27, 1, 9, (33, 64)), (99, 64, 3, 3, (37, 100)),
+                                              (128, 64, 3, 3, (256, 256)), (17, 5, 3, 3, (32, 40))])
+def test_conv_tall_tile_shapes(ops, cin, cout, k, kw, hw):
+    """33 .. 64 output channels on dense stride-1 rows of >= 32 lines run the 512-pixel tile (PP = 4: four pixel blocks per MFMA wave,
+    two activation items per staging thread): ragged heights / widths, a channel tail, the 1 x 9 head shape, pre-activation
+    addend + residual + accumulate through its epilogue; and the same bits with a CU budget (which takes the 256-pixel form)."""
+    torch.manual_seed(cin + 3 * cout)
+    n = 1 if hw[0] > 100 else 3
+    x = torch.randn(n, cin, *hw)
+    w = torch.randn(cout, cin, k, kw)
+    b = torch.randn(cout)
+    res = torch.randn(n, cout, *hw)
+    conv = torch.nn.functional.conv2d(x, w * (1 / math.sqrt(cin * k * kw)), bias=b, padding=(k // 2, kw // 2))
+    want = (torch.nn.functional.leaky_relu(conv, 0.1) + res) / math.sqrt(2)
+    pk = ops.pack_conv_weight(w.cuda())
+    got = ops.conv2d(x.cuda(), pk, b.cuda(), cout, k, pad=kw // 2 if k == 1 else k // 2, act=True, residual=res.cuda(), out_scale=1 / math.sqrt(2)) \
+        if k == kw else None
+    if got is None:   # the 1 x k head form: padding on x only
+        got = ops.conv2d(x.cuda(), pk, b.cuda(), cout, k, pad=kw // 2, act=True)
+        hp = got.shape[2]
+        got = (got[:, :, (hp - hw[0]) // 2:(hp - hw[0]) // 2 + hw[0]] + res.cuda()) / math.sqrt(2)
+    close(got, want, 2e-4)
+    if k == kw:
+        ops.CONV_CU_LIMIT = 7
+        try:
+            budget = ops.conv2d(x.cuda(), pk, b.cuda(), cout, k, pad=k // 2, act=True, residual=res.cuda(), out_scale=1 / math.sqrt(2))
+        finally:
+            ops.CONV_CU_LIMIT = 0
+        assert torch.equal(budget, got), "the 256- and the 512-pixel tile must round identically"
+        base = torch.randn(n, cout, *hw).cuda()
+        acc = base.clone()
+        ops.conv2d(x.cuda(), pk, b.cuda(), cout, k, pad=k // 2, out=acc, accumulate=True)
+        close(acc, base.cpu() + conv, 2e-4)
+
+
 def test_conv_fp32_mfma_variant(ops):
     """The exact-fp32 kernel (v_mfma_f32_32x32x2_f32) stays available next to the split-bf16 default."""
     torch.manual_seed(11)
