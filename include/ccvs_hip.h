@@ -16,7 +16,9 @@
  *   - `stream` is a hipStream_t (passed as void*); launches are asynchronous on it;
  *   - return 0 on success, negative on error; ccvs_last_error() gives the message of the
  *     last failing call on this host thread;
- *   - no internal threads, no hidden state; safe from one host thread per device.
+ *   - no internal threads; host state = the thread-local error string, lazily set kernel attributes and the mutex-guarded
+ *     table of ccvs_stream_cu_limit.  Several host threads may launch on different streams of one device once every kind
+ *     of call has been made at least once from one thread (the pipelined schedule warms up that way).
  */
 #ifndef CCVS_HIP_H
 #define CCVS_HIP_H
