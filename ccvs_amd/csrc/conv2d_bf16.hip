@@ -669,12 +669,18 @@ __global__ __launch_bounds__(512, (MB == 1 && PP == 2) ? 4 : 2) void conv2d_bf16
             }                                                                                                          \
         }                                                                                                              \
     }
-                int tb = 0;
-                for (; tb + 2 <= ntx; tb += 2) {
-                    CB_TAP4(0, tb, true)
-                    CB_TAP4(1, tb + 1, (tb + 2 < ntx))
+                if constexpr (NTY == 3) {   // (written out: see the 256-pixel form below)
+                    CB_TAP4(0, 0, true)
+                    CB_TAP4(1, 1, true)
+                    CB_TAP4(0, 2, false)
+                } else {
+                    int tb = 0;
+                    for (; tb + 2 <= ntx; tb += 2) {
+                        CB_TAP4(0, tb, true)
+                        CB_TAP4(1, tb + 1, (tb + 2 < ntx))
+                    }
+                    if (tb < ntx) { CB_TAP4(0, tb, false) }
                 }
-                if (tb < ntx) { CB_TAP4(0, tb, false) }
 #undef CB_TAP4
             } else {
             // Software-pipelined fragment reads: the ds_reads of the NEXT 32-cout block (and, on a tap's last block,
@@ -715,12 +721,25 @@ __global__ __launch_bounds__(512, (MB == 1 && PP == 2) ? 4 : 2) void conv2d_bf16
     }
             CB_LD_B(0, 0)
             CB_LD_A(0, 0, 0)
-            int tb = 0;
-            for (; tb + 2 <= ntx; tb += 2) {
-                CB_TAP(0, 0, tb, true)
-                CB_TAP(1, (MB & 1), tb + 1, (tb + 2 < ntx))
+            if constexpr (NTY == 3) {
+                // 3 x 3 kernels (three taps per row, known at compile time): the tap loop is written out, so that no
+                // run-time branch sits between the fragment reads and the MFMAs.  In the loop form hipcc's wait-count pass
+                // puts `s_waitcnt lgkmcnt(0)` directly behind every prefetch (`ds_read x2; s_waitcnt lgkmcnt(0); v_mfma x6`:
+                // it waits for the reads it has JUST issued); written out, the waits sit 4-6 MFMAs behind the reads
+                // (+1...+3 % per shape).  Hand-counted waits with the reads as asm statements were tried and are 2.4 x
+                // SLOWER: with an LDS-DMA in flight (the next step's weights) hipcc drains vmcnt in front of every asm
+                // statement that might touch LDS.
+                CB_TAP(0, 0, 0, true)
+                CB_TAP(1, (MB & 1), 1, true)
+                CB_TAP(0, 0, 2, false)
+            } else {
+                int tb = 0;
+                for (; tb + 2 <= ntx; tb += 2) {
+                    CB_TAP(0, 0, tb, true)
+                    CB_TAP(1, (MB & 1), tb + 1, (tb + 2 < ntx))
+                }
+                if (tb < ntx) { CB_TAP(0, 0, tb, false) }
             }
-            if (tb < ntx) { CB_TAP(0, 0, tb, false) }
 #undef CB_LD_B
 #undef CB_LD_A
 #undef CB_TAP

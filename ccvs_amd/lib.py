@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libccvs_hip.so")
+# (CCVS_LIB: another build of the same library, for A/B measurements of kernel changes on one GPU box)
+LIB_PATH = os.environ.get("CCVS_LIB") or os.path.join(_HERE, "csrc", "libccvs_hip.so")
 
 # every symbol include/ccvs_hip.h declares
 EXPORTS = [
