@@ -333,15 +333,32 @@ __global__ __launch_bounds__(512, (MB == 1 && PP == 2) ? 4 : 2) void conv2d_bf16
 #pragma unroll
     for (int j = 0; j < NI; ++j) { vitem[j] = false; vin[j] = false; ve[j] = 0; vh[j] = 0; vptr[j] = xn; }
     if (xrole) {
-        const int n_items = IH * NQ * 2;
+        // Item order inside a half: column PAIR slowest, then the row, then the column of the pair -- 8 consecutive lanes =
+        // 2 neighbouring float4 columns x 4 rows.  Their ds_write_b128 still land in 8 different 16-byte slots modulo
+        // 128 B (slot = 4 q + r (4 NQ + 1) mod 8 with 4 NQ + 1 = 1 or 5 mod 8), and their global loads touch 4 cache lines
+        // instead of the 8 of the rows-fastest order (a wave-load: 32 lines instead of 64 for the texture addresser).
+        const int NQP = (NQ + 1) >> 1;                       // column pairs
+        const bool pairs = !(ablate & 8192);                 // 8192: the rows-fastest order of round 2
+        const int per_half = pairs ? NQP * IH * 2 : IH * NQ;
+        const int n_items = per_half * 2;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int it0_ = rt + NPX * j;
-            vitem[j] = it0_ < n_items;
             const int it = min(it0_, n_items - 1);
-            vh[j] = it / (IH * NQ);
-            const int rem = it - vh[j] * IH * NQ;
-            const int vq = rem / IH, vr = rem - vq * IH;  // rows fastest (see IWS)
+            vh[j] = it / per_half;
+            const int rem = it - vh[j] * per_half;
+            int vq, vr;
+            if (pairs) {
+                const int t = rem >> 1;
+                const int qh = t / IH;
+                vr = t - qh * IH;
+                vq = 2 * qh + (rem & 1);
+            } else {
+                vq = rem / IH;
+                vr = rem - vq * IH;
+            }
+            vitem[j] = it0_ < n_items && vq < NQ;
+            vq = min(vq, NQ - 1);
             const int gy = iy0 + vr, gxa = ix0 - xsh + 4 * vq;
             vin[j] = gy >= 0 && gy < p.Hin && gxa >= 0 && gxa < p.Win;  // aligned and Win % 4 == 0: all 4 pixels in or out
             vptr[j] = xn + (long)(8 * vh[j]) * p.in_sC + (vin[j] ? gy * p.Win + gxa : 0);
@@ -963,7 +980,7 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, int CinG, int
     // aligned float4 staging: dense stride-1 rows on 16-byte boundaries, one item per staging thread
     const int xsh = ((-k.pad % 4) + 4) % 4, nq = (xsh + halo_w + 3) / 4;
     const bool vec_ok = !k.transposed && k.stride == 1 && k.Win % 4 == 0 && k.in_sC % 4 == 0 && k.in_sN % 4 == 0 &&
-                        (reinterpret_cast<uintptr_t>(k.x) & 15) == 0 && TW >= 16 && halo_h * nq * 2 <= 256 && ntx_max <= (MB == 1 ? 9 : 3) &&
+                        (reinterpret_cast<uintptr_t>(k.x) & 15) == 0 && TW >= 16 && halo_h * ((nq + 1) / 2) * 4 <= 256 && ntx_max <= (MB == 1 ? 9 : 3) &&
                         (k.kh == 1 || k.kh == 3) && !(ablate & 4);
     if constexpr (TW == 32 && MB == 2) {
         // the 512-pixel tile (PP = 4, 16 x 32): 64 output channels, VEC staging, at least two tile rows of work.  Measured per
@@ -973,7 +990,7 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, int CinG, int
         static const int pp4 = getenv("CCVS_CONV_PP4") ? atoi(getenv("CCVS_CONV_PP4")) : 1;
         const int th4 = 16, halo_h4 = (th4 - 1) + k.kh;
         const size_t smem_4 = (size_t)(2 * 4 * halo_h4 * (nq * 4 + 1) + 2 * ntx_max * 4 * NT) * 16;
-        if (pp4 && vec_ok && !k.out_p8 && k.Hout >= 2 * th4 && halo_h4 * nq * 2 <= 512 && smem_4 <= 156 * 1024 && smem_4 >= (size_t)32 * 512 * 4) {
+        if (pp4 && vec_ok && !k.out_p8 && k.Hout >= 2 * th4 && halo_h4 * ((nq + 1) / 2) * 4 <= 512 && smem_4 <= 156 * 1024 && smem_4 >= (size_t)32 * 512 * 4) {
             k.tiles_y = cdiv(k.Hout, th4);
             const dim3 grid4(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
             const long total4 = (long)grid4.x * grid4.y * grid4.z;
