@@ -377,7 +377,7 @@ def main():
                 res = gen.run_pipelined(iter(batches), first_iter=first, cu_limit=args.cu_limit, finish=finish, lanes=args.lanes, chains=args.chains,
                                         ramp=ramp)
                 handles = [r["finished"] for r in res]
-                stages = gen.pipeline_stage_ms() if engine.is_main else {}
+                stages = gen.pipeline_stage_ms()       # every rank: the line reports the stages per rank
                 if engine.is_main:
                     stages["timeline"] = gen.pipeline_timeline()
             else:
@@ -386,9 +386,8 @@ def main():
                 for i, data in enumerate(batches):
                     out = gen.generate_vid(data, first + i)
                     handles.append(finish(first + i, out["fake"]))
-                    if engine.is_main:
-                        for k, v in gen.stage_ms().items():
-                            stages[k] += v
+                    for k, v in gen.stage_ms().items():
+                        stages[k] += v
             clips = None
             for h in handles:
                 clips = h.wait()
