@@ -1101,7 +1101,12 @@ extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const flo
     const int gz = d->N * (d->transposed ? 4 : 1);
     CCVS_REQUIRE(gz <= 65535, "ccvs_conv2d_bf16x3: batch %d too large for one launch", d->N);
     hipStream_t st = (hipStream_t)stream;
-    const int mb = (d->CoutPad % 128 == 0) ? 4 : ((d->CoutPad % 64 == 0) ? 2 : 1);
+    int mb = (d->CoutPad % 128 == 0) ? 4 : ((d->CoutPad % 64 == 0) ? 2 : 1);
+    // Small launches (the 8 x 8 ... 32 x 32 levels of the encoder / decoder at 16 images: one or four pixel tiles per image):
+    // with 128 output channels per workgroup they are 16-64 workgroups walking the whole K depth alone on a quarter of the
+    // chip.  Narrower channel blocks give the same tiles to 2-4 x as many workgroups (same arithmetic per output, bit-identical).
+    static const int small_split = getenv("CCVS_CONV_SMALL_SPLIT") ? atoi(getenv("CCVS_CONV_SMALL_SPLIT")) : 256;   // workgroups aimed at; 0: off
+    while (mb > 1 && (long)k.tiles_x * k.tiles_y * gz * (d->CoutPad / (32 * mb)) < small_split) mb >>= 1;
 #define CB_DISPATCH(TWv)                                                                                        \
     if (mb == 4) return launch_conv_bf16<TWv, 4>(k, w_split, CinG, halo_h, halo_w, ntx_max, gz, st);           \
     if (mb == 2) return launch_conv_bf16<TWv, 2>(k, w_split, CinG, halo_h, halo_w, ntx_max, gz, st);           \
