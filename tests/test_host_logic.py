@@ -1,0 +1,73 @@
+"""not gpu: host-side logic of the path that needs no device -- the sliding token windows of `Transformer.generate_fake`
+(transformer_model.py:301-326), the token-group sizing of `Generator.run_pipelined`, the merged frame / ancillary token order of
+`GPT.stream_kinds` (mingpt.py:246-282) against the oracle's merge, and the reference launch-line presets."""
+import types
+
+import pytest
+import torch
+
+from oracle import ccvs_oracle as O
+
+
+def _transformer_stub(z_len, z_chunk):
+    from ccvs_amd.models.skip_vid_generator.models.transformer_model import Transformer
+    t = Transformer.__new__(Transformer)          # no networks: only the window arithmetic is exercised
+    t.opt = types.SimpleNamespace(z_len=z_len, z_chunk=z_chunk)
+    return t
+
+
+@pytest.mark.parametrize("z_len,z_chunk,total", [(1280, 80, 3600), (1024, 64, 1024 + 64 * 3 + 10), (256, 66, 300), (192, 64, 193)])
+def test_token_windows_match_the_reference_loop(z_len, z_chunk, total):
+    """`token_windows` against the reference's own bookkeeping (curr_len / add_len / i of transformer_model.py:301-326)."""
+    want, curr, i = [], z_len, 1
+    while curr < total:
+        add = total - curr if total - curr < z_chunk else None
+        want.append((i, add))
+        curr += add if add is not None else z_chunk
+        i += 1
+    assert list(_transformer_stub(z_len, z_chunk).token_windows(total)) == want
+    assert sum(z_chunk if a is None else a for _, a in want) == total - z_len
+
+
+def test_token_group_size_rules():
+    """Stacked rows fit one weight pass (64) and one decode step (256); host-drawn noise and beam search are never stacked."""
+    from ccvs_amd.helpers.generator import Generator
+    g = Generator.__new__(Generator)
+    g.opt = types.SimpleNamespace(sample=True, beam_size=None)
+    g.transformer_model = types.SimpleNamespace(sample_noise="device")
+    assert g._token_group_size(16, 3) == 3 and g._token_group_size(16, 8) == 4 and g._token_group_size(64, 3) == 1
+    assert g._token_group_size(5, 3) == 3 and g._token_group_size(100, 3) == 1
+    g.transformer_model.sample_noise = "host"
+    assert g._token_group_size(16, 3) == 1            # one generator stream per batch, in the reference's order
+    g.opt.sample = False
+    assert g._token_group_size(16, 3) == 3            # greedy: nothing is drawn
+    g.opt.beam_size = 4
+    assert g._token_group_size(16, 3) == 1
+
+
+@pytest.mark.parametrize("n_code,n_state", [(64 * 3, 16 * 3), (64 * 2 + 5, 16 * 3), (64 * 15 + 5, 16 * 16), (64, 16)])
+def test_stream_kinds_equal_the_oracle_merge(n_code, n_state):
+    """The merged sequence order the KV-cached engine walks (`GPT.stream_kinds`) is the oracle's `gpt_merge_state` order
+    (mingpt.py:258-282): checked by merging index-carrying embeddings."""
+    from ccvs_amd.models.skip_vid_generator.models.mingpt import GPT
+    net = GPT.__new__(GPT)
+    net.config = types.SimpleNamespace(shape=[8, 8], state_size=16, num_blocks=16, state_front=False)
+    kinds = GPT.stream_kinds(net, n_code, n_state)
+    cfg = O.namespace(z_shape=[8, 8], state_size=16, state_front=False)
+    emb = torch.arange(n_code, dtype=torch.float32).view(1, n_code, 1)                 # frame token i carries +i
+    semb = -(torch.arange(n_state, dtype=torch.float32) + 1).view(1, n_state, 1)        # ancillary token i carries -(i+1)
+    merged = O.gpt_merge_state(cfg, emb, semb)[0, :, 0].tolist()
+    got = [float(i) if k == 0 else -(float(i) + 1) for k, i in kinds]
+    assert got == merged
+
+
+def test_reference_launch_line_presets():
+    from ccvs_amd.tools.options import Options, DRUMS_ARGV, BAIR_P2P_ARGV, KINETICS_ARGV
+    d = Options().parse(load_qvid_generator=True, load_transformer=True, load_stft_ae=True, argv=list(DRUMS_ARGV))
+    x, q, a = d["transformer"], d["qvid_generator"], d["stft_ae"]
+    assert (x.vid_len, x.cond_len, x.z_len, x.z_chunk, x.state_size, x.num_blocks) == (45, 960, 1280, 80, 16, 16) and x.stft and x.keep_state
+    assert q.keep_first and q.n_first == 8 and q.max_dim == 128 and q.aspect_ratio == 1 and a.stft_shape == [8, 2] and a.stft_hsize == 512
+    p = Options().parse(load_qvid_generator=True, load_transformer=True, argv=list(BAIR_P2P_ARGV))["transformer"]
+    assert p.p2p and p.vid_len == 16 and p.cond_len == 64
+    k = Options().parse(load_qvid_generator=True, load_transformer=True, argv=list(KINETICS_ARGV))["transformer"]
+    assert k.z_num == 16384 and k.cond_len == 320
