@@ -442,7 +442,9 @@ class GPT(nn.Module):
             parts.append(ops.gpt_embed(cond_idx.contiguous(), self._token_table(), table, 0, off).view(b, t_cond, C))
         else:
             t_cond = 0
-        parts.append(ops.gpt_embed(idx.contiguous(), self._token_table(), c["pos_table"], 0).view(b, t, C))
+        if t > 0:   # (t == 0: unconditional generation, scripts/bairhd/save_videos_unc.sh -- the start token alone opens the sequence)
+            parts.append(ops.gpt_embed(idx.contiguous(), self._token_table(), c["pos_table"], 0).view(b, t, C))
+        assert parts, "nothing to run: no frame token, no conditioning prefix, no start / label token"
         x = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
         tq = n_pre + t_cond + t
         assert c["len"] == 0 and tq <= c["T"], "Cannot forward, model block size is exhausted."

@@ -308,3 +308,35 @@ def test_start_and_label_tokens_golden(golden_dir):
     assert torch.equal(out.cpu(), torch.from_numpy(g["greedy"]))
     out = tr({"code": code[:, :64].clone(), "vid_lbl": lbl.clone()}, mode="inference", total_len=74)["code"]
     assert torch.equal(out.cpu(), torch.from_numpy(g["greedy"]))
+
+
+def test_unconditional_generation_vs_oracle():
+    """scripts/bairhd/save_videos_unc.sh: `--x_cond_len 0 --x_use_start_token` -- NO conditioning frame: the token loop starts
+    from the start token alone (an empty code tensor), the decoder's first frame has no context (`has_ctx=False`) and the ring
+    fills from the synthesized frames.  Greedy tokens and pixels against the oracle, fresh weights."""
+    from ccvs_amd.tools.options import Options
+    from ccvs_amd.helpers.generator import Generator
+    opt = Options().parse(load_qvid_generator=True, load_transformer=True,
+                          argv=TINY_ARGV + ["--x_use_start_token", "--x_cond_len", "0", "--x_top_k", "10"])
+    xopt, qopt = opt["transformer"], opt["qvid_generator"]
+    xopt.sample, xopt.rec_pass = False, False
+    torch.manual_seed(5)
+    gen = Generator(opt).build_models()
+    with torch.no_grad():
+        net = gen.transformer_model.net_t
+        for p_ in (net.s_emb, net.t_emb):
+            p_.normal_(0, 0.02)
+        vid = gen.synthetic_batch(2, seed=71)["vid"]
+        z_e, _ = gen.vid_model.net_e(vid[:, :1].cuda())
+        cb = gen.vid_model.net_q.embedding.weight
+        cb.copy_(torch.randn(cb.shape, generator=torch.Generator().manual_seed(4)).cuda() * z_e.std())
+    out = gen.generate_vid({"vid": vid.clone()})
+    cpu = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    nets = {"e": cpu(gen.vid_model.net_e), "q": cpu(gen.vid_model.net_q), "g": cpu(gen.vid_model.net_g), "t": cpu(gen.transformer_model.net_t)}
+    with torch.no_grad():
+        want = O.generate_vid(nets, qopt, xopt, vid)
+    assert out["fake"]["code"].shape == want["code"].shape == (2, xopt.vid_len * 64)
+    assert torch.equal(out["fake"]["code"].cpu(), want["code"]), "greedy tokens from the start token alone differ from the oracle"
+    assert out["fake"]["vid"].shape == want["vid"].shape
+    assert maxdiff(out["fake"]["vid"], want["vid"]) < PIX_TOL
+

@@ -71,3 +71,35 @@ def test_output_stage_vs_reference_save_video_batch(ref, tmp_path):
     got.clear()
     g.save_video_batch(vid.clone(), 2, 0, str(tmp_path), 4, True, True, [-1, 1], "kinetics600")
     assert torch.equal(torch.stack([v for _, v in got]), O.pack_u8_imagenet(vid))
+
+
+def _script_argv(path):
+    import re
+    import shlex
+    body = open(path).read().split("helpers/generator.py", 1)[1].replace("\\\n", " ")
+    return shlex.split(re.sub(r"\$\{GPU_IDS\}", "0", body))
+
+
+def test_every_reference_save_script_parses_like_the_reference(ref):
+    """The flags of all nine `scripts/*/save_videos*.sh` launch lines: the product's `Options` must accept them (training-only
+    flags ignored) and give the fields the synthesis path reads the values the reference's own parser gives."""
+    import glob
+    from ccvs_amd.tools.options import Options
+    scripts = sorted(glob.glob(os.path.join(rh.REF_ROOT, "scripts", "*", "save_videos*.sh")))
+    assert len(scripts) >= 9
+    x_fields = ["vid_len", "cond_len", "z_len", "z_chunk", "z_num", "z_shape", "state_size", "state_num", "num_blocks", "top_k", "temperature",
+                "sample", "p2p", "stft", "state", "keep_state", "use_start_token", "cat", "n_layer", "n_head", "n_embd", "emb_mode",
+                "sample_state", "top_k_state", "temperature_state", "batch_size_vid", "max_dim", "aspect_ratio", "fps", "imagenet_norm"]
+    q_fields = ["necf", "necf_mult", "z_num", "z_size", "z_shape", "skip_context", "skip_memory", "keep_first", "n_first", "use_inter", "inter_p",
+                "max_dim", "aspect_ratio", "vid_len", "use_ema"]
+    for path in scripts:
+        argv = _script_argv(path)
+        want = rh.parse_reference_options(argv)
+        got = Options().parse(load_qvid_generator=True, load_transformer=True, load_state_estimator=True, load_stft_ae=True, argv=argv)
+        for key, fields in (("transformer", x_fields), ("qvid_generator", q_fields)):
+            for f in fields:
+                if hasattr(want[key], f):
+                    assert getattr(got[key], f) == getattr(want[key], f), (os.path.basename(path), key, f, getattr(got[key], f), getattr(want[key], f))
+        if want.get("stft_ae") is not None and "--x_stft" in argv:
+            for f in ("stft_num", "stft_size", "stft_hsize", "stft_shape"):
+                assert getattr(got["stft_ae"], f) == getattr(want["stft_ae"], f), (path, f)
