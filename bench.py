@@ -499,6 +499,12 @@ def main():
                              "clock_note": "GRBM cycles / time = 2.0 GHz under this kernel (power-limited), i.e. a 2083 TF/s bf16 ceiling",
                              "share_of_step_time": (shared["share_of_step_time"] if shared else conv_ms * 1e-3 / elapsed)},
             }
+            tl = stage.get("timeline")
+            if tl:   # the price of the schedule: a batch is in flight from its encode to the end of its decode
+                lat = [t["d1"] - t["e0"] for t in tl]
+                line["latency_ms_per_batch"] = {"mean": sum(lat) / len(lat), "max": max(lat),
+                                                "note": "encode start to decode end of one batch (HIP events); the serial schedule's is its step time"}
+            line["hbm_peak_allocated_gb"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30   # every batch in flight + weights + graphs' pools (torch allocator)
             # the token loop as a whole, in situ: weights ONCE per step of a token group + the keys and values of every batch in it,
             # against the HBM peak
             net_t = gen.transformer_model.net_t

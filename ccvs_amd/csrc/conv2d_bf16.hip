@@ -1084,6 +1084,8 @@ extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const flo
     k.pre = d->pre; k.pre_sN = d->pre_sN; k.pre_sC = d->pre_sC; k.pre_div = d->pre_div > 0 ? d->pre_div : 1;
     k.in_p8 = d->in_p8 ? 1 : 0; k.out_p8 = d->out_p8 ? 1 : 0;
     k.nwork = 0; k.gx = k.gy = 1; k.work0 = 0; k.xcd_chunk = 0; k.cu_limit = d->cu_limit > 0 ? d->cu_limit : ccvs_cu_limit_of(stream);
+    static const int pre_order = getenv("CCVS_CONV_PRE_ORDER") ? atoi(getenv("CCVS_CONV_PRE_ORDER")) : 1;   // 0: image-major tiles for every launch
+    k.zi = (pre_order && d->pre && k.pre_div > 1 && !d->transposed && d->N % k.pre_div == 0) ? k.pre_div : 0;
     if (k.in_p8) CCVS_REQUIRE(!d->transposed && d->stride == 1 && d->Cin % 8 == 0, "ccvs_conv2d_bf16x3: packed input needs stride 1, Cin %% 8 == 0");
     if (k.out_p8) CCVS_REQUIRE(!d->transposed && d->Cout % 8 == 0 && !d->accumulate && !residual, "ccvs_conv2d_bf16x3: packed output needs Cout %% 8 == 0, no residual / accumulate");
     const int CinG = 2 * ((d->Cin + 15) / 16);  // 8-channel groups, Cin padded to 16

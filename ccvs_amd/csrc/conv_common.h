@@ -26,6 +26,7 @@ struct ConvK {
     int nwork, gx, gy, work0;
     int xcd_chunk;  // XCD-aware order of the tiles of one launch (see CONV_TILE_COORDS)
     int cu_limit;  // host side only: CUs this launch may occupy (0 = classic 3-D grid over all of them)
+    int zi;        // > 1: the zi images that share one `pre` image run back to back per tile (see CONV_TILE_COORDS)
 };
 
 // Tile coordinates of a workgroup.  Workgroups are handed to the 8 XCDs round-robin in dispatch order (linear id % 8), and
@@ -33,6 +34,10 @@ struct ConvK {
 // are all fetched through OTHER L2s.  The linear id is therefore re-mapped so that XCD j walks the j-th contiguous eighth
 // of the tile sequence (x fastest within an image): neighbouring tiles then meet in the same L2, at about the same time.
 // (xcd_chunk = tiles / 8 when that divides, else 0 = identity; correctness does not depend on the placement.)
+// zi > 1 (a launch whose epilogue adds `pre[n / pre_div]`, zi = pre_div images per `pre` image): the sequence is
+// (image group, tile, image of the group) with the image fastest, so the zi workgroups that read one tile of `pre` run back to
+// back on one XCD and 14 of 15 of those reads hit its L2 -- image-major, they were a whole image of tiles (tens of MB) apart and
+// every one of them went to HBM: 8 GB of the 22 GB the first Subpixel convolution of a 256 x 256 frame moved.
 #define CONV_TILE_COORDS(p, bx, by, bz)                                         \
     int bx, by, bz;                                                             \
     {                                                                           \
@@ -40,10 +45,19 @@ struct ConvK {
                                : (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)); \
         if ((p).xcd_chunk > 0) w_ = (w_ & 7) * (p).xcd_chunk + (w_ >> 3);       \
         w_ += (p).work0;                                                        \
-        bx = w_ % (p).gx;                                                       \
-        const int r_ = w_ / (p).gx;                                             \
-        by = r_ % (p).gy;                                                       \
-        bz = r_ / (p).gy;                                                       \
+        if ((p).zi > 1) {                                                       \
+            const int per_ = (p).gx * (p).gy * (p).zi;                          \
+            const int g_ = w_ / per_, q_ = w_ - g_ * per_;                      \
+            const int t_ = q_ / (p).zi;                                         \
+            bz = g_ * (p).zi + (q_ - t_ * (p).zi);                              \
+            bx = t_ % (p).gx;                                                   \
+            by = t_ / (p).gx;                                                   \
+        } else {                                                                \
+            bx = w_ % (p).gx;                                                   \
+            const int r_ = w_ / (p).gx;                                         \
+            by = r_ % (p).gy;                                                   \
+            bz = r_ / (p).gy;                                                   \
+        }                                                                       \
     }
 
 struct AxisTaps {

@@ -156,6 +156,30 @@ def test_conv_tall_tile_shapes(ops, cin, cout, k, kw, hw):
         close(acc, base.cpu() + conv, 2e-4)
 
 
+@pytest.mark.parametrize("cin,cout,hw,n,div", [(99, 128, (64, 64), 6, 3), (35, 64, (40, 64), 10, 5), (19, 32, (32, 32), 4, 2), (195, 128, (16, 16), 30, 15)])
+def test_conv_shared_pre_image_tile_order(ops, cin, cout, hw, n, div):
+    """The first Subpixel convolution adds `pre[n // pre_div]` in its epilogue (skip_autoencoder.py:224: the `dec` block of the
+    input is the same for the k contexts of a frame).  Launches of that kind walk their tiles (image group, tile, image): every
+    image and tile must still be computed exactly once -- against torch, and with a CU budget (chunked 1-D launches over the same
+    sequence)."""
+    torch.manual_seed(cin + n)
+    x = torch.randn(n, cin, *hw)
+    w = torch.randn(cout, cin, 3, 3)
+    b = torch.randn(cout)
+    pre = torch.randn(n // div, cout, *hw)
+    want = torch.nn.functional.conv2d(x, w * (1 / math.sqrt(cin * 9)), bias=b, padding=1) + pre.repeat_interleave(div, dim=0)
+    want = torch.nn.functional.leaky_relu(want, 0.1)
+    pk = ops.pack_conv_weight(w.cuda())
+    got = ops.conv2d(x.cuda(), pk, b.cuda(), cout, 3, pad=1, act=True, pre=pre.cuda(), pre_div=div)
+    close(got, want, 2e-4)
+    ops.CONV_CU_LIMIT = 5
+    try:
+        budget = ops.conv2d(x.cuda(), pk, b.cuda(), cout, 3, pad=1, act=True, pre=pre.cuda(), pre_div=div)
+    finally:
+        ops.CONV_CU_LIMIT = 0
+    assert torch.equal(budget, got)
+
+
 def test_conv_fp32_mfma_variant(ops):
     """The exact-fp32 kernel (v_mfma_f32_32x32x2_f32) stays available next to the split-bf16 default."""
     torch.manual_seed(11)
