@@ -631,6 +631,47 @@ def pack_u8_norm(vid, std, mean):
     return out
 
 
+def psnr(x, y, data_range=1.0):
+    """Per-image PSNR of [N, C, H, W] fp32 tensors, piq.psnr's formula (tools/pytorch_metrics/metrics.py:24-25): [N] fp32."""
+    _need_gpu(x, y)
+    assert x.shape == y.shape and x.dim() == 4 and x.dtype == y.dtype == torch.float32, (x.shape, y.shape)
+    x, y = x.contiguous(), y.contiguous()
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().ccvs_psnr(_p(x), _p(y), _p(out), x.shape[0], x[0].numel(), float(data_range), _stream()), "ccvs_psnr")
+    return out
+
+
+def ssim_planes(x, y, data_range=2.0):
+    """skimage 0.17.2 `structural_similarity` (defaults) of every 2-D plane of [..., H, W] fp32 tensors: [...] fp64
+    (tools/pytorch_metrics/metrics.py:15-22; data_range 2 = what skimage takes for float planes when none is given)."""
+    _need_gpu(x, y)
+    assert x.shape == y.shape and x.dim() >= 2 and x.dtype == y.dtype == torch.float32, (x.shape, y.shape)
+    x, y = x.contiguous(), y.contiguous()
+    h, w = x.shape[-2:]
+    planes = x.numel() // (h * w)
+    out = torch.empty(planes, dtype=torch.float64, device=x.device)
+    L = _lib.load()
+    step = 65535   # planes per call
+    ws = torch.empty(int(L.ccvs_ssim_workspace_bytes(min(planes, step), h, w)), dtype=torch.uint8, device=x.device)
+    xf, yf = x.view(planes, h, w), y.view(planes, h, w)
+    for p0 in range(0, planes, step):
+        n = min(step, planes - p0)
+        _lib.check(L.ccvs_ssim(_p(xf[p0:]), _p(yf[p0:]), _p(out[p0:]), _p(ws), n, h, w, float(data_range), _stream()), "ccvs_ssim")
+    return out.view(x.shape[:-2])
+
+
+def resize_bilinear(x, size):
+    """F.interpolate(x, size=size, mode='bilinear') (align_corners False) of [..., H, W] fp32 (tools/pytorch_metrics/metrics.py:124)."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.dim() >= 2
+    x = x.contiguous()
+    h, w = x.shape[-2:]
+    oh, ow = int(size[0]), int(size[1])
+    out = torch.empty(*x.shape[:-2], oh, ow, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().ccvs_resize_bilinear(_p(x), _p(out), x.numel() // (h * w), h, w, oh, ow, _stream()), "ccvs_resize_bilinear")
+    return out
+
+
 def pack_u8(vid, lo=-1.0, hi=1.0):
     """[..., 3, H, W] fp32 -> [..., H, W, 3] uint8 (helpers/generator.py:306-309)."""
     _need_gpu(vid)

@@ -319,6 +319,22 @@ int ccvs_pack_u8(const float* vid, uint8_t* out, int64_t N, int32_t H, int32_t W
 int ccvs_pack_u8_norm(const float* vid, uint8_t* out, int64_t N, int32_t H, int32_t W, const float* std3, const float* mean3,
                       void* stream);
 
+/* ---- evaluation metrics on the produced clips --------------------------------
+ * tools/pytorch_metrics/metrics.py:24-25 get_psnr = piq.psnr(x, y, data_range=1., reduction='mean') (piq 0.5.4): per image
+ * -10 log10(mean((x/R - y/R)^2) + 1e-8); out[N] fp32 (the caller takes the mean).  x, y: [N, per_image] fp32. */
+int ccvs_psnr(const float* x, const float* y, float* out, int64_t N, int64_t per_image, float data_range, void* stream);
+/* tools/pytorch_metrics/metrics.py:15-22 get_ssim = skimage.metrics.structural_similarity on every 2-D plane x[i, c], y[i, c]
+ * with scikit-image 0.17.2's defaults: 7 x 7 uniform window, sample covariance, K1 = 0.01, K2 = 0.03, float64 arithmetic,
+ * mean over the windows inside the plane; data_range is the caller's (the reference passes float planes and no data_range,
+ * for which skimage 0.17.2 takes the dtype's span: 2).  x, y: [planes, H, W] fp32; out[planes] fp64;
+ * workspace: ccvs_ssim_workspace_bytes(planes, H, W) bytes of device memory. */
+int64_t ccvs_ssim_workspace_bytes(int64_t planes, int32_t H, int32_t W);
+int ccvs_ssim(const float* x, const float* y, double* out, void* workspace, int64_t planes, int32_t H, int32_t W, double data_range,
+              void* stream);
+/* tools/pytorch_metrics/metrics.py:115-124 `upscale`: F.interpolate(frames, size=(OH, OW), mode='bilinear') (align_corners
+ * False) of [planes, H, W] fp32 planes, in torch's own formulation (source index, blend order). */
+int ccvs_resize_bilinear(const float* x, float* out, int64_t planes, int32_t H, int32_t W, int32_t OH, int32_t OW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
