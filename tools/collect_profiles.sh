@@ -20,7 +20,7 @@ for SCHED in pipelined serial; do
   rm -rf /tmp/prof_$SCHED
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$SCHED -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strict-f32 --schedule $SCHED > /tmp/prof_$SCHED.log 2>&1
   cp $(ls /tmp/prof_$SCHED/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_${SCHED}_kernel_stats.csv
-  tail -1 /tmp/prof_$SCHED.log > $OUT/${TAG}_bench_${SCHED}_under_rocprof.json
+  grep "^{" /tmp/prof_$SCHED.log | tail -1 > $OUT/${TAG}_bench_${SCHED}_under_rocprof.json
 done
 unset CCVS_BENCH_SUPERVISE
 SHAPE="195 128 3 256 240" timeout 900 bash $ROOT/tools/pmc_conv_counters.sh > $OUT/${TAG}_pmc_conv_counters.txt 2>&1
