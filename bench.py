@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--ramp", type=str, default=None, help="pipelined: sizes of the first token groups, e.g. 1,2 (then --lanes)")
     ap.add_argument("--no-strict-f32", action="store_true", help="skip the exact-fp32-convolution leg reported as strict_f32 (2 serial batches after the timed region)")
     ap.add_argument("--rec-pass", action="store_true", help="also run the reference's teacher-forced reconstruction decode (not counted)")
+    ap.add_argument("--encode", choices=["cond", "all"], default="all",
+                    help="frames of the input clip the encoder sees: all of them, as the reference's generate_vid does (default; its rec pass reads those "
+                         "codes), or only the conditioning frames synthesis reads (the default line carries that figure as `encode_cond_only`)")
+    ap.add_argument("--no-encode-cond-leg", action="store_true", help="skip the second timed pass (same K batches) with only the conditioning frames encoded")
     return ap.parse_args()
 
 
@@ -152,7 +156,8 @@ def build_generator(args):
     from ccvs_amd.helpers.generator import Generator
     argv = list({"bair": BAIR_ARGV, "kinetics": KINETICS_ARGV, "bair-p2p": BAIR_P2P_ARGV, "drums": DRUMS_ARGV}[args.config])
     # the teacher-forced "rec" decode of the REAL codes is not part of the metric (synthesized frames only)
-    argv += ["--batch_size_vid", str(args.batch), "--x_sample_noise", args.sample_noise, "--rec_pass", "true" if args.rec_pass else "false"]
+    argv += ["--batch_size_vid", str(args.batch), "--x_sample_noise", args.sample_noise, "--rec_pass", "true" if args.rec_pass else "false",
+             "--encode_all", "true" if args.encode == "all" else "false"]
     opt = Options().parse(load_qvid_generator=True, load_transformer=True, load_stft_ae=(args.config == "drums"), argv=argv)
     torch.manual_seed(0)  # reference initialisers under seed 0
     with contextlib.redirect_stdout(sys.stderr):   # "Loading untrained ... net": stdout carries the ONE JSON line only
@@ -448,6 +453,7 @@ def main():
             # bf16x3: three bf16 MFMA products per algorithmic fp32 product; peak = dense bf16 MFMA
             peak = BF16_MFMA_PEAK_TFLOPS if kind == "bf16x3" else FP32_MFMA_PEAK_TFLOPS
             products = 3 if kind == "bf16x3" else 1
+            n_enc = gen._frames_to_encode(xopt.vid_len, int(torch.prod(torch.tensor(opt["qvid_generator"].z_shape))))
             line = {
                 "metric": {"bair": "synthesized frames/sec (BAIR 256x256, cond=1, pred=15), whole job",
                            "kinetics": "synthesized frames/sec (Kinetics-600 64x64, cond=5, pred=11), whole job",
@@ -464,6 +470,8 @@ def main():
                                         "drums": "AudioSet-Drums 128x128 audio-conditioned, 15 -> 30 frames, STFT tokens given (BASELINE.json configs[4], "
                                                  "scripts/drums/save_videos_audio_on.sh)"}[args.config], "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                            "predicted_frames_per_clip": predicted,
+                           "encode": (f"all {xopt.vid_len} frames of every input clip, as the reference's generate_vid does (helpers/generator.py:69)" if n_enc == xopt.vid_len
+                                      else f"the {n_enc} conditioning frame(s) per clip that synthesis reads (`--encode cond`)"),
                            "rec_pass": ("also run, not counted" if args.rec_pass else "off: the reference's extra teacher-forced reconstruction decode is not part of "
                                         "the synthesized-frames metric (SURVEY 8d)"), "sampling": f"top-k {xopt.top_k}, T={xopt.temperature}, noise={args.sample_noise}",
                            "schedule": (f"pipelined: up to {gen.last_lanes * gen.last_chains + 1} batches in flight per GPU -- {gen.last_chains} token loops on "
@@ -536,6 +544,25 @@ def main():
                                  "stage_ms_per_step_by_rank": rank_stages,
                                  "host_threads_per_rank": {"torch_intra_op": torch.get_num_threads(), "launch_threads": 1 + (gen.last_chains if args.schedule == "pipelined" else 0)},
                                  "scaling_curve": "not measured by this run: one line per N; the driver derives efficiency from the N = 1, 2, 4, 8 lines (tools/scale_sweep.sh runs them)"}
+            if args.encode == "all" and args.config == "bair" and world == 1 and not args.no_encode_cond_leg and not args.rec_pass:
+                # the same K batches and schedule with only the conditioning frame of every clip encoded: synthesis reads nothing else
+                # ("from conditioning frames resident on GPU"); the reference also encodes the 15 frames it is about to
+                # replace, for its rec pass, and that is what `value` above includes.  Reported beside it, never as `value`.
+                xopt.encode_all = False
+                try:
+                    run(4000, [make_batch(4000 + w) for w in range(max(1, min(args.warmup, 3)))])   # untimed
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    _, stage_c = run(5000, batches)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    line["encode_cond_only"] = {"value": frames / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / args.steps,
+                                                "stage_ms_per_step": {k: v / args.steps for k, v in stage_c.items() if k != "timeline"},
+                                                "frames_encoded_per_clip": gen._frames_to_encode(xopt.vid_len, int(torch.prod(torch.tensor(opt["qvid_generator"].z_shape)))),
+                                                "note": f"same {args.steps} batches and schedule, `--encode_all false`: the encoder sees the conditioning frame(s) only; "
+                                                        "the synthesized clips are the same bits (tests/test_features_gpu.py::test_encode_conditioning_frames_only)"}
+                finally:
+                    xopt.encode_all = True
             if args.config == "bair" and world == 1 and not args.conv_precision and not args.no_strict_f32:
                 # the same path with EXACT fp32 convolutions (v_mfma_f32_32x32x2_f32 instead of the split-bf16 products), serial
                 # schedule, outside the timed region: what the arithmetic choice of `dtype` buys, in the driver's own line

@@ -127,14 +127,23 @@ class Generator:
             img = F.interpolate(img, size=opt.down_size, mode='bilinear')
             img = F.interpolate(img, size=vid.shape[-2:], mode='bilinear')
             data["vid"] = img.view(bs, t, *vid.shape[2:])
-        encoded_data = self.vid_model(data, mode='vid_encoder')            # encode all frames
+        size = int(torch.prod(torch.tensor(qopt.z_shape)))
+        n_keep = self._frames_to_encode(data["vid"].shape[1], size)
+        if n_keep < data["vid"].shape[1]:                                   # --encode_all false: the conditioning frames only
+            enc_in = {k: v for k, v in data.items() if k != "vid"}
+            enc_in["vid"] = data["vid"][:, :n_keep].contiguous()
+            encoded_data = self.vid_model(enc_in, mode='vid_encoder')
+            data["vid"] = data["vid"].cuda()
+        else:
+            encoded_data = self.vid_model(data, mode='vid_encoder')        # encode all frames
+        n_frames = data["vid"].shape[1]                                     # the crops below are fractions of the WHOLE clip
         if opt.state:                                                       # generator.py:73-77: estimate + quantise the state
             encoded_data.update(self.state_model(encoded_data, mode='vid_encoder'))
             data.update(self.state_model(encoded_data, mode='vid_decoder'))
         if opt.stft:                                                        # generator.py:78-80
             encoded_data.update(self.stft_model(data, mode='vid_encoder'))
 
-        size = int(torch.prod(torch.tensor(qopt.z_shape)))                  # generator.py:83-102
+        # generator.py:83-102
         cond_step, t_step = (1, opt.vid_len - 1) if opt.p2p else (0, opt.vid_len)
         total_len = (cond_step + t_step) * size
         cond_len = cond_step * size
@@ -145,8 +154,8 @@ class Generator:
         else:
             crop_prop = opt.cond_len / (size * opt.vid_len)
         cropped = {}
-        cropped["code"] = encoded_data["code"][:, :int(crop_prop * encoded_data["code"].size(1))]
-        encoded_data["inter"] = [feat[:, :int(crop_prop * feat.size(1))].contiguous() for feat in encoded_data["inter"]]
+        cropped["code"] = encoded_data["code"][:, :int(crop_prop * (size * n_frames if n_keep < n_frames else encoded_data["code"].size(1)))]
+        encoded_data["inter"] = [feat[:, :int(crop_prop * (n_frames if n_keep < n_frames else feat.size(1)))].contiguous() for feat in encoded_data["inter"]]
         cropped["inter"] = encoded_data["inter"]
         if opt.p2p:
             cropped["cond_code"] = encoded_data["code"][:, -opt.z_chunk:]
@@ -170,6 +179,19 @@ class Generator:
             cropped["vid_lbl"] = data["vid_lbl"]
         return {"data": data, "encoded": encoded_data, "cropped": cropped, "total_len": total_len, "cond_len": cond_len,
                 "crop_prop": crop_prop}
+
+    def _frames_to_encode(self, n_frames, size):
+        """Frames of the input clip the encoder has to see.  The reference encodes all of them (generator.py:69); with
+        `--encode_all false` only those the conditioning crop keeps (generator.py:93-99: the first crop_prop of the codes and of
+        the skip features) -- when nothing else reads the rest: no rec pass, no state / audio stream estimated from the clip, no
+        end frame (point-to-point), no single-image mode."""
+        opt = self.opt
+        if getattr(opt, "encode_all", True) or getattr(opt, "rec_pass", True) or opt.rec_only or opt.state or opt.stft or opt.p2p or opt.gen_from_img:
+            return n_frames
+        crop_prop = opt.cond_len / (size * opt.vid_len)
+        n_code = -(-int(crop_prop * size * n_frames) // size)             # frames holding the kept tokens
+        n_inter = int(crop_prop * n_frames)                                # frames of skip features kept
+        return min(n_frames, max(1, n_code, n_inter))
 
     @torch.no_grad()
     def decode_codes(self, ws, code, state_code=None):

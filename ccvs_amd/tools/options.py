@@ -71,6 +71,11 @@ class Options:
         # (helpers/generator.py:172-189); on by default like the reference, switchable because it is not part of the
         # synthesized-frames metric
         _flag(p, "--rec_pass", default=True)
+        # (ccvs_amd) the reference encodes EVERY frame of the input clip (helpers/generator.py:69) although synthesis reads the
+        # conditioning frames only -- the other codes feed its rec pass and `enc_code`.  `--encode_all false`: with the rec pass
+        # off and no state / audio / point-to-point conditioning, encode just the frames the conditioning crop keeps (the same
+        # bits for `fake`: frames are encoded independently); `enc_code` then holds those frames' codes only.
+        _flag(p, "--encode_all", default=True)
         # ---- q_: quantised video model (tools/options.py:159-264)
         p.add_argument("--q_enc_model", type=str, default="taming")
         p.add_argument("--q_dec_model", type=str, default="stylegan2")

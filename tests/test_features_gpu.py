@@ -340,3 +340,34 @@ def test_unconditional_generation_vs_oracle():
     assert out["fake"]["vid"].shape == want["vid"].shape
     assert maxdiff(out["fake"]["vid"], want["vid"]) < PIX_TOL
 
+
+
+def test_encode_conditioning_frames_only(tiny):
+    """`--encode_all false`: with the rec pass off the encoder sees only the frames the conditioning crop keeps
+    (helpers/generator.py:93-99) -- the synthesized clip and its tokens are the same bits as with the reference's encode of the
+    whole clip (frames are encoded independently), `enc_code` holds the kept frames' codes; serial and pipelined schedule; with
+    the rec pass on, or an end frame to read (point-to-point), every frame is still encoded."""
+    from ccvs_amd.helpers.generator import Generator
+    xopt = tiny["xopt"]
+    size = int(np.prod(tiny["qopt"].z_shape))                     # tokens per frame
+    xopt.sample, xopt.rec_pass = False, False
+    try:
+        gen = Generator(tiny["opt"])
+        gen.vid_model, gen.transformer_model = tiny["qv"], tiny["tr"]
+        data = gen.synthetic_batch(2, seed=91)
+        full = gen.generate_vid({"vid": data["vid"].clone()}, 7)
+        xopt.encode_all = False
+        n_keep = gen._frames_to_encode(xopt.vid_len, size)
+        assert 1 <= n_keep < xopt.vid_len and n_keep == -(-xopt.cond_len // size)
+        cond = gen.generate_vid({"vid": data["vid"].clone()}, 7)
+        assert cond["enc_code"].shape == (2, n_keep * size) and torch.equal(cond["enc_code"], full["enc_code"][:, :n_keep * size])
+        assert torch.equal(cond["fake"]["code"], full["fake"]["code"]) and torch.equal(cond["fake"]["vid"], full["fake"]["vid"])
+        assert cond["real"].is_cuda and cond["real"].shape == full["real"].shape
+        res = gen.run_pipelined(({"vid": data["vid"].clone()} for _ in range(2)), first_iter=7, lanes=2, chains=1)
+        assert torch.equal(res[0]["fake"]["vid"], full["fake"]["vid"]) and res[0]["enc_code"].shape == (2, n_keep * size)
+        xopt.rec_pass = True
+        assert gen._frames_to_encode(xopt.vid_len, size) == xopt.vid_len      # the rec pass reads every frame's codes
+        xopt.rec_pass, xopt.p2p = False, True
+        assert gen._frames_to_encode(xopt.vid_len, size) == xopt.vid_len      # the end frame is read
+    finally:
+        xopt.sample, xopt.rec_pass, xopt.encode_all, xopt.p2p = False, True, True, False
