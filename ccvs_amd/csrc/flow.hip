@@ -589,11 +589,56 @@ __global__ __launch_bounds__(256) void tap_shift_add_kernel(const float* __restr
     }
 }
 
+// W % 4 == 0: a lane owns four consecutive pixels of a row -- every tap is one 16-byte load (dword-aligned in the horizontal
+// form), the result one 16-byte store; per pixel the same sum in the same order as the one-pixel form.
+__global__ __launch_bounds__(256) void tap_shift_add4_kernel(const float* __restrict__ t, const float* __restrict__ bias,
+                                                             float* __restrict__ y, long y_sN, long total4, int k, int H, int W,
+                                                             int accumulate, int vertical) {
+    const int Wt = vertical ? W : W + k - 1, Ht = vertical ? H + k - 1 : H;
+    const long tap = (long)3 * Ht * Wt + (vertical ? Wt : 1);
+    const int Wq = W >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % Wq) * 4;
+        long r = i / Wq;
+        const int yy = (int)(r % H);
+        r /= H;
+        const int co = (int)(r % 3);
+        const long n = r / 3;
+        const float* tp = t + ((n * 3 * k + co) * Ht + yy) * (long)Wt + x;
+        const float b = bias ? bias[co] : 0.f;
+        float acc[4] = {b, b, b, b};
+        for (int kk = 0; kk < k; ++kk) {
+            const F32Quad q = *reinterpret_cast<const F32Quad*>(tp + kk * tap);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += q.v[j];
+        }
+        F32Quad* dst = reinterpret_cast<F32Quad*>(y + n * y_sN + ((long)co * H + yy) * W + x);
+        F32Quad o;
+        if (accumulate) {
+            const F32Quad d = *dst;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o.v[j] = d.v[j] + acc[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o.v[j] = acc[j];
+        }
+        *dst = o;
+    }
+}
+
 extern "C" int ccvs_tap_shift_add(const float* t, const float* bias, float* y, int64_t y_sN, int32_t N, int32_t k, int32_t H, int32_t W,
                                   int32_t accumulate, int32_t vertical, void* stream) {
     CCVS_REQUIRE(t && y, "ccvs_tap_shift_add: null pointer");
     CCVS_REQUIRE(N > 0 && k >= 1 && k <= 9 && H > 0 && W > 0, "ccvs_tap_shift_add: bad shape");
     const long total = (long)N * 3 * H * W;
+    if (W % 4 == 0 && y_sN % 4 == 0) {
+        const long total4 = total / 4;
+        const unsigned blocks4 = limited_grid(cdiv64(total4, 256) < 65536 * 16 ? cdiv64(total4, 256) : 65536 * 16, stream, 8);
+        hipLaunchKernelGGL(tap_shift_add4_kernel, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, t, bias, y, (long)y_sN, total4, k, H, W, accumulate,
+                           vertical ? 1 : 0);
+        CCVS_CHECK_LAUNCH("ccvs_tap_shift_add");
+        return CCVS_OK;
+    }
     const unsigned blocks = limited_grid(cdiv64(total, 256) < 65536 * 16 ? cdiv64(total, 256) : 65536 * 16, stream, 8);
     hipLaunchKernelGGL(tap_shift_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, bias, y, (long)y_sN, total, k, H, W, accumulate,
                        vertical ? 1 : 0);

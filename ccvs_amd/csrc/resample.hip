@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(FirK p) {
 #define BLUR_TH 16
 #define BLUR_TW 64
 __global__ __launch_bounds__(256) void blur4x4_tile_kernel(FirK p, int tiles_x, GridWalk gw) {
-    __shared__ float tile[(BLUR_TH + 3) * (BLUR_TW + 4)];
+    __shared__ __attribute__((aligned(16))) float tile[(BLUR_TH + 3) * (BLUR_TW + 4)];
     constexpr int IWp = BLUR_TW + 4, IH = BLUR_TH + 3, IW = BLUR_TW + 3;
     const int tid = threadIdx.x;
     GRID_WALK_BEGIN(gw, bx, by, bz)
@@ -66,11 +66,23 @@ __global__ __launch_bounds__(256) void blur4x4_tile_kernel(FirK p, int tiles_x, 
     if (w_ != (long)blockIdx.x) __syncthreads();   // persistent walk: the tile of the previous block has been read by everyone
     const float* xp = p.x + nc * (long)p.H * p.W;
     const int iy0 = ty * BLUR_TH - p.pad0, ix0 = tx * BLUR_TW - p.pad0;
-    for (int e = tid; e < IH * IW; e += 256) {
-        const int r = e / IW, c = e - r * IW;
+    // 16 bytes per lane where the four columns lie inside the row (dword-aligned is enough for the load on gfx950; the LDS
+    // slot is 16-byte aligned: the tile starts at ix0); clamped scalar loads with zero fill at the image border
+    for (int e = tid; e < IH * (IWp / 4); e += 256) {
+        const int r = e / (IWp / 4), c = (e - r * (IWp / 4)) * 4;
         const int iy = iy0 + r, ix = ix0 + c;
-        const float t = xp[(long)min(max(iy, 0), p.H - 1) * p.W + min(max(ix, 0), p.W - 1)];
-        tile[r * IWp + c] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? t : 0.f;
+        f32x4 t4;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix + 3 < p.W) {
+            const F32Quad q = *reinterpret_cast<const F32Quad*>(xp + (long)iy * p.W + ix);
+            t4 = f32x4{q.v[0], q.v[1], q.v[2], q.v[3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = xp[(long)min(max(iy, 0), p.H - 1) * p.W + min(max(ix + j, 0), p.W - 1)];
+                t4[j] = (iy >= 0 && iy < p.H && ix + j >= 0 && ix + j < p.W) ? t : 0.f;
+            }
+        }
+        *reinterpret_cast<f32x4*>(&tile[r * IWp + c]) = t4;
     }
     __syncthreads();
     const int row = tid >> 4, col = (tid & 15) * 4;
@@ -79,9 +91,12 @@ __global__ __launch_bounds__(256) void blur4x4_tile_kernel(FirK p, int tiles_x, 
     float h[4][4];
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
-        float r[7];
-#pragma unroll
-        for (int c = 0; c < 7; ++c) r[c] = tile[(row + ky) * IWp + col + c];
+        // the 7 values of the row window as two 16-byte LDS reads (col and the row stride are multiples of 4 floats): with 28
+        // dword reads per thread, lanes 16 bytes apart on rows 272 bytes apart, 58 % of the kernel's LDS cycles were bank
+        // conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, tools/pmc_decoder_kernels.sh)
+        const f32x4 ra = *reinterpret_cast<const f32x4*>(&tile[(row + ky) * IWp + col]);
+        const f32x4 rb = *reinterpret_cast<const f32x4*>(&tile[(row + ky) * IWp + col + 4]);
+        const float r[7] = {ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2]};
 #pragma unroll
         for (int o = 0; o < 4; ++o) h[ky][o] = (r[o] + r[o + 3]) + 3.f * (r[o + 1] + r[o + 2]);
     }
@@ -269,6 +284,87 @@ __global__ __launch_bounds__(256) void down2_kernel(FirK p) {
     }
 }
 
+// The same blur + decimate through an LDS tile: a workgroup owns 16 x 64 outputs of one plane; their 34 x 130 input window is
+// staged once (16 bytes per lane, zeros outside the image) instead of being fetched as twelve overlapping 16-byte loads per
+// thread through L1, and each thread reads the 4 x 10 window of its four outputs as three 16-byte LDS reads per row.  Per
+// output the same sums in the same order as down2_kernel (rows outside the image add zeros instead of being skipped).
+#define DOWN_TH 16
+#define DOWN_TW 64
+__global__ __launch_bounds__(256) void down2_tile_kernel(FirK p, int tiles_x, GridWalk gw) {
+    constexpr int IH = 2 * DOWN_TH + 2, IWp = 2 * DOWN_TW + 4;   // 34 rows x 132 floats (130 used)
+    __shared__ __attribute__((aligned(16))) float tile[IH * IWp];
+    const int tid = threadIdx.x;
+    const float t4[4] = {1.f, 3.f, 3.f, 1.f};
+    GRID_WALK_BEGIN(gw, bx, by, bz)
+    (void)bz;
+    const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+    const long nc = by;
+    if (w_ != (long)blockIdx.x) __syncthreads();
+    const float* xp = p.x + nc * (long)p.H * p.W;
+    const int iy0 = ty * DOWN_TH * 2 - p.pad0, ix0 = tx * DOWN_TW * 2 - p.pad0;
+    for (int e = tid; e < IH * (IWp / 4); e += 256) {
+        const int r = e / (IWp / 4), c = (e - r * (IWp / 4)) * 4;
+        const int iy = iy0 + r, ix = ix0 + c;
+        f32x4 v4;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix + 3 < p.W) {
+            const F32Quad q = *reinterpret_cast<const F32Quad*>(xp + (long)iy * p.W + ix);
+            v4 = f32x4{q.v[0], q.v[1], q.v[2], q.v[3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = xp[(long)min(max(iy, 0), p.H - 1) * p.W + min(max(ix + j, 0), p.W - 1)];
+                v4[j] = (iy >= 0 && iy < p.H && ix + j >= 0 && ix + j < p.W) ? t : 0.f;
+            }
+        }
+        *reinterpret_cast<f32x4*>(&tile[r * IWp + c]) = v4;
+    }
+    __syncthreads();
+    const int row = tid >> 4, cg = tid & 15;
+    const int oy = ty * DOWN_TH + row, ox0 = tx * DOWN_TW + cg * 4;
+    if (oy < p.Ho && ox0 < p.Wo) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            float w[12];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(&tile[(2 * row + ky) * IWp + 8 * cg + 4 * q]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[4 * q + e] = r4[e];
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float rsum = 0.f;
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) rsum += t4[kx] * w[2 * o + kx];
+                acc[o] += t4[ky] * rsum;
+            }
+        }
+        const long oi = (nc * p.Ho + oy) * (long)p.Wo + ox0;
+        const int nv = min(4, p.Wo - ox0);
+        float v[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            v[o] = acc[o] * (p.gain * (1.f / 64.f));
+            if (p.act == CCVS_ACT_LRELU) v[o] = lrelu01(v[o]);
+        }
+        if (nv == 4) {
+            if (p.res) {
+                const F32Quad r4 = *reinterpret_cast<const F32Quad*>(p.res + oi);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) v[o] += r4.v[o];
+            }
+            F32Quad o4;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) o4.v[o] = v[o] * p.out_scale;
+            *reinterpret_cast<F32Quad*>(p.y + oi) = o4;
+        } else {
+            for (int o = 0; o < nv; ++o) p.y[oi + o] = (v[o] + (p.res ? p.res[oi + o] : 0.f)) * p.out_scale;
+        }
+    }
+    GRID_WALK_END
+}
+
 extern "C" int ccvs_upfirdn2d(const float* x, float* y, const float* residual, int64_t NC, int32_t H, int32_t W, int32_t up,
                               int32_t down, int32_t pad0, int32_t pad1, float gain, int32_t act, float out_scale, void* stream) {
     CCVS_REQUIRE(x && y, "ccvs_upfirdn2d: null pointer");
@@ -295,6 +391,10 @@ extern "C" int ccvs_upfirdn2d(const float* x, float* y, const float* residual, i
         } else {
             hipLaunchKernelGGL(upsample2_kernel, dim3(blocks), dim3(256), 0, st, k);
         }
+    } else if (up == 1 && down == 2 && k.Wo >= 32 && k.Ho >= 8 && !getenv("CCVS_DOWN2_DIRECT")) {   // (small planes: the direct form below)
+        const int tiles_x = cdiv(k.Wo, DOWN_TW), tiles_y = cdiv(k.Ho, DOWN_TH);
+        const GridWalk gw = grid_walk((long)tiles_x * tiles_y, NC, 1);
+        hipLaunchKernelGGL(down2_tile_kernel, dim3(limited_grid(gw.total, stream, 8)), dim3(256), 0, st, k, tiles_x, gw);
     } else if (up == 1 && down == 2) {
         const long work = NC * k.Ho * ((k.Wo + 3) / 4);
         const unsigned blocks = limited_grid(cdiv64(work, 256) < 65536 * 16 ? cdiv64(work, 256) : 65536 * 16, stream, 8);

@@ -180,6 +180,37 @@ def test_conv_shared_pre_image_tile_order(ops, cin, cout, hw, n, div):
     assert torch.equal(budget, got)
 
 
+@pytest.mark.parametrize("k,hw,precision", [(9, (32, 48), "bf16x3"), (9, (19, 37), "bf16x3"), (5, (16, 24), "bf16x3"), (3, (9, 8), "bf16x3"),
+                                            (9, (16, 36), "f32"), (5, (13, 18), "f32")])
+def test_flow_occ_heads_vs_torch(ops, k, hw, precision):
+    """flow_head (2 outputs) + occ_head (1) of Matching / Subpixel (skip_autoencoder.py:176-177, 225-226) as ONE convolution to 3k
+    maps plus the tap sum (`ccvs_tap_shift_add`: four pixels per lane when W % 4 == 0, one otherwise; vertical taps behind the
+    split-bf16 1 x k kernel, horizontal ones behind the fp32 k x 1 kernel): against the two k x k convolutions, written into a
+    channel-slice view, plain and accumulating."""
+    torch.manual_seed(k * 100 + hw[1])
+    n, c = 3, 32
+    feat = torch.randn(n, c, *hw)
+    fw, ow = torch.randn(2, c, k, k), torch.randn(1, c, k, k)
+    b3 = torch.randn(3)
+    scale = 1 / math.sqrt(c * k * k)
+    want = torch.nn.functional.conv2d(feat, torch.cat([fw, ow]) * scale, bias=b3, padding=k // 2)
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = precision
+    try:
+        pk = ops.pack_head_weights(fw.cuda(), ow.cuda())
+        buf = torch.zeros(n, 7, *hw).cuda()              # [.. | flow 2 | occ 1] tail of a wider tensor, as in InterBlock.forward_fused
+        out = buf[:, 4:]
+        ops.conv_heads(feat.cuda(), pk, b3.cuda(), out, accumulate=False)
+        close(out, want, 2e-4)
+        assert torch.equal(buf[:, :4].cpu(), torch.zeros(n, 4, *hw))
+        base = torch.randn(n, 3, *hw)
+        out.copy_(base)
+        ops.conv_heads(feat.cuda(), pk, b3.cuda(), out, accumulate=True)
+        close(out, base + want, 2e-4)
+    finally:
+        ops.CONV_PRECISION = old
+
+
 def test_conv_fp32_mfma_variant(ops):
     """The exact-fp32 kernel (v_mfma_f32_32x32x2_f32) stays available next to the split-bf16 default."""
     torch.manual_seed(11)
