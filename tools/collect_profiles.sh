@@ -18,7 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 export CCVS_BENCH_SUPERVISE=0   # (bench.py also recognises the profiler's preload by itself)
 for SCHED in pipelined serial; do
   rm -rf /tmp/prof_$SCHED
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$SCHED -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strict-f32 --schedule $SCHED > /tmp/prof_$SCHED.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$SCHED -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strict-f32 --no-encode-cond-leg --schedule $SCHED > /tmp/prof_$SCHED.log 2>&1
   cp $(ls /tmp/prof_$SCHED/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_${SCHED}_kernel_stats.csv
   grep "^{" /tmp/prof_$SCHED.log | tail -1 > $OUT/${TAG}_bench_${SCHED}_under_rocprof.json
 done
