@@ -14,6 +14,7 @@
 // apart: every read a two-way bank conflict).
 // ---------------------------------------------------------------------------------------
 #define CORR_CC 8
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int S>
 __global__ __launch_bounds__(256) void correlation7x7_kernel(const float* __restrict__ first, const float* __restrict__ second,
@@ -76,16 +77,108 @@ __global__ __launch_bounds__(256) void correlation7x7_kernel(const float* __rest
     GRID_WALK_END   // (every channel chunk starts with a barrier: the next block's staging waits for this block's reads)
 }
 
+// Two pixels per lane (Wo even, planes of at least 64 columns): the one-pixel form is bound by the LDS pipe (49 ds_read_b32 per
+// pixel and channel; SQ_LDS_IDX_ACTIVE / SQ_BUSY_CYCLES = 1.05, no conflicts).  A lane that owns the pixel pair (x, x + 1) needs the
+// 8 consecutive values B[y + dy][x .. x + 7] per row and channel: four 8-byte LDS reads (256 B/clk) serve 14 products instead of
+// fourteen 4-byte reads (128 B/clk), and the 49 results per pixel leave as 8-byte stores.  Workgroup = 8 x 64 output pixels;
+// per (pixel, displacement) the channels are added in the same order as above: the same bits.
+template <int S>
+__global__ __launch_bounds__(256) void correlation7x7x2_kernel(const float* __restrict__ first, const float* __restrict__ second,
+                                                               float* __restrict__ out, int C, int H, int W, int Ho, int Wo,
+                                                               int first_div, int lrelu, int tiles_x, GridWalk gw) {
+    constexpr int TH = 8, TW = 64;
+    constexpr int IH = TH + 6, IW = TW + 6;   // in units of s pixels; IW even: a lane's pair is 8-byte aligned in LDS
+    __shared__ __attribute__((aligned(16))) float bt[CORR_CC][IH * IW];
+    const int tid = threadIdx.x;
+    GRID_WALK_BEGIN(gw, bx, by, bz)
+    (void)bz;
+    const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+    const int n = by;
+    const int py = tid >> 5, px = (tid & 31) * 2;
+    const int oy = ty * TH + py, ox = tx * TW + px;
+    const bool live = (oy < Ho && ox < Wo);    // Wo even: the pair is in or out together
+    const int iy0 = ty * TH * S - 3 * S, ix0 = tx * TW * S - 3 * S;
+    const float* A = first + (long)(n / first_div) * C * H * W;
+    const float* B = second + (long)n * C * H * W;
+
+    float acc0[49], acc1[49];
+#pragma unroll
+    for (int d = 0; d < 49; ++d) { acc0[d] = 0.f; acc1[d] = 0.f; }
+
+    for (int c0 = 0; c0 < C; c0 += CORR_CC) {
+        __syncthreads();
+        for (int e = tid; e < IH * IW; e += 256) {
+            const int r = e / IW, c = e - r * IW;
+            const int gy = iy0 + r * S, gx = ix0 + c * S;
+            const bool ok = (gy >= 0 && gy < H && gx >= 0 && gx < W);
+            const long o = ok ? (long)gy * W + gx : 0;
+#pragma unroll
+            for (int cc = 0; cc < CORR_CC; ++cc) {
+                const float t = B[(long)min(c0 + cc, C - 1) * H * W + o];
+                bt[cc][e] = (ok && c0 + cc < C) ? t : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < CORR_CC; ++cc) {
+            const float* ap = A + (long)min(c0 + cc, C - 1) * H * W + (live ? (long)(oy * S) * W + ox * S : 0);
+            const float ta0 = ap[0], ta1 = ap[live ? S : 0];
+            const bool on = live && c0 + cc < C;
+            const float a0 = on ? ta0 : 0.f, a1 = on ? ta1 : 0.f;
+            const float* bp = &bt[cc][py * IW + px];
+#pragma unroll
+            for (int dy = 0; dy < 7; ++dy) {
+                float r[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x2 t2 = *reinterpret_cast<const f32x2*>(bp + dy * IW + 2 * q);   // 8-byte aligned: ds_read_b64
+                    r[2 * q] = t2[0]; r[2 * q + 1] = t2[1];
+                }
+#pragma unroll
+                for (int dx = 0; dx < 7; ++dx) {
+                    acc0[dy * 7 + dx] += a0 * r[dx];
+                    acc1[dy * 7 + dx] += a1 * r[dx + 1];
+                }
+            }
+        }
+    }
+    if (live) {
+        const float inv = 1.f / (float)C;
+        float* o = out + (long)n * 49 * Ho * Wo + (long)oy * Wo + ox;
+#pragma unroll
+        for (int d = 0; d < 49; ++d) {
+            float v0 = acc0[d] * inv, v1 = acc1[d] * inv;
+            if (lrelu) { v0 = lrelu01(v0); v1 = lrelu01(v1); }
+            F32Pair w2;
+            w2.x = v0; w2.y = v1;
+            *reinterpret_cast<F32Pair*>(o + (long)d * Ho * Wo) = w2;
+        }
+    }
+    GRID_WALK_END
+}
+
 extern "C" int ccvs_correlation7x7(const float* first, const float* second, float* out, int32_t N, int32_t C, int32_t H, int32_t W,
                                    int32_t stride, int32_t first_div, int32_t lrelu, void* stream) {
     CCVS_REQUIRE(first && second && out, "ccvs_correlation7x7: null pointer");
     CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && first_div >= 1, "ccvs_correlation7x7: bad shape");
     CCVS_REQUIRE(stride == 1 || stride == 2, "ccvs_correlation7x7: stride %d unsupported", stride);
     const int Ho = cdiv(H, stride), Wo = cdiv(W, stride);
+    hipStream_t st = (hipStream_t)stream;
+    static const int pair_form = getenv("CCVS_CORR_PAIR") ? atoi(getenv("CCVS_CORR_PAIR")) : 1;
+    if (pair_form && Wo % 2 == 0 && Wo >= 64) {
+        const int tiles_x2 = cdiv(Wo, 64), tiles_y2 = cdiv(Ho, 8);
+        const GridWalk gw2 = grid_walk((long)tiles_x2 * tiles_y2, N, 1);
+        const dim3 grid2(limited_grid(gw2.total, stream, 4));
+        if (stride == 1)
+            hipLaunchKernelGGL((correlation7x7x2_kernel<1>), grid2, dim3(256), 0, st, first, second, out, C, H, W, Ho, Wo, first_div, lrelu, tiles_x2, gw2);
+        else
+            hipLaunchKernelGGL((correlation7x7x2_kernel<2>), grid2, dim3(256), 0, st, first, second, out, C, H, W, Ho, Wo, first_div, lrelu, tiles_x2, gw2);
+        CCVS_CHECK_LAUNCH("ccvs_correlation7x7");
+        return CCVS_OK;
+    }
     const int tiles_x = cdiv(Wo, 32), tiles_y = cdiv(Ho, 8);
     const GridWalk gw = grid_walk((long)tiles_x * tiles_y, N, 1);
     const dim3 grid(limited_grid(gw.total, stream, stride == 1 ? 8 : 4));
-    hipStream_t st = (hipStream_t)stream;
     if (stride == 1)
         hipLaunchKernelGGL((correlation7x7_kernel<1>), grid, dim3(256), 0, st, first, second, out, C, H, W, Ho, Wo, first_div, lrelu, tiles_x, gw);
     else
