@@ -45,6 +45,28 @@ def test_token_group_size_rules():
     assert g._token_group_size(16, 3) == 1
 
 
+def test_frames_the_encoder_has_to_see():
+    """`--encode_all false`: only the frames the conditioning crop keeps (helpers/generator.py:93-99) -- and only when nothing else
+    reads the rest of the clip; the default is the reference's encode of every frame."""
+    from ccvs_amd.helpers.generator import Generator
+    g = Generator.__new__(Generator)
+    base = dict(encode_all=False, rec_pass=False, rec_only=False, state=False, stft=False, p2p=False, gen_from_img=False, cond_len=64, vid_len=16)
+    g.opt = types.SimpleNamespace(**base)
+    assert g._frames_to_encode(16, 64) == 1                                   # BAIR: one conditioning frame of 64 tokens
+    g.opt.cond_len = 320
+    assert g._frames_to_encode(16, 64) == 5                                   # Kinetics: five
+    g.opt.cond_len = 100
+    assert g._frames_to_encode(16, 64) == 2                                   # a partial frame of tokens keeps its frame
+    g.opt.cond_len = 0
+    assert g._frames_to_encode(16, 64) == 1                                   # unconditional: the encoder still needs an input
+    g.opt.cond_len = 64
+    for key in ("encode_all", "rec_pass", "rec_only", "state", "stft", "p2p", "gen_from_img"):
+        g.opt = types.SimpleNamespace(**dict(base, **{key: True}))
+        assert g._frames_to_encode(16, 64) == 16, key                          # someone reads the rest of the clip: the reference's encode
+    g.opt = types.SimpleNamespace(**{k: v for k, v in base.items() if k not in ("encode_all", "rec_pass")})
+    assert g._frames_to_encode(16, 64) == 16                                   # options from a reference launch line: reference behaviour
+
+
 @pytest.mark.parametrize("n_code,n_state", [(64 * 3, 16 * 3), (64 * 2 + 5, 16 * 3), (64 * 15 + 5, 16 * 16), (64, 16)])
 def test_stream_kinds_equal_the_oracle_merge(n_code, n_state):
     """The merged sequence order the KV-cached engine walks (`GPT.stream_kinds`) is the oracle's `gpt_merge_state` order
