@@ -49,11 +49,12 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(FirK p) {
     }
 }
 
-// up = down = 1: a 256-thread workgroup owns a 16 x 64 output tile of one channel plane; the
-// (16+3) x (64+3) input tile is staged once in LDS with coalesced loads (every input element is read
+// up = down = 1: a 256-thread workgroup owns a 32 x 64 output tile of one channel plane (two rows of four outputs per thread;
+// with 16 rows the loads of a workgroup were too few to cover their latency: 2.9 TB/s); the
+// (32+3) x (64+3) input tile is staged once in LDS with coalesced loads (every input element is read
 // from HBM once, unconditionally from a clamped address), then each thread produces 4 consecutive
 // outputs of one row with the separable 1-3-3-1 passes and writes them as one 16-byte store.
-#define BLUR_TH 16
+#define BLUR_TH 32
 #define BLUR_TW 64
 __global__ __launch_bounds__(256) void blur4x4_tile_kernel(FirK p, int tiles_x, GridWalk gw) {
     __shared__ __attribute__((aligned(16))) float tile[(BLUR_TH + 3) * (BLUR_TW + 4)];
@@ -85,7 +86,9 @@ __global__ __launch_bounds__(256) void blur4x4_tile_kernel(FirK p, int tiles_x, 
         *reinterpret_cast<f32x4*>(&tile[r * IWp + c]) = t4;
     }
     __syncthreads();
-    const int row = tid >> 4, col = (tid & 15) * 4;
+#pragma unroll
+    for (int rr = 0; rr < BLUR_TH / 16; ++rr) {
+    const int row = (tid >> 4) + 16 * rr, col = (tid & 15) * 4;
     const int oy = ty * BLUR_TH + row, ox0 = tx * BLUR_TW + col;
     if (oy < p.Ho && ox0 < p.Wo) {
     float h[4][4];
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(256) void blur4x4_tile_kernel(FirK p, int tiles_x, 
         *reinterpret_cast<F32Quad*>(p.y + oi) = o4;
     } else {
         for (int o = 0; o < nv; ++o) p.y[oi + o] = (v[o] + (p.res ? p.res[oi + o] : 0.f)) * p.out_scale;
+    }
     }
     }
     GRID_WALK_END
@@ -391,7 +395,7 @@ extern "C" int ccvs_upfirdn2d(const float* x, float* y, const float* residual, i
         } else {
             hipLaunchKernelGGL(upsample2_kernel, dim3(blocks), dim3(256), 0, st, k);
         }
-    } else if (up == 1 && down == 2 && k.Wo >= 32 && k.Ho >= 8 && !getenv("CCVS_DOWN2_DIRECT")) {   // (small planes: the direct form below)
+    } else if (up == 1 && down == 2 && k.Wo >= 32 && k.Ho >= 8) {   // (small planes: the direct form below)
         const int tiles_x = cdiv(k.Wo, DOWN_TW), tiles_y = cdiv(k.Ho, DOWN_TH);
         const GridWalk gw = grid_walk((long)tiles_x * tiles_y, NC, 1);
         hipLaunchKernelGGL(down2_tile_kernel, dim3(limited_grid(gw.total, stream, 8)), dim3(256), 0, st, k, tiles_x, gw);
