@@ -500,13 +500,73 @@ __global__ __launch_bounds__(256) void dwconvT4x4s2x2_kernel(const float* __rest
     }
 }
 
+// FOUR input pixels (jx .. jx + 3) per thread (W % 4 == 0): a 3 x 6 neighbourhood in -- per row one aligned 16-byte load plus the two
+// edge columns -- and a 2 x 8 output block out as four 16-byte stores.  The two-pixel form spends its time on index arithmetic and
+// 28 load instructions per 32 bytes stored (2.5 TB/s); this one issues 25 per 128 bytes.  Per output the sum of dwconvT4x4s2_kernel.
+__global__ __launch_bounds__(256) void dwconvT4x4s2x4_kernel(const float* __restrict__ x, long x_sN, const float* __restrict__ w,
+                                                             float* __restrict__ y, long y_sN, long N, int C, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W, W4 = W >> 2;
+    const long total = N * C * (long)H * W4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int jx = (int)(i % W4) * 4;
+        const long t = i / W4;
+        const int iy = (int)(t % H);
+        const long nc = t / H;
+        const int c = (int)(nc % C);
+        const long n = nc / C;
+        const float* xp = x + n * x_sN + (long)c * H * W;
+        const float* wp = w + c * 16;
+        float v[3][6];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int yy = iy + a - 1;
+            const bool rin = yy >= 0 && yy < H;
+            const float* rp = xp + (long)min(max(yy, 0), H - 1) * W;
+            const F32Quad m = *reinterpret_cast<const F32Quad*>(rp + jx);
+            const float l = rp[max(jx - 1, 0)], r = rp[min(jx + 4, W - 1)];
+            v[a][0] = (rin && jx > 0) ? l : 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v[a][1 + b] = rin ? m.v[b] : 0.f;
+            v[a][5] = (rin && jx + 4 < W) ? r : 0.f;
+        }
+        const int kyt[2][2] = {{1, 3}, {0, 2}}, nyt[2][2] = {{1, 0}, {2, 1}};
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float* yp = y + n * y_sN + ((long)c * Ho + 2 * iy + a) * Wo + 2 * jx;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {        // two 16-byte stores per output row
+                F32Quad o4;
+#pragma unroll
+                for (int bj = 0; bj < 2; ++bj) {
+                    const int bi = 2 * h + bj;   // input column jx + bi
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                            for (int tb = 0; tb < 2; ++tb) acc += v[nyt[a][ta]][bi + nyt[b][tb]] * wp[kyt[a][ta] * 4 + kyt[b][tb]];
+                        o4.v[2 * bj + b] = acc;
+                    }
+                }
+                *reinterpret_cast<F32Quad*>(yp + 4 * h) = o4;
+            }
+        }
+    }
+}
+
 extern "C" int ccvs_dwconvT4x4s2(const float* x, int64_t x_sN, const float* w, float* y, int64_t y_sN, int32_t N, int32_t C, int32_t H,
                                  int32_t W, void* stream) {
     CCVS_REQUIRE(x && w && y, "ccvs_dwconvT4x4s2: null pointer");
     CCVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "ccvs_dwconvT4x4s2: empty tensor");
     const long work = (long)N * C * H * W;
     const unsigned blocks = limited_grid(cdiv64(work, 256) < 65536 * 16 ? cdiv64(work, 256) : 65536 * 16, stream, 8);
-    if (W % 2 == 0) {
+    static const int quad_form = getenv("CCVS_DWCONVT_X4") ? atoi(getenv("CCVS_DWCONVT_X4")) : 1;
+    if (quad_form && W % 4 == 0 && x_sN % 4 == 0) {
+        const long work4 = (long)N * C * H * (W / 4);
+        const unsigned blocks4 = limited_grid(cdiv64(work4, 256) < 65536 * 16 ? cdiv64(work4, 256) : 65536 * 16, stream, 8);
+        hipLaunchKernelGGL(dwconvT4x4s2x4_kernel, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, x, (long)x_sN, w, y, (long)y_sN, (long)N, C, H, W);
+    } else if (W % 2 == 0) {
         const long work2 = (long)N * C * H * (W / 2);
         const unsigned blocks2 = limited_grid(cdiv64(work2, 256) < 65536 * 16 ? cdiv64(work2, 256) : 65536 * 16, stream, 8);
         hipLaunchKernelGGL(dwconvT4x4s2x2_kernel, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, x, (long)x_sN, w, y, (long)y_sN, (long)N, C, H, W);

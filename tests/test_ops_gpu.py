@@ -61,9 +61,15 @@ def test_upfirdn2d_oracle(ops, shape, up, down, pad):
 
 def test_dwconvT(ops):
     torch.manual_seed(0)
-    for c, h, w in [(2, 5, 7), (49, 16, 16), (1, 1, 1)]:
+    for c, h, w in [(2, 5, 7), (49, 16, 16), (1, 1, 1), (3, 9, 6), (3, 6, 4), (5, 7, 36)]:   # one / two / four input pixels per thread (W odd, % 2, % 4)
         x, wt = torch.randn(3, c, h, w), torch.randn(c, 1, 4, 4)
         close(ops.dwconvT4x4s2(x.cuda(), wt.cuda()), O.dw_convT_x2(x, wt), 1e-5)
+    # into the [flow | occ] tail of a wider tensor (batch stride free), as InterBlock.forward_fused does
+    x, wt = torch.randn(2, 3, 8, 12), torch.randn(3, 1, 4, 4)
+    buf = torch.zeros(2, 7, 16, 24).cuda()
+    ops.dwconvT4x4s2(x.cuda(), wt.cuda(), out=buf[:, 4:])
+    close(buf[:, 4:], O.dw_convT_x2(x, wt), 1e-5)
+    assert torch.equal(buf[:, :4].cpu(), torch.zeros(2, 4, 16, 24))
 
 
 # ------------------------------------------------------------------ conv

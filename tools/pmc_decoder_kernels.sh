@@ -12,7 +12,7 @@ for c in "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_IDX_ACTIVE SQ_LDS_B
 done
 python3 - <<'PY'
 import csv, glob, collections, re
-names = ("correlation7x7", "backwarp4", "warp_fuse_blend4", "warp_proj4", "blur4x4_tile", "down2", "dwconvT4x4s2x2", "tap_shift_add", "upsample2x2")
+names = ("correlation7x7", "backwarp4", "warp_fuse_blend4", "warp_proj4", "blur4x4_tile", "down2", "dwconvT4x4s2", "tap_shift_add", "upsample2x2")
 def short(n):
     for k in names:
         if k in n: return k
