@@ -201,7 +201,7 @@ extern "C" int ccvs_conv2d(const float* x, const float* w_packed, const float* b
     k.act = d->act; k.accumulate = d->accumulate; k.out_scale = d->out_scale;
     k.pre = d->pre; k.pre_sN = d->pre_sN; k.pre_sC = d->pre_sC; k.pre_div = d->pre_div > 0 ? d->pre_div : 1;
     k.in_p8 = 0; k.out_p8 = 0;
-    k.nwork = 0; k.gx = k.gy = 1; k.work0 = 0; k.xcd_chunk = 0; k.cu_limit = 0; k.zi = 0;  // the fp32-MFMA form always runs the classic 3-D grid
+    k.nwork = 0; k.gx = k.gy = 1; k.work0 = 0; k.xcd_chunk = 0; k.cu_limit = 0; k.zi = 0; k.ktail = 0;  // the fp32-MFMA form always runs the classic 3-D grid
     CCVS_REQUIRE(!d->in_p8 && !d->out_p8, "ccvs_conv2d: packed activations are a split-bf16 format (use ccvs_conv2d_bf16x3)");
 
     // virtual grid (largest parity class for the transposed form)

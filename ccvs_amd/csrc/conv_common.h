@@ -27,6 +27,7 @@ struct ConvK {
     int xcd_chunk;  // XCD-aware order of the tiles of one launch (see CONV_TILE_COORDS)
     int cu_limit;  // host side only: CUs this launch may occupy (0 = classic 3-D grid over all of them)
     int zi;        // > 1: the zi images that share one `pre` image run back to back per tile (see CONV_TILE_COORDS)
+    int ktail;     // r = Cin % 16 in {1, 2, 3} and the weights are in the packed-tail form (ccvs_conv_desc.w_ktail); else 0
 };
 
 // Tile coordinates of a workgroup.  Workgroups are handed to the 8 XCDs round-robin in dispatch order (linear id % 8), and

@@ -116,6 +116,7 @@ struct Gemm16 {
     int M, N, K, epi, ks;
     const float* ln_s; float ln_eps;
     float* kcache; float* vcache; int C, H, D, Tq, Tmax, pos0; const int32_t* pos_dev;
+    int seq;           // 1: whole-sequence call (CCVS_GEMM_SEQ): the row-blocked form whatever M is (see launch_gemm16)
     int grp_rows;      // > 0: batch row b takes its device-resident position from pos_dev[b / grp_rows] (row groups of a decode step)
     int kz;            // K slices across workgroups (gridDim.z); > 1 only with a workspace
     float* ws_slabs;   // [tile][kz][64 lanes][4] partial accumulators
@@ -429,7 +430,13 @@ static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
     if (!(g.M > 0 && g.N > 0 && g.K > 0)) { ccvs_set_error("%s: empty tensor", name); return CCVS_ERR_ARG; }
     if (g.K % 16 != 0 || g.ldx % 4 != 0) { ccvs_set_error("%s: K=%d must be a multiple of 16 (ldx %% 4 == 0)", name, g.K); return CCVS_ERR_ARG; }
     if (g.epi < 0 || g.epi > 2 || (g.epi == 2 && !g.res)) { ccvs_set_error("%s: bad epilogue", name); return CCVS_ERR_ARG; }
-    const bool decode_form = g.M <= GEMM_DECODE_MAX_M;
+    // Which kernel runs is a property of the CALL KIND, never of how many rows share the launch: the two forms partition K
+    // differently (4 waves x kz slices and one accumulator chain vs 8 waves and two chains), so their low bits differ, and a
+    // row must come out the same whether its batch is prefilled alone or stacked with the other batches of a token group
+    // (B t0 <= 256 alone, G B t0 > 256 stacked).  Whole-sequence calls (prefill, teacher-forced forward, re-prefill of a slid
+    // window: CCVS_GEMM_SEQ in the epilogue word, Tq > 1 for the QKV form) always take the row-blocked form; single-position
+    // calls (decode steps) take the weight-stream form up to GEMM_DECODE_MAX_M rows and the row-blocked one beyond.
+    const bool decode_form = !g.seq && g.M <= GEMM_DECODE_MAX_M;
     if (decode_form && ((long)g.N * g.K * 4 >= (1L << 31) || (long)g.M * g.ldx * 4 >= (1L << 31))) {
         ccvs_set_error("%s: operand beyond 2^31 bytes (32-bit buffer offsets)", name);
         return CCVS_ERR_ARG;
@@ -456,7 +463,8 @@ extern "C" int64_t ccvs_gemm_workspace_bytes(void) { return (int64_t)GEMM_WS_TIL
 extern "C" int ccvs_gemm_nt(const float* x, int64_t ldx, const float* w, const float* bias, const float* res, float* y, int64_t ldy,
                             int32_t M, int32_t N, int32_t K, int32_t epilogue, void* workspace, void* stream) {
     Gemm16 g = {};
-    g.x = x; g.ldx = ldx; g.w = w; g.bias = bias; g.res = res; g.y = y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.epi = epilogue;
+    g.x = x; g.ldx = ldx; g.w = w; g.bias = bias; g.res = res; g.y = y; g.ldy = ldy; g.M = M; g.N = N; g.K = K;
+    g.epi = epilogue & 0xff; g.seq = (epilogue & CCVS_GEMM_SEQ) ? 1 : 0;
     if (workspace) {
         g.ws_slabs = (float*)workspace;
         g.ws_count = (int*)((char*)workspace + (size_t)GEMM_WS_TILES * 4 * 256 * sizeof(float));
@@ -467,9 +475,10 @@ extern "C" int ccvs_gemm_nt(const float* x, int64_t ldx, const float* w, const f
 extern "C" int ccvs_gemm_ln(const float* x, int64_t ldx, const float* w_gamma, const float* bias_beta, const float* w_rowsum, float eps,
                             float* y, int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t epilogue, void* stream) {
     CCVS_REQUIRE(w_rowsum, "ccvs_gemm_ln: null pointer");
-    CCVS_REQUIRE(epilogue == 0 || epilogue == 1, "ccvs_gemm_ln: bad epilogue");
+    CCVS_REQUIRE((epilogue & 0xff) == 0 || (epilogue & 0xff) == 1, "ccvs_gemm_ln: bad epilogue");
     Gemm16 g = {};
-    g.x = x; g.ldx = ldx; g.w = w_gamma; g.bias = bias_beta; g.y = y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.epi = epilogue;
+    g.x = x; g.ldx = ldx; g.w = w_gamma; g.bias = bias_beta; g.y = y; g.ldy = ldy; g.M = M; g.N = N; g.K = K;
+    g.epi = epilogue & 0xff; g.seq = (epilogue & CCVS_GEMM_SEQ) ? 1 : 0;
     g.ln_s = w_rowsum; g.ln_eps = eps;
     return launch_gemm16(g, (hipStream_t)stream, "ccvs_gemm_ln");
 }
@@ -483,6 +492,7 @@ extern "C" int ccvs_gemm_ln_qkv(const float* x, int64_t ldx, const float* w_gamm
     g.x = x; g.ldx = ldx; g.w = w_gamma; g.bias = bias_beta; g.y = q; g.ldy = C; g.M = B * Tq; g.N = 3 * C; g.K = C; g.epi = 0;
     g.ln_s = w_rowsum; g.ln_eps = eps;
     g.kcache = kcache; g.vcache = vcache; g.C = C; g.H = H; g.D = C / H; g.Tq = Tq; g.Tmax = Tmax; g.pos0 = pos0; g.pos_dev = pos_dev;
+    g.seq = Tq > 1 ? 1 : 0;
     return launch_gemm16(g, (hipStream_t)stream, "ccvs_gemm_ln_qkv");
 }
 
@@ -1143,7 +1153,8 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream) {
     CCVS_REQUIRE(D == 64 || D == 32 || D == 16, "ccvs_gpt_decode_step: head dim %d unsupported (16, 32, 64)", D);
     CCVS_REQUIRE(d->temperature > 0.f, "ccvs_gpt_decode_step: bad temperature");
     CCVS_REQUIRE(d->groups >= 0 && (d->groups <= 1 || d->B % d->groups == 0), "ccvs_gpt_decode_step: %d rows do not split into %d groups", d->B, d->groups);
-    CCVS_REQUIRE(d->B <= GEMM_DECODE_MAX_M, "ccvs_gpt_decode_step: at most %d rows per step", GEMM_DECODE_MAX_M);
+    // (more rows than the weight-stream form takes run the row-blocked form inside launch_gemm16; row groups cannot)
+    CCVS_REQUIRE(d->groups <= 1 || d->B <= GEMM_DECODE_MAX_M, "ccvs_gpt_decode_step: at most %d rows per grouped step", GEMM_DECODE_MAX_M);
     const int grp_rows = d->groups > 1 ? d->B / d->groups : 0;   // 0: one group (widx / len / state are single words)
     const size_t smem_att = (size_t)(16 + 4 * 256 + d->Tmax) * sizeof(float);
     const size_t smem_pick = (size_t)PICK_SMEM_WORDS(d->V) * sizeof(float);

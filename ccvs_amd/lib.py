@@ -31,6 +31,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32), ("accumulate", C.c_int32), ("out_scale", C.c_float),
         ("pre", C.c_void_p), ("pre_sN", C.c_int64), ("pre_sC", C.c_int64), ("pre_div", C.c_int32),
         ("in_p8", C.c_int32), ("out_p8", C.c_int32), ("cu_limit", C.c_int32),
+        ("w_ktail", C.c_void_p),
     ]
 
 

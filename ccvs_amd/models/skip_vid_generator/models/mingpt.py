@@ -378,15 +378,18 @@ class GPT(nn.Module):
         c = self._cache
         pos0 = 0 if pos_dev is not None else c["len"]
         C = self.config.n_embd
+        # whole-sequence calls always run the row-blocked GEMM form, single-position calls the weight-stream form: a row's
+        # bits must not depend on how many rows share the launch (include/ccvs_hip.h, CCVS_GEMM_SEQ)
+        seq = ops.GEMM_SEQ if tq > 1 else 0
         for i, blk in enumerate(self.blocks):
             # 5 launches per layer: [ln1 + QKV + cache scatter] [attention] [proj + residual]
             #                       [ln2 + fc + GELU] [fc2 + residual]
             qkv_w, fc_w = blk.folded()
             q = ops.gemm_ln_qkv(x, *qkv_w, c["k"][i], c["v"][i], b, tq, pos0, pos_dev, eps=blk.ln1.eps).view(b, tq, C)
             att = ops.attention(q, c["k"][i], c["v"][i], pos0, pos_dev)
-            ops.gemm_nt(att.view(b * tq, C), blk.attn.proj.weight, blk.attn.proj.bias, ops.EPI_RESIDUAL, residual=x, out=x)
-            h = ops.gemm_ln(x, *fc_w, eps=blk.ln2.eps, epilogue=ops.EPI_GELU)
-            ops.gemm_nt(h, blk.mlp[3].weight, blk.mlp[3].bias, ops.EPI_RESIDUAL, residual=x, out=x)
+            ops.gemm_nt(att.view(b * tq, C), blk.attn.proj.weight, blk.attn.proj.bias, ops.EPI_RESIDUAL | seq, residual=x, out=x)
+            h = ops.gemm_ln(x, *fc_w, eps=blk.ln2.eps, epilogue=ops.EPI_GELU | seq)
+            ops.gemm_nt(h, blk.mlp[3].weight, blk.mlp[3].bias, ops.EPI_RESIDUAL | seq, residual=x, out=x)
         if pos_dev is None:
             c["len"] = pos0 + tq
         return x

@@ -138,12 +138,18 @@ class QVidModel(torch.nn.Module):
         has_cond = isinstance(cond_inter, list) and len(cond_inter) > 0
         if has_cond:
             ctx += 1
-        for _ in range(opt.vid_len - ctx):
+        n_new = opt.vid_len - ctx
+        for step in range(n_new):
             inters = [[feat[:, order[mem - dt]: order[mem - dt] + 1] for feat in ring] for dt in opt.skip_context if dt <= curr]
             if has_cond:
                 inters.append(cond_inter)
             if opt.skip_mode == "enc":
                 fake_img, _ = self.net_g(z[:, curr:curr + 1], inters, has_ctx=curr > 0)
+                if step == n_new - 1:
+                    # the ring is local to this call and no frame follows: the reference's re-encode of the last
+                    # synthesized frame (quantized_video_model.py:890-891) feeds slots nobody reads -- not run
+                    fakes.append(fake_img)
+                    break
                 new_inter = self.encode(fake_img, None, "vid", False, None, None, quantize=False)["inter"]
             elif opt.skip_mode == "dec":
                 fake_img, _, _, _, inter_dec = self.net_g(z[:, curr:curr + 1], inters, return_all=True, inter_pre_warping=False,

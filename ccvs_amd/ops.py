@@ -13,6 +13,7 @@ from . import lib as _lib
 
 ACT_NONE, ACT_LRELU = 0, 1
 EPI_NONE, EPI_GELU, EPI_RESIDUAL = 0, 1, 2
+GEMM_SEQ = 0x100   # CCVS_GEMM_SEQ: whole-sequence call (OR-ed into the epilogue word)
 
 
 class KernelTimer:
@@ -85,12 +86,14 @@ CONV_CU_LIMIT = 0
 
 
 class PackedConv:
-    """Kernel-ready weights of one convolution (built once per parameter version)."""
-    __slots__ = ("kind", "data", "cin", "cout", "cout_pad", "k", "kw")
+    """Kernel-ready weights of one convolution (built once per parameter version).  `ktail`: the same weights with the
+    last 16-channel chunk in the packed-tail order (`ccvs_conv_desc.w_ktail`), or None."""
+    __slots__ = ("kind", "data", "cin", "cout", "cout_pad", "k", "kw", "ktail")
 
-    def __init__(self, kind, data, cin, cout, cout_pad, k, kw=None):
+    def __init__(self, kind, data, cin, cout, cout_pad, k, kw=None, ktail=None):
         self.kind, self.data, self.cin, self.cout, self.cout_pad, self.k = kind, data, cin, cout, cout_pad, k
         self.kw = k if kw is None else kw
+        self.ktail = ktail
 
 
 class P8Act:
@@ -138,7 +141,20 @@ def pack_conv_weight(weight, precision=None, scale=None):
     lo = (full - hi.float()).to(torch.bfloat16)
     lay = lambda t: t.view(kh * kw, cinp // 8, 8, cpad).permute(0, 1, 3, 2)
     out = torch.stack([lay(hi), lay(lo)], dim=2).contiguous()  # [tap][cg][2][cpad][8]
-    return PackedConv("bf16x3", out, cin, cout, cpad, kh, kw)
+    ktail = None
+    r = cin % 16
+    if kh == 3 and kw == 3 and 1 <= r <= 3 and cin > 16:
+        # Packed K tail (include/ccvs_hip.h, ccvs_conv_desc.w_ktail): the last chunk's 9 taps x r channels as ceil(9r/16)
+        # steps whose K position kk of step j holds (tap t, channel c) with 16 j + kk = t r + c; rest of the chunk zero.
+        tail = torch.zeros(kh * kw, 16, cpad, dtype=torch.float32, device=weight.device)   # [tap slot j][kk][cout]
+        q = torch.arange(9 * r, device=weight.device)
+        tail.view(-1, cpad)[q] = full[q // r, cin - r + q % r]
+        full_t = full.clone()
+        full_t[:, cinp - 16:] = tail
+        hi_t = full_t.to(torch.bfloat16)
+        lo_t = (full_t - hi_t.float()).to(torch.bfloat16)
+        ktail = torch.stack([lay(hi_t), lay(lo_t)], dim=2).contiguous()
+    return PackedConv("bf16x3", out, cin, cout, cpad, kh, kw, ktail=ktail)
 
 
 def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=False, residual=None,
@@ -189,6 +205,9 @@ def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=Fa
     d.accumulate = 1 if accumulate else 0
     d.out_scale = out_scale
     d.cu_limit = CONV_CU_LIMIT
+    kt = getattr(w_packed, "ktail", None)
+    if kt is not None and stride == 1 and not transposed and not in_p8:
+        d.w_ktail = kt.data_ptr()
     L = _lib.load()
     prof = KERNEL_TIMER
     if prof is not None:

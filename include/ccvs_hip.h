@@ -79,6 +79,15 @@ typedef struct ccvs_conv_desc {
      * finds free CUs beside the decoder's convolutions.  0: one launch, one workgroup per tile over the whole chip.
      * Results are identical either way. */
     int32_t cu_limit;
+    /* Packed K tail (ccvs_conv2d_bf16x3, 3 x 3 stride-1 layers with Cin % 16 = r in {1, 2, 3} and Cin > 16; NULL = none):
+     * a second copy of w_split in which the LAST 16-channel chunk -- r real channels, 16 - r of padding, nine tap steps
+     * of matrix work on mostly zeros -- is re-laid as ceil(9 r / 16) steps whose K index runs over (tap, channel) pairs:
+     * in tap slot j of tap row 0 of that chunk, K position kk holds w[tap t][Cin - r + c] with 16 j + kk = t r + c; the
+     * other slots of the chunk are zero.  The kernel gathers the matching (tap, channel) values of the staged tile for
+     * these steps, so the 49- and 99-channel inputs of Matching / Subpixel (skip_autoencoder.py:173-177,217-221) cost
+     * 28 / 56 tap steps instead of 36 / 63.  Used when the launch runs the vectorised producer / consumer kernel;
+     * every other form reads w_split.  Same products, same fp32 accumulator: sums differ only in their order. */
+    const void* w_ktail;
 } ccvs_conv_desc;
 
 int ccvs_conv2d(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
@@ -204,10 +213,14 @@ int ccvs_layernorm(const float* x, const float* gamma, const float* beta, float*
 
 /* y = epilogue(x @ W^T + bias): nn.Linear (mingpt.py:44-51,107-110,169).
  * x [M,K] row stride ldx, W [N,K] (torch Linear layout), y [M,N] row stride ldy.
- * epilogue: 0 none, 1 GELU(erf) (mingpt.py:109), 2 add residual (res [M,N], stride ldy).
+ * epilogue: 0 none, 1 GELU(erf) (mingpt.py:109), 2 add residual (res [M,N], stride ldy); OR-ed with CCVS_GEMM_SEQ for a
+ * whole-sequence call (prefill, teacher-forced forward, re-prefill of a slid window).  The flag picks the kernel form by the
+ * KIND of call instead of by M: a row's bits then do not depend on how many other rows share the launch (a batch prefilled
+ * alone and the same batch stacked into a token group agree bit for bit).  ccvs_gemm_ln_qkv derives it from Tq > 1.
  * workspace (may be NULL): ccvs_gemm_workspace_bytes() bytes of device memory, ZEROED once by the caller and
  * then owned by this call chain; with it, GEMMs with few output columns also split K across workgroups
  * (deterministic last-arriver reduction) so that every CU streams weights. */
+#define CCVS_GEMM_SEQ 0x100
 int64_t ccvs_gemm_workspace_bytes(void);
 int ccvs_gemm_nt(const float* x, int64_t ldx, const float* w, const float* bias, const float* res, float* y, int64_t ldy,
                  int32_t M, int32_t N, int32_t K, int32_t epilogue, void* workspace, void* stream);

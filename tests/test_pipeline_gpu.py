@@ -82,6 +82,47 @@ def test_decode_gemm_rows_do_not_depend_on_the_launch():
         assert (whole[2] - want).abs().max().item() < 2e-4
 
 
+def test_sequence_gemm_rows_do_not_depend_on_the_launch():
+    """Whole-sequence calls (`CCVS_GEMM_SEQ`; the QKV form with Tq > 1) run ONE kernel form whatever the row count: the rows of
+    a 256-row prefill (a batch alone) and the same rows inside a 272- / 768-row launch (the batch stacked into a token group)
+    are the same bits -- the old pick by M put 256 rows on the weight-stream kernel and 257+ on the row-blocked one, whose K
+    partitions differ.  Logits-level check: plain, deep-K, LayerNorm-folded + GELU, and the QKV form with its cache scatter."""
+    from ccvs_amd import ops
+    g = torch.Generator().manual_seed(9)
+    C, F, M = 256, 1024, 768
+    x = torch.randn(M, C, generator=g).cuda()
+    h = torch.randn(M, 4096, generator=g).cuda()
+    w_proj, b_proj = (torch.randn(C, C, generator=g) * 0.05).cuda(), torch.randn(C, generator=g).cuda()
+    w_fc2, b_fc2 = (torch.randn(C, 4096, generator=g) * 0.02).cuda(), torch.randn(C, generator=g).cuda()
+    w_fc, b_fc = (torch.randn(F, C, generator=g) * 0.05).cuda(), torch.randn(F, generator=g).cuda()
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    fc_packed = ops.pack_ln_linear(w_fc, b_fc, gamma, beta)
+    w_qkv, b_qkv = (torch.randn(3 * C, C, generator=g) * 0.05).cuda(), torch.randn(3 * C, generator=g).cuda()
+    qkv_packed = ops.pack_ln_linear(w_qkv, b_qkv, gamma, beta)
+    H, Tq = 4, 16
+    SEQ = ops.GEMM_SEQ
+
+    def run(m):
+        xs, hs = x[:m], h[:m]
+        out = [ops.gemm_nt(xs, w_proj, b_proj, ops.EPI_RESIDUAL | SEQ, residual=xs),
+               ops.gemm_nt(hs, w_fc2, b_fc2, ops.EPI_RESIDUAL | SEQ, residual=xs),
+               ops.gemm_ln(xs, *fc_packed, epilogue=ops.EPI_GELU | SEQ)]
+        kc, vc = torch.zeros(m // Tq, H, Tq, C // H, device="cuda"), torch.zeros(m // Tq, H, Tq, C // H, device="cuda")
+        out.append(ops.gemm_ln_qkv(xs, *qkv_packed, kc, vc, m // Tq, Tq, 0))
+        return out + [kc, vc]
+
+    ref = run(256)
+    for m in (64, 272, 768):
+        got = run(m)
+        n = min(m, 256)
+        for a, b in zip(ref[:4], got[:4]):
+            assert torch.equal(a[:n], b[:n]), m
+        for a, b in zip(ref[4:], got[4:]):
+            assert torch.equal(a[:n // Tq], b[:n // Tq]), m
+    want = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x[:256], (C,), gamma, beta) @ w_fc.t() + b_fc)
+    assert (ref[2] - want).abs().max().item() < 2e-4
+
+
 @pytest.mark.parametrize("batch,groups,sample", [(16, 3, True), (5, 3, True), (24, 2, True), (16, 4, False)])
 def test_grouped_token_loop_equals_per_batch(batch, groups, sample):
     """`ccvs_gpt_decode.groups`: the token loops of several batches as ONE loop over their stacked rows (weights streamed once
@@ -110,6 +151,21 @@ def test_grouped_token_loop_equals_per_batch(batch, groups, sample):
         assert torch.equal(eager[g * batch:(g + 1) * batch], alone[g])
     if sample:
         assert not torch.equal(alone[0][:, 16:], alone[1][:, 16:])
+
+
+def test_decode_step_with_more_rows_than_the_weight_stream_form():
+    """A graph-replayed generation with more than 256 rows and one group (a large --batch on a small configuration) runs: the
+    decode step's GEMMs fall to the row-blocked form inside the launcher.  Greedy tokens equal the eager (per-op) loop's, and
+    the first 8 rows equal a generation of those 8 rows alone up to the first near-tie (different GEMM forms: low bits)."""
+    from ccvs_amd.models.skip_vid_generator.models import mingpt
+    torch.manual_seed(3)
+    net = mingpt.GPT(vocab_size=64, block_size=48, num_blocks=3, n_layer=2, n_head=2, n_embd=64, emb_mode="temporal", shape=(4, 4)).cuda()
+    for p in net.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    codes = torch.randint(0, 64, (320, 16), device="cuda")
+    graph = net.generate(codes, 12, sample=False)
+    eager = net.generate(codes, 12, sample=False, use_graph=False)
+    assert graph.shape == (320, 28) and torch.equal(graph, eager)
 
 
 def test_conv_cu_limit_is_bit_identical():

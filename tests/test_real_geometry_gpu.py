@@ -169,6 +169,55 @@ def test_bair_teacher_forced_15_frames_vs_oracle():
     assert max(per_frame) < PIX_TOL, per_frame
 
 
+def test_bair_default_init_codebook_tie_audit():
+    """the run with the reference's DEFAULT codebook initialiser U(-1/n_e, 1/n_e) (quantize.py:30), reported
+    separately with a tie audit.  One BAIR encode (B = 1, two 256 x 256 frames = 128 latent positions against 1024 codes of
+    512 dims): the distances |z|^2 + |e|^2 - 2 z.e are dominated by |z|^2 (|e| <= 0.03), so neighbouring codes sit within a few
+    ulp of each other and every argmin is a near-tie.  Indices vs the oracle; every mismatch must lie inside the oracle's own
+    rounding of the distance (the rule of test_vq_golden[default]): |d[got] - d[want]| <= 4 eps max|d|.  The count is printed."""
+    from ccvs_amd.tools.options import Options, BAIR_ARGV
+    from ccvs_amd.models.skip_vid_generator.models.quantized_video_model import QVidModel
+    opt = Options().parse(load_qvid_generator=True, load_transformer=True, argv=list(BAIR_ARGV))
+    qopt = opt["qvid_generator"]
+    torch.manual_seed(0)
+    qv = QVidModel(qopt, is_train=False, is_main=True).eval()   # codebook as the reference initialises it: no calibration
+    cb = qv.net_q.embedding.weight.detach()
+    assert cb.shape == (1024, 512) and float(cb.abs().max()) <= 1.0 / 1024
+    vid = torch.rand(1, 2, 3, 256, 256, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    enc = qv({"vid": vid.clone()}, mode="vid_encoder")
+    nets = {"e": cpu_sd(qv.net_e), "q": cpu_sd(qv.net_q), "g": cpu_sd(qv.net_g)}
+    with torch.no_grad():
+        want = O.qvid_encode(nets, qopt, vid)
+        z_e = O.encoder_forward(nets["e"], qopt, vid)[0].reshape(-1, 512, 8, 8)       # the oracle's pre-quantisation latents
+        z_hip = qv.net_e(vid.cuda())[0].reshape(-1, 512, 8, 8).cpu()                    # the HIP encoder's
+    got, ref = enc["code"].cpu().flatten(), want["code"].flatten()
+    assert got.shape == ref.shape == (128,)
+    c = nets["q"]["embedding.weight"]
+    zf = z_e.permute(0, 2, 3, 1).reshape(-1, 512)
+    dz = (z_hip - z_e).permute(0, 2, 3, 1).reshape(-1, 512).norm(dim=1)               # |z_hip - z_oracle| per position
+    d = (zf ** 2).sum(1, keepdim=True) + (c ** 2).sum(1) - 2 * zf @ c.t()
+    tol = 4 * torch.finfo(torch.float32).eps * d.abs().max(dim=1).values
+
+    def audit(a, b, what, moved):
+        bad = (a != b).nonzero().flatten().tolist()
+        for r in bad:
+            gap = (d[r, a[r]] - d[r, b[r]]).abs().item()
+            # a latent that moved by dz shifts the distance DIFFERENCE of two codes by at most 2 |dz| |e_a - e_b| (Cauchy-Schwarz)
+            lim = tol[r].item() + (2 * dz[r] * (c[a[r]] - c[b[r]]).norm()).item() * moved
+            assert gap <= lim, f"{what}: position {r}: codes {int(a[r])} vs {int(b[r])}, distance gap {gap:.3e} > {lim:.3e}"
+        return len(bad)
+
+    # (a) the argmin kernel alone on the ORACLE's latents (free of convolution round-off): ties inside the rounding of d only
+    k_idx = qv.net_q.indices(z_e.cuda()).cpu().flatten()
+    n_kernel = audit(k_idx, O.vq_indices(z_e, c).flatten(), "argmin kernel on the oracle's latents", 0)
+    # (b) the whole encode (split-bf16 convolutions + argmin) against the oracle's codes
+    n_e2e = audit(got, ref, "encode", 1)
+    top2 = d.topk(2, dim=1, largest=False).values
+    print(f"\nBAIR default-init codebook (U(+-1/1024)): {n_kernel} / 128 positions differ in the argmin kernel alone, "
+          f"{n_e2e} / 128 through the whole encode, all inside the audited bound (median top-2 gap "
+          f"{float((top2[:, 1] - top2[:, 0]).median()):.2e}, median 4 eps max|d| {float(tol.median()):.2e}, max |dz| {float(dz.max()):.2e})")
+
+
 @pytest.fixture(scope="module")
 def big_gpt():
     from ccvs_amd.models.skip_vid_generator.models.mingpt import GPT
