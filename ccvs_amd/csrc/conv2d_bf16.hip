@@ -5,7 +5,7 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
-#define CB_DECL(TWv, MBv) int ccvs_conv_bf16_launch_##TWv##_##MBv(const ConvK& k, const void* wsplit, const void* wktail, int CinG, int halo_h, int halo_w, int ntx_max, int gz, hipStream_t st);
+#define CB_DECL(TWv, MBv) int ccvs_conv_bf16_launch_##TWv##_##MBv(const ConvK& k, const void* wsplit, const void* wktail, int CinG, int halo_h, int halo_w, int ntx_max, int gz, hipStream_t st, int wpc2);
 CB_DECL(32, 4) CB_DECL(32, 2) CB_DECL(32, 1) CB_DECL(16, 4) CB_DECL(16, 2) CB_DECL(16, 1) CB_DECL(8, 4) CB_DECL(8, 2) CB_DECL(8, 1)
 #undef CB_DECL
 
@@ -63,10 +63,19 @@ extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const flo
     // chip.  Narrower channel blocks give the same tiles to 2-4 x as many workgroups (same arithmetic per output, bit-identical).
     static const int small_split = getenv("CCVS_CONV_SMALL_SPLIT") ? atoi(getenv("CCVS_CONV_SMALL_SPLIT")) : 256;   // workgroups aimed at; 0: off
     while (mb > 1 && (long)k.tiles_x * k.tiles_y * gz * (d->CoutPad / (32 * mb)) < small_split) mb >>= 1;
+    // Few input channels per output byte (the 49- and 99-channel layers in front of 128 outputs): 64 output channels per
+    // workgroup and two workgroups per CU, so that one tile's prologue / epilogue runs beside the other's K loop
+    // (conv2d_bf16_kernels.h, WPC).  CCVS_CONV_WPC2 = largest Cin that takes this form (0: off).
+    static const int wpc2_cin = getenv("CCVS_CONV_WPC2") ? atoi(getenv("CCVS_CONV_WPC2")) : 0;
+    int wpc2 = 0;
+    if (wpc2_cin > 0 && mb >= 2 && TW == 32 && d->Cin <= wpc2_cin && d->kh == 3 && d->kw == 3 && d->stride == 1 && !d->transposed && !d->in_p8 && !d->out_p8) {
+        mb = 2;
+        wpc2 = 1;
+    }
 #define CB_DISPATCH(TWv)                                                                                        \
-    if (mb == 4) return ccvs_conv_bf16_launch_##TWv##_4(k, w_split, d->w_ktail, CinG, halo_h, halo_w, ntx_max, gz, st);           \
-    if (mb == 2) return ccvs_conv_bf16_launch_##TWv##_2(k, w_split, d->w_ktail, CinG, halo_h, halo_w, ntx_max, gz, st);           \
-    return ccvs_conv_bf16_launch_##TWv##_1(k, w_split, d->w_ktail, CinG, halo_h, halo_w, ntx_max, gz, st);
+    if (mb == 4) return ccvs_conv_bf16_launch_##TWv##_4(k, w_split, d->w_ktail, CinG, halo_h, halo_w, ntx_max, gz, st, wpc2);           \
+    if (mb == 2) return ccvs_conv_bf16_launch_##TWv##_2(k, w_split, d->w_ktail, CinG, halo_h, halo_w, ntx_max, gz, st, wpc2);           \
+    return ccvs_conv_bf16_launch_##TWv##_1(k, w_split, d->w_ktail, CinG, halo_h, halo_w, ntx_max, gz, st, wpc2);
     if (TW == 32) { CB_DISPATCH(32) }
     if (TW == 16) { CB_DISPATCH(16) }
     CB_DISPATCH(8)

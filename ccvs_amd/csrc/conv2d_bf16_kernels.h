@@ -241,8 +241,15 @@ __global__ __launch_bounds__(64 * NW) void conv2d_bf16x3_kernel(ConvK p, const u
 // 128->64 3x3, 2.4x its pure MFMA time).  Four pixel blocks held in registers against the same weight fragments bring a
 // 64-channel layer to the read intensity of a 128-channel one (2 MB + 8 reads for 12 MB MFMAs) at the same accumulator
 // count (MB x PP x 16 = 128).  VEC staging only (dense stride-1 rows), two activation items per staging thread.
-template <int TW, int MB, int NTY, int PP = 2>
-__global__ __launch_bounds__(512, (MB == 1 && PP == 2) ? 4 : 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
+// WPC = 2 (64 output channels per workgroup, dense 3 x 3 only): compiled for TWO workgroups per CU (<= 128 VGPRs, ~77 KB of
+// LDS each, one register set in the staging waves).  A tile's prologue (workgroup launch, first chunk: ~5 us) and epilogue
+// (131 KB of output per 128-channel tile: ~10 us at the rate the chip writes) are not overlapped with anything while a CU holds
+// ONE workgroup -- CCVS_CONV_ABLATE runs: 14.5 us of the 36 us a 49->128 tile takes, 40 % -- so layers with few input channels
+// per output byte gain from a second resident workgroup whose K loop runs meanwhile, although its activations are then
+// staged once per 64 output channels instead of once per 128.
+template <int TW, int MB, int NTY, int PP = 2, int WPC = 1>
+__global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
+    static_assert(WPC == 1 || (WPC == 2 && MB == 2 && PP == 2 && NTY == 3), "two workgroups per CU: the 64-channel 3 x 3 form only");
     static_assert(PP == 2 || (PP == 4 && NTY > 0 && MB == 2), "the 512-pixel tile exists for the VEC staging mode and 64 output channels");
     constexpr bool VEC = NTY > 0;
     // NTY == -8: the input is a packed split-bf16 activation (P8: [N][C/8][hi|lo][H][W] x 8 bf16, written by the epilogue of
@@ -262,6 +269,16 @@ __global__ __launch_bounds__(512, (MB == 1 && PP == 2) ? 4 : 2) void conv2d_bf16
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Wave priority of the WHOLE workgroup (bits 16-17 of `ablate`, set by the launcher from CCVS_CONV_PRIO): beside the token
+    // loops of other batches every SIMD also hosts waves of the decode kernels, and vector / memory issue is arbitrated by
+    // priority, then age (tools/conv_contention_probe.py: one memory-streaming wave per SIMD costs the convolution 20-35 %,
+    // a VALU-spinning one 140-200 % -- whether its loads hit L2 or HBM makes no difference).
+    {
+        const int prio = (ablate >> 16) & 3;
+        if (prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    }
     // (measured: making the role provably wave-uniform with readfirstlane, or s_setprio(1) on the MFMA
     //  waves, both cost ~25 % on the 195->128 3x3 shape with hipcc / ROCm 7.2 -- left as plain predication)
     const bool producer = wave >= 4;
@@ -582,7 +599,7 @@ __global__ __launch_bounds__(512, (MB == 1 && PP == 2) ? 4 : 2) void conv2d_bf16
         constexpr int NTYc = VEC ? NTY : 1;
         const bool work = !(ablate & (1 | 256));   // 256: weights still arrive, activations are not staged
         const bool drain = ablate & 64;   // experiments: the old __syncthreads() steps
-        const bool deep = !(ablate & 2048);   // 2048: one chunk of lead (the round-2 schedule)
+        const bool deep = WPC == 1 && !(ablate & 2048);   // 2048: one chunk of lead (the round-2 schedule; always with two workgroups per CU)
         if (work) {
             load_xv(0, min(1, nchunks - 1));
             if (deep) load_xv(1, min(2, nchunks - 1));
@@ -705,6 +722,38 @@ __global__ __launch_bounds__(512, (MB == 1 && PP == 2) ? 4 : 2) void conv2d_bf16
                     if (tb < ntx) { CB_TAP4(0, tb, false) }
                 }
 #undef CB_TAP4
+            } else if constexpr (WPC == 2) {
+                // two workgroups per CU: every SIMD hosts two MFMA waves, one of which computes while the other waits for its
+                // fragments -- plain reads (no second register set: the 128-VGPR budget), weights one block ahead
+                const int ntx = ax.nt, xd0 = ax.d0 - ax.lo, xdd = ax.dd;
+#pragma unroll
+                for (int tb = 0; tb < 3; ++tb) {
+                    if (tb < ntx) {
+                        const uint4* it_ = it0 + (xd0 + tb * xdd);
+                        const uint4* wt_ = wt0 + tb * 4 * NT;
+                        bf16x8 qb[2][2], wa[2][2];
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp) {
+                            qb[pp][0] = __builtin_bit_cast(bf16x8, it_[bofs[pp]]);
+                            qb[pp][1] = __builtin_bit_cast(bf16x8, it_[plane + bofs[pp]]);
+                        }
+                        wa[0][0] = __builtin_bit_cast(bf16x8, wt_[0]);
+                        wa[0][1] = __builtin_bit_cast(bf16x8, wt_[NT]);
+#pragma unroll
+                        for (int m = 0; m < MB; ++m) {
+                            if (m + 1 < MB) {
+                                wa[(m + 1) & 1][0] = __builtin_bit_cast(bf16x8, wt_[(m + 1) * 32]);
+                                wa[(m + 1) & 1][1] = __builtin_bit_cast(bf16x8, wt_[NT + (m + 1) * 32]);
+                            }
+#pragma unroll
+                            for (int pp = 0; pp < 2; ++pp) {
+                                acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[m & 1][1], qb[pp][0], acc[m][pp], 0, 0, 0);
+                                acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[m & 1][0], qb[pp][1], acc[m][pp], 0, 0, 0);
+                                acc[m][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[m & 1][0], qb[pp][0], acc[m][pp], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
             } else {
             // Software-pipelined fragment reads: the ds_reads of the NEXT 32-cout block (and, on a tap's last block,
             // of the next tap's pixels) are issued before the current block's 6 MFMAs, into the other register
@@ -821,6 +870,7 @@ __global__ __launch_bounds__(512, (MB == 1 && PP == 2) ? 4 : 2) void conv2d_bf16
         }
       }
     }
+    if (ablate & 16384) return;   // timing experiments: no epilogue (nothing is written)
     // ---- epilogue ------------------------------------------------------------------------------
     // Dense convolutions: the accumulators (one pixel column per lane, 16 couts in registers) go
     // through LDS so that ALL 8 waves write 16-byte pieces along x (a lane then owns 4 consecutive
@@ -967,7 +1017,7 @@ static int conv_occupancy(const void* fn, int threads, size_t smem_bytes) {
 }
 
 template <int TW, int MB>
-static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* wktail, int CinG, int halo_h, int halo_w, int ntx_max, int gz, hipStream_t st) {
+static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* wktail, int CinG, int halo_h, int halo_w, int ntx_max, int gz, hipStream_t st, int wpc2) {
     constexpr int NT = 32 * MB;
     int plane = halo_h * halo_w;
     if (plane > 256 * CB_MAX_E) {
@@ -985,7 +1035,9 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
         (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    static const int ablate = getenv("CCVS_CONV_ABLATE") ? atoi(getenv("CCVS_CONV_ABLATE")) : 0;  // timing experiments only (1: no staging, 2: no MFMA, 4: scalar staging, 128: no weight DMA, 256: no activation staging)
+    static const int ablate_env = getenv("CCVS_CONV_ABLATE") ? atoi(getenv("CCVS_CONV_ABLATE")) : 0;  // timing experiments only (1: no staging, 2: no MFMA, 4: scalar staging, 128: no weight DMA, 256: no activation staging)
+    static const int conv_prio = getenv("CCVS_CONV_PRIO") ? atoi(getenv("CCVS_CONV_PRIO")) : 0;   // s_setprio of the producer / consumer kernels (0-3)
+    const int ablate = (ablate_env & 0xffff) | ((conv_prio & 3) << 16);
     ConvK k = k_in;
     const dim3 grid3(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
     // cu_limit > 0: the tiles go out as consecutive 1-D chunks of cu_limit x (workgroups of this instantiation that fit one
@@ -1049,7 +1101,7 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
         static const int pp4 = getenv("CCVS_CONV_PP4") ? atoi(getenv("CCVS_CONV_PP4")) : 1;
         const int th4 = 16, halo_h4 = (th4 - 1) + k.kh;
         const size_t smem_4 = (size_t)(2 * 4 * halo_h4 * (nq * 4 + 1) + 2 * ntx_max * 4 * NT) * 16;
-        if (pp4 && vec_ok && !k.out_p8 && k.Hout >= 2 * th4 && halo_h4 * ((nq + 1) / 2) * 4 <= 512 && smem_4 <= 156 * 1024 && smem_4 >= (size_t)32 * 512 * 4) {
+        if (pp4 && !wpc2 && vec_ok && !k.out_p8 && k.Hout >= 2 * th4 && halo_h4 * ((nq + 1) / 2) * 4 <= 512 && smem_4 <= 156 * 1024 && smem_4 >= (size_t)32 * 512 * 4) {
             k.tiles_y = cdiv(k.Hout, th4);
             const dim3 grid4(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
             const long total4 = (long)grid4.x * grid4.y * grid4.z;
@@ -1074,6 +1126,20 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
     }
     if (vec_ok) {
         const size_t smem_v = (size_t)(2 * 4 * halo_h * (nq * 4 + 1) + 2 * ntx_max * 4 * NT) * 16;
+        if constexpr (TW == 32 && MB == 2) {
+            if (wpc2 && k.kh == 3 && k.kw == 3 && smem_v <= 80 * 1024 && k.cu_limit <= 0) {   // two workgroups per CU (see the kernel)
+                static bool attr2 = false;
+                if (!attr2) {
+                    (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 3, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    attr2 = true;
+                }
+                k.ktail = kt ? ktail_r : 0;
+                CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, 3, 2, 2>), 512, smem_v, (const uint4*)(kt ? wktail : wsplit), CinG, ntx_max, ablate);
+                k.ktail = 0;
+                CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
+                return CCVS_OK;
+            }
+        }
         if (smem_v <= 156 * 1024) {
             if (k.kh == 3) {
                 k.ktail = kt ? ktail_r : 0;

@@ -400,6 +400,158 @@ __global__ __launch_bounds__(512) void gemm16_rb_kernel(Gemm16 p) {
     }
 }
 
+// Whole-sequence form (CCVS_GEMM_SEQ: prefill, teacher-forced forward, re-prefill of a slid window): a dense LDS-tiled GEMM
+// on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products, 157 TFLOP/s peak).  With hundreds to thousands of rows
+// the weights are no longer a stream to be read once but operands to be re-used: the row-blocked kernel above fetches every
+// operand from global memory per 64 rows x 16 columns (52-82 TFLOP/s).
+//   * workgroup = 4 waves = a 128 x 128 output tile, wave w the 64 x 64 quadrant (w >> 1, w & 1): 2 x 2 MFMA blocks, 64
+//     accumulator registers; K in stages of 16;
+//   * both operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, the next stage is in flight
+//     while this one is multiplied), double-buffered, one barrier per stage.  LDS image of an operand stage:
+//     [k quad q = 0..3][row 0..127][4 floats], quads 129 units apart -- a wave-instruction of the DMA fills 64 consecutive
+//     rows of one quad (the per-lane SOURCE address does the transposition), and the fragment read of a 32-row block is 32
+//     consecutive 16-byte units per lane half: conflict-free ds_read_b128;
+//   * lane half h reads k = 8 s + 4 h .. + 3 of sub-step s for both operands, and MFMA j of the sub-step contracts the pair
+//     (8 s + j, 8 s + 4 + j): the contraction order over k is free as long as both operands agree;
+//   * the folded LayerNorm's row statistics are summed from the x stages in LDS (thread t: row t >> 1, k quads 2 (t & 1), +1);
+//   * epilogue as everywhere (LayerNorm fold, bias, GELU, residual, K / V scatter into the cache); a 32 x 32 block leaves as
+//     128-byte row segments.
+// A row's arithmetic depends on (N, K) only -- never on M or on the tile the row falls into -- so a batch prefilled alone and
+// the same batch inside a stacked token group agree bit for bit (tests/test_pipeline_gpu.py).
+// Workgroup order: XCD j (linear id % 8) walks the row tiles j, j + 8, ...: the workgroups that share a row tile of x meet
+// in one L2, and every XCD streams the weights once per round of eight row tiles.
+#define GS_BM 128
+#define GS_QS (GS_BM + 1)   // 16-byte units between the k quads of an operand stage
+typedef __attribute__((address_space(3))) void gs_lds_void;
+__global__ __launch_bounds__(256, 4) void gemm_seq_kernel(Gemm16 p, int row_tiles, int col_tiles) {
+    // two separate LDS variables, one per stage buffer, and the stage loop unrolled by two: hipcc orders a ds_read behind an
+    // in-flight LDS-DMA unless the two provably touch different LDS objects -- with one array indexed by (stage & 1) every
+    // fragment read waited (vmcnt 0) for the DMA of the NEXT stage issued just before it, and nothing overlapped
+    __shared__ __attribute__((aligned(16))) f32x4 sm0[2 * 4 * GS_QS];   // [x | w][quad][row]
+    __shared__ __attribute__((aligned(16))) f32x4 sm1[2 * 4 * GS_QS];
+    __shared__ float fin[GS_BM * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int rt, ct;
+    {
+        const int w = blockIdx.x;
+        if (row_tiles % 8 == 0) {
+            const int i = w >> 3;
+            rt = (w & 7) + 8 * (i / col_tiles);
+            ct = i % col_tiles;
+        } else {
+            rt = w / col_tiles;
+            ct = w - rt * col_tiles;
+        }
+    }
+    const int m0 = rt * GS_BM, n0 = ct * GS_BM;
+    // DMA: 16 wave-instructions per stage, 4 per wave: wave q fills k quad q of both operands, two halves of 64 rows each.
+    // buffer_load ... lds: a 128-bit descriptor per operand in SGPRs, a per-lane byte offset that never changes and the
+    // stage's K offset as the scalar offset -- no address VGPR is rewritten inside the loop (with global_load_lds hipcc builds
+    // a 64-bit address in a VGPR pair per DMA and waits, vmcnt 0, for the previous DMA before it overwrites the pair).
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((long)p.M * p.ldx * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((long)p.N * p.K * 4), 0x00020000);
+    unsigned xoff[2], woff[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        xoff[hf] = (unsigned)((long)min(m0 + 64 * hf + lane, p.M - 1) * p.ldx + 4 * wave) * 4u;
+        woff[hf] = (unsigned)((long)min(n0 + 64 * hf + lane, p.N - 1) * p.K + 4 * wave) * 4u;
+    }
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
+    float sx = 0.f, sxx = 0.f;
+    const int nst = p.K / 16;
+#define GS_DMA(k0, SM)                                                                                             \
+    _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                             \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (gs_lds_void*)((SM) + wave * GS_QS + 64 * hf), 16, xoff[hf], (k0) * 4, 0, 0);               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (gs_lds_void*)((SM) + 4 * GS_QS + wave * GS_QS + 64 * hf), 16, woff[hf], (k0) * 4, 0, 0);  \
+    }
+#define GS_STAGE(SM, NEXT_DMA)                                                                                     \
+    {                                                                                                              \
+        const f32x4* xa = (SM);                                                                                    \
+        const f32x4* wb = (SM) + 4 * GS_QS;                                                                        \
+        f32x4 a[2][2], b[2][2], t0, t1;                                                                            \
+        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                         \
+            const int q = 2 * s2 + h;                                                                              \
+            _Pragma("unroll") for (int bi = 0; bi < 2; ++bi) a[s2][bi] = xa[q * GS_QS + 64 * wr + 32 * bi + l31];  \
+            _Pragma("unroll") for (int bj = 0; bj < 2; ++bj) b[s2][bj] = wb[q * GS_QS + 64 * wc + 32 * bj + l31];  \
+        }                                                                                                          \
+        if (p.ln_s) {                                                                                              \
+            const int r = tid >> 1, q0 = 2 * (tid & 1);                                                            \
+            t0 = xa[q0 * GS_QS + r];                                                                               \
+            t1 = xa[(q0 + 1) * GS_QS + r];                                                                         \
+        }                                                                                                          \
+        /* every LDS read of this stage is issued BEFORE the next stage's DMA: hipcc orders a ds_read behind any */ \
+        /* LDS-DMA still in flight (s_waitcnt vmcnt(0)), which would serialise the stages                        */ \
+        NEXT_DMA                                                                                                   \
+        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                                                           \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
+                _Pragma("unroll") for (int bi = 0; bi < 2; ++bi)                                                   \
+                    _Pragma("unroll") for (int bj = 0; bj < 2; ++bj)                                               \
+                        acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2][bi][j], b[s2][bj][j], acc[bi][bj], 0, 0, 0); \
+        if (p.ln_s) {                                                                                              \
+            ln_accum(t0, sx, sxx);                                                                                 \
+            ln_accum(t1, sx, sxx);                                                                                 \
+        }                                                                                                          \
+    }
+    GS_DMA(0, sm0)
+    for (int st = 0; st < nst; st += 2) {
+        __syncthreads();                                   // stage st has landed (the barrier drains vmcnt) and the other buffer is free
+        GS_STAGE(sm0, if (st + 1 < nst) { GS_DMA(16 * (st + 1), sm1) })
+        if (st + 1 >= nst) break;
+        __syncthreads();
+        GS_STAGE(sm1, if (st + 2 < nst) { GS_DMA(16 * (st + 2), sm0) })
+    }
+#undef GS_DMA
+#undef GS_STAGE
+    if (p.ln_s) {
+        sx += __shfl_xor(sx, 1, 64);
+        sxx += __shfl_xor(sxx, 1, 64);
+        if (!(tid & 1)) {
+            float mean, rstd;
+            ln_finish(sx, sxx, p.K, p.ln_eps, mean, rstd);
+            fin[(tid >> 1) * 2] = mean;
+            fin[(tid >> 1) * 2 + 1] = rstd;
+        }
+        __syncthreads();
+    }
+    int pos0 = p.pos0;
+    if (p.kcache && p.pos_dev) pos0 += *p.pos_dev;
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+        const int col = n0 + 64 * wc + 32 * bj + l31;
+        if (col >= p.N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+        const float sn = p.ln_s ? p.ln_s[col] : 0.f;
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = 64 * wr + 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = m0 + lr;
+                if (row >= p.M) continue;
+                const float v = gemm_epilogue(acc[bi][bj][r], p.ln_s != nullptr, p.ln_s ? fin[lr * 2 + 1] : 0.f, p.ln_s ? fin[lr * 2] : 0.f, sn, bv,
+                                              p.epi, p.epi == 2 ? p.res[(long)row * p.ldy + col] : 0.f);
+                if (p.kcache && col >= p.C) {
+                    const int cc = col - p.C;
+                    float* cache = cc >= p.C ? p.vcache : p.kcache;
+                    const int c2 = cc >= p.C ? cc - p.C : cc;
+                    const int hh = c2 / p.D, d = c2 - hh * p.D;
+                    const int b = row / p.Tq, t = row - b * p.Tq;
+                    if (pos0 + t < p.Tmax) cache[(((long)b * p.H + hh) * p.Tmax + pos0 + t) * p.D + d] = v;
+                } else {
+                    p.y[(long)row * p.ldy + col] = v;
+                }
+            }
+        }
+    }
+}
+
 // K slices across workgroups (split-K): spreads GEMMs with few output columns over the chip.  Pays only for deep K:
 // the release/acquire hand-off costs ~3-4 us (measured).
 static int getenv_int(const char* name, int dflt) {
@@ -446,7 +598,11 @@ static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
     if (g.kz > 1 && cdiv(g.N, 16) * cdiv(g.M, 16) > GEMM_WS_TILES) g.kz = 1;   // cannot happen for M <= 256 (kz > 1 needs <= 64 column tiles)
     g.ks = decode_form ? GEMM_WAVES : 8;
     while (g.ks > 1 && g.K % (16 * g.ks * g.kz) != 0) g.ks >>= 1;
-    if (!decode_form)
+    static const int seq_dense = getenv_int("CCVS_GEMM_SEQ_DENSE", 1);   // 0: the row-blocked weight-stream form of rounds 2-3
+    if (!decode_form && g.seq && seq_dense && (long)g.M * g.ldx * 4 < (1L << 31) && (long)g.N * g.K * 4 < (1L << 31)) {   // (buffer descriptors: 32-bit byte offsets)
+        const int rt = cdiv(g.M, GS_BM), ct = cdiv(g.N, GS_BM);
+        hipLaunchKernelGGL(gemm_seq_kernel, dim3(rt * ct), dim3(256), 0, st, g, rt, ct);
+    } else if (!decode_form)
         hipLaunchKernelGGL((gemm16_rb_kernel<4>), dim3(cdiv(g.N, 16), cdiv(g.M, 64), 1), dim3(512), 0, st, g);
     else if (decode_nt() & 2)
         hipLaunchKernelGGL(gemm16_kernel<2>, dim3(cdiv(g.N, 16), cdiv(g.M, 16), g.kz), dim3(64 * GEMM_WAVES), 0, st, g.x, g.w, g.ldx, g.K, g.N, g.M, g.ks,
