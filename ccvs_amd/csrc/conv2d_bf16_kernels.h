@@ -17,6 +17,7 @@
 #include "common.h"
 #include "conv_common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -83,6 +84,60 @@ __device__ __forceinline__ void stage_pixel(const float* __restrict__ xn, long i
     }
 }
 
+// Epilogue of one 32-channel x 32-pixel accumulator block written straight from registers (stride-2 / transposed layers and the
+// synchronous kernel: a lane owns one output pixel and 16 of the channels).  `s_waitcnt vmcnt` counts stores as well as loads, so
+// a load issued behind a store cannot be waited for without also waiting until the store has been acknowledged by memory
+// (~0.6 us): with bias, residual and store interleaved element by element -- the form of rounds 1-3 -- a wave paid that round trip
+// 64-128 times per tile, several times the tile's matrix work.  Here the bias comes from LDS (`bias_s`: the 32 values of the
+// block), the addend of all 16 elements is fetched first, and the 16 stores follow each other without a load in between.
+// add_kind: 0 none, 1 pre-activation image, 2 residual, 3 accumulate, 4 several (element by element).
+__device__ __forceinline__ void epi_block16(const ConvK& p, const f32x16& a, const float* bias_s, int n, int co0, long opix, int add_kind) {
+    float* yb = p.y + (long)n * p.out_sN + opix;
+    if (add_kind == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cl = (r & 3) + 8 * (r >> 2), co = co0 + cl;
+            if (co < p.Cout) {
+                float v = a[r] + bias_s[cl];
+                if (p.act == CCVS_ACT_LRELU) v = lrelu01(v);
+                yb[(long)co * p.out_sC] = v * p.out_scale;
+            }
+        }
+    } else {
+        const float* pb = p.pre ? p.pre + (long)(n / p.pre_div) * p.pre_sN + opix : nullptr;
+        const float* rb = p.res ? p.res + (long)n * p.res_sN + opix : nullptr;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 8) {   // (two halves: 24 registers of addends instead of 48 -- the 32-channel kernels are capped at 128)
+            float a1[8], a2[8], a3[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = r0 + q;
+                const long co = min(co0 + (r & 3) + 8 * (r >> 2), p.Cout - 1);
+                a1[q] = pb ? pb[co * p.pre_sC] : 0.f;
+                a2[q] = rb ? rb[co * p.res_sC] : 0.f;
+                a3[q] = p.accumulate ? yb[co * p.out_sC] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = r0 + q;
+                const int cl = (r & 3) + 8 * (r >> 2), co = co0 + cl;
+                if (co < p.Cout) {
+                    float v = (a[r] + a1[q]) + bias_s[cl];
+                    if (p.act == CCVS_ACT_LRELU) v = lrelu01(v);
+                    v = (v + a2[q]) * p.out_scale;
+                    yb[(long)co * p.out_sC] = v + a3[q];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (or hipcc hoists the loads of every following block above these stores: ~100 registers, spilled)
+        }
+    }
+}
+
+__device__ __forceinline__ int conv_add_kind(const ConvK& p) {
+    const int n_add = (p.pre ? 1 : 0) + (p.res ? 1 : 0) + (p.accumulate ? 1 : 0);
+    return n_add == 0 ? 0 : (n_add > 1 ? 4 : (p.pre ? 1 : (p.res ? 2 : 3)));
+}
+
 // NW waves (4 or 8): with 8, every wave owns ONE 32-pixel block (half the accumulators) and twice as many threads stage the
 // halo tile -- the workgroup is alone on its CU (LDS), so the extra waves are what overlaps its loads (env CCVS_CONV_SYNC_WAVES).
 template <int TW, int MB, int NW>
@@ -91,6 +146,7 @@ __global__ __launch_bounds__(64 * NW) void conv2d_bf16x3_kernel(ConvK p, const u
     constexpr int NT = 32 * MB;
     constexpr int NTH = 64 * NW, PP = 8 / NW;
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+    __shared__ float bias_s[32 * MB];   // read in the epilogue (epi_block16)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     CONV_TILE_COORDS(p, bx, by, bz)
@@ -101,6 +157,7 @@ __global__ __launch_bounds__(64 * NW) void conv2d_bf16x3_kernel(ConvK p, const u
     const AxisTaps ay = axis_taps(p.kh, p.stride, p.pad, p.transposed, cls >> 1, p.Hout);
     const AxisTaps ax = axis_taps(p.kw, p.stride, p.pad, p.transposed, cls & 1, p.Wout);
     if (ty * TH >= ay.V || tx * TW >= ax.V) return;
+    if (tid < 32 * MB) bias_s[tid] = (p.bias && n0 + tid < p.Cout) ? p.bias[n0 + tid] : 0.f;   // visible after the first barrier of the chunk loop
 
     const int IH = (TH - 1) * ay.s + ay.ext + 1;
     const int IW = (TW - 1) * ax.s + ax.ext + 1;
@@ -184,6 +241,7 @@ __global__ __launch_bounds__(64 * NW) void conv2d_bf16x3_kernel(ConvK p, const u
         }
     }
 
+    const int add_kind = conv_add_kind(p);
 #pragma unroll
     for (int pp = 0; pp < PP; ++pp) {
         const int pj = (wave * PP + pp) * 32 + (lane & 31);
@@ -194,20 +252,24 @@ __global__ __launch_bounds__(64 * NW) void conv2d_bf16x3_kernel(ConvK p, const u
         const long opix = (long)oy * p.Wout + ox;
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
+            if constexpr (MB == 1) {   // (register-capped kernels: the element-by-element form, written here -- through epi_block16 it spills)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = n0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                if (co < p.Cout) {
-                    float v = acc[m][pp][r];
-                    if (p.pre) v += p.pre[(long)(n / p.pre_div) * p.pre_sN + (long)co * p.pre_sC + opix];
-                    if (p.bias) v += p.bias[co];
-                    if (p.act == CCVS_ACT_LRELU) v = lrelu01(v);
-                    if (p.res) v += p.res[(long)n * p.res_sN + (long)co * p.res_sC + opix];
-                    v *= p.out_scale;
-                    float* dst = p.y + (long)n * p.out_sN + (long)co * p.out_sC + opix;
-                    if (p.accumulate) v += *dst;
-                    *dst = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int co = n0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    if (co < p.Cout) {
+                        float v = acc[m][pp][r];
+                        if (p.pre) v += p.pre[(long)(n / p.pre_div) * p.pre_sN + (long)co * p.pre_sC + opix];
+                        if (p.bias) v += p.bias[co];
+                        if (p.act == CCVS_ACT_LRELU) v = lrelu01(v);
+                        if (p.res) v += p.res[(long)n * p.res_sN + (long)co * p.res_sC + opix];
+                        v *= p.out_scale;
+                        float* dst = p.y + (long)n * p.out_sN + (long)co * p.out_sC + opix;
+                        if (p.accumulate) v += *dst;
+                        *dst = v;
+                    }
                 }
+            } else {
+                epi_block16(p, acc[m][pp], bias_s + m * 32 + 4 * khalf, n, n0 + m * 32 + 4 * khalf, opix, add_kind);
             }
         }
     }
@@ -267,6 +329,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
     constexpr int NTXM = (MB == 1) ? 9 : 3;              // most taps per row (1 x k head kernels run with MB = 1)
     constexpr int CB_WR = (NTXM * 4 * NT + NPW - 1) / NPW;  // uint4 of tap-row weights per weight-staging thread
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+    __shared__ float bias_s[32 * MB];   // the workgroup's bias values: read from LDS in the epilogue (see there: no vector-memory wait between its stores)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Wave priority of the WHOLE workgroup (bits 16-17 of `ablate`, set by the launcher from CCVS_CONV_PRIO): beside the token
@@ -299,6 +362,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
     const AxisTaps ay = axis_taps(p.kh, p.stride, p.pad, p.transposed, cls >> 1, p.Hout);
     const AxisTaps ax = axis_taps(p.kw, p.stride, p.pad, p.transposed, cls & 1, p.Wout);
     if (ty * TH >= ay.V || tx * TW >= ax.V) return;
+    if (tid < 32 * MB) bias_s[tid] = (p.bias && n0 + tid < p.Cout) ? p.bias[n0 + tid] : 0.f;   // visible after the first step barrier
 
     const int IH = (TH - 1) * ay.s + ay.ext + 1;
     const int IW = (TW - 1) * ax.s + ax.ext + 1;
@@ -878,6 +942,14 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
     // issue-bound.  32 couts x 256 pixels per pass, MB passes.
     if (!p.transposed) {
         float* stage = reinterpret_cast<float*>(smem4);
+        constexpr int NIT = (8 * NPIX + 255 + NP) / (256 + NP);   // 16-byte pieces of a 32-channel pass per thread
+        constexpr bool LEANK = MB == 1 || WPC == 2;   // kernels capped at 128 registers: the fast path below or the plain piece-by-piece one
+        // addends of the epilogue: 0 none, 1 pre-activation image, 2 residual, 3 accumulate, 4 more than one of them
+        const int add_kind = conv_add_kind(p);
+        const bool fast_epi = add_kind <= 3 && (tx + 1) * TW <= ax.V && (ty + 1) * TH <= ay.V && n0 + NT <= p.Cout && (p.Wout & 3) == 0 &&
+                              (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 && (p.out_sN & 3) == 0 && (p.out_sC & 3) == 0 &&
+                              (add_kind != 1 || ((reinterpret_cast<uintptr_t>(p.pre) & 15) == 0 && (p.pre_sN & 3) == 0 && (p.pre_sC & 3) == 0)) &&
+                              (add_kind != 2 || ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0 && (p.res_sN & 3) == 0 && (p.res_sC & 3) == 0));
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             if (!producer) {
@@ -887,7 +959,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
                     for (int r = 0; r < 16; ++r)
                         stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * NPIX + (rw * PP + pp) * 32 + (lane & 31)] = acc[m][pp][r];
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: the previous pass's stores stay in flight
             if (PP == 2 && p.out_p8) {   // (packed output: 256-pixel tiles only; the launcher never pairs it with PP = 4)
                 // packed output: a thread takes one pixel x 8 output channels of the staged 32 x 256 block, applies the
                 // epilogue, splits to hi / lo and writes two 16-byte units (lanes = consecutive pixels: coalesced)
@@ -922,23 +994,147 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
                 if (m + 1 < MB) __syncthreads();
                 continue;
             }
-#pragma unroll
-            for (int i = 0; i < (8 * NPIX + 255 + NP) / (256 + NP); ++i) {
+            // No wait on vector memory inside the store loop: `s_waitcnt vmcnt` counts stores too, so a wait for a load issued
+            // after a store -- the bias value, the residual of the next piece -- also waits until that store has been
+            // acknowledged by memory (~0.6 us).  With the loads of every piece interleaved with its store the tile's 131 KB left
+            // the CU one round trip at a time: 9.9 us per 128-channel tile (CCVS_CONV_ABLATE runs), a quarter of the time a
+            // 49->128 tile takes.  The bias values are fetched once in front of the first pass; a layer without addends
+            // (most of them) issues no load at all here, the others fetch the addends of ALL pieces of a pass first.
+            auto piece = [&](int i, int& co, long& opix, int& nv, int& col, int& px) -> bool {
                 const int idx4 = tid + (256 + NP) * i;
-                if (idx4 >= 8 * NPIX) break;
-                const int col = idx4 / (NPIX / 4), px = (idx4 % (NPIX / 4)) * 4;
-                const int co = n0 + m * 32 + col;
+                col = idx4 / (NPIX / 4);
+                px = (idx4 % (NPIX / 4)) * 4;
+                co = n0 + m * 32 + col;
                 const int prow = px / TW, pcol = px - prow * TW;
                 const int vy = ty * TH + prow, vx = tx * TW + pcol;
-                if (co < p.Cout && vy < ay.V && vx < ax.V) {
+                opix = (long)vy * p.Wout + vx;
+                nv = min(4, ax.V - vx);
+                return idx4 < 8 * NPIX && co < p.Cout && vy < ay.V && vx < ax.V;
+            };
+            if (fast_epi) {
+                // The whole tile inside the image, every output channel real, every row 16-byte aligned (the layers that matter):
+                // straight-line code -- hipcc can then COUNT its waits (vmcnt(n) for the addend of piece i leaves the stores of
+                // the pieces before it in flight; behind a per-piece branch it falls back to vmcnt(0))
+                const float* abase = add_kind == 1 ? p.pre + (long)(n / p.pre_div) * p.pre_sN : add_kind == 2 ? p.res + (long)n * p.res_sN : p.y + (long)n * p.out_sN;
+                const long a_sC = add_kind == 1 ? p.pre_sC : add_kind == 2 ? p.res_sC : p.out_sC;
+                float* ybase = p.y + (long)n * p.out_sN;
+                // (offsets are recomputed where they are used: kept in arrays across the two phases they cost the 32-channel kernels,
+                //  capped at 128 registers, a spill)
+#define CB_EPI_OFFS(i)                                                                               \
+        const int idx4_ = tid + (256 + NP) * (i);                                                    \
+        const int col_ = idx4_ / (NPIX / 4), px_ = (idx4_ % (NPIX / 4)) * 4;                         \
+        const int prow_ = px_ / TW, pcol_ = px_ - prow_ * TW;                                        \
+        const long opix_ = (long)(ty * TH + prow_) * p.Wout + tx * TW + pcol_;                       \
+        const int co_ = n0 + m * 32 + col_;
+#define CB_EPI_FINISH(ADD1, ADD2, ADD3)                                                              \
+    _Pragma("unroll") for (int i = 0; i < NIT; ++i) {                                                \
+        CB_EPI_OFFS(i)                                                                               \
+        const float4 a4 = *reinterpret_cast<const float4*>(stage + col_ * NPIX + px_);              \
+        float v[4] = {a4.x, a4.y, a4.z, a4.w};                                                       \
+        const float bv = bias_s[m * 32 + col_];                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
+            float t = (v[j] + (ADD1)) + bv;                                                          \
+            if (p.act == CCVS_ACT_LRELU) t = lrelu01(t);                                             \
+            t = (t + (ADD2)) * p.out_scale;                                                          \
+            v[j] = t + (ADD3);                                                                       \
+        }                                                                                            \
+        *reinterpret_cast<float4*>(ybase + (long)co_ * p.out_sC + opix_) = make_float4(v[0], v[1], v[2], v[3]); \
+    }
+                if (add_kind == 0) {
+                    CB_EPI_FINISH(0.f, 0.f, 0.f)
+                } else {
+                    f32x4 ad[NIT];
+#pragma unroll
+                    for (int i = 0; i < NIT; ++i) {
+                        CB_EPI_OFFS(i)
+                        ad[i] = *reinterpret_cast<const f32x4*>(abase + (long)co_ * a_sC + opix_);
+                    }
+                    if (add_kind == 1) { CB_EPI_FINISH(ad[i][j], 0.f, 0.f) }
+                    else if (add_kind == 2) { CB_EPI_FINISH(0.f, ad[i][j], 0.f) }
+                    else { CB_EPI_FINISH(0.f, 0.f, ad[i][j]) }
+                }
+#undef CB_EPI_OFFS
+#undef CB_EPI_FINISH
+            } else if (!LEANK && add_kind == 0) {
+                // no addend (most layers): a code path of its own WITHOUT any vector-memory load, so that hipcc has no reason to
+                // put a wait between the stores (a conditional load makes it wait with vmcnt(0) at the first use of the value)
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) {
+                    int co, nv, col, px;
+                    long opix;
+                    if (!piece(i, co, opix, nv, col, px)) continue;
                     const float4 a4 = *reinterpret_cast<const float4*>(stage + col * NPIX + px);
                     float v[4] = {a4.x, a4.y, a4.z, a4.w};
-                    const float bv = p.bias ? p.bias[co] : 0.f;
-                    const long opix = (long)vy * p.Wout + vx;
+                    const float bv = bias_s[m * 32 + col];
+                    float* dst = p.y + (long)n * p.out_sN + (long)co * p.out_sC + opix;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = (v[j] + 0.f) + bv;
+                        if (p.act == CCVS_ACT_LRELU) t = lrelu01(t);
+                        v[j] = (t + 0.f) * p.out_scale + 0.f;
+                    }
+                    if (nv == 4 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j) if (j < nv) dst[j] = v[j];
+                    }
+                }
+            } else if (!LEANK && add_kind <= 3) {
+                // exactly one addend: its pieces are fetched first, then every piece is finished and stored
+                float ad[NIT][4];
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ad[i][j] = 0.f;
+                    int co, nv, col, px;
+                    long opix;
+                    if (!piece(i, co, opix, nv, col, px)) continue;
+                    const float* src = add_kind == 1 ? p.pre + (long)(n / p.pre_div) * p.pre_sN + (long)co * p.pre_sC + opix
+                                     : add_kind == 2 ? p.res + (long)n * p.res_sN + (long)co * p.res_sC + opix
+                                                     : p.y + (long)n * p.out_sN + (long)co * p.out_sC + opix;
+                    if (nv == 4 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+                        const float4 t = *reinterpret_cast<const float4*>(src);
+                        ad[i][0] = t.x; ad[i][1] = t.y; ad[i][2] = t.z; ad[i][3] = t.w;
+                    } else {
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j) if (j < nv) ad[i][j] = src[j];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) {
+                    int co, nv, col, px;
+                    long opix;
+                    if (!piece(i, co, opix, nv, col, px)) continue;
+                    const float4 a4 = *reinterpret_cast<const float4*>(stage + col * NPIX + px);
+                    float v[4] = {a4.x, a4.y, a4.z, a4.w};
+                    const float bv = bias_s[m * 32 + col];
+                    float* dst = p.y + (long)n * p.out_sN + (long)co * p.out_sC + opix;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = (v[j] + (add_kind == 1 ? ad[i][j] : 0.f)) + bv;
+                        if (p.act == CCVS_ACT_LRELU) t = lrelu01(t);
+                        t = (t + (add_kind == 2 ? ad[i][j] : 0.f)) * p.out_scale;
+                        v[j] = t + (add_kind == 3 ? ad[i][j] : 0.f);
+                    }
+                    if (nv == 4 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j) if (j < nv) dst[j] = v[j];
+                    }
+                }
+            } else {
+                // piece by piece (several addends at once -- no layer of the models does this -- and the ragged tiles of the
+                // register-capped kernels): the form of rounds 1-3
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) {
+                    int co, nv, col, px;
+                    long opix;
+                    if (!piece(i, co, opix, nv, col, px)) continue;
+                    const float4 a4 = *reinterpret_cast<const float4*>(stage + col * NPIX + px);
+                    float v[4] = {a4.x, a4.y, a4.z, a4.w};
+                    const float bv = bias_s[m * 32 + col];
                     float* dst = p.y + (long)n * p.out_sN + (long)co * p.out_sC + opix;
                     const float* rsrc = p.res ? p.res + (long)n * p.res_sN + (long)co * p.res_sC + opix : nullptr;
                     const float* psrc = p.pre ? p.pre + (long)(n / p.pre_div) * p.pre_sN + (long)co * p.pre_sC + opix : nullptr;
-                    const int nv = min(4, ax.V - vx);
                     const bool vec = (nv == 4) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) &&
                                      (!rsrc || (reinterpret_cast<uintptr_t>(rsrc) & 15) == 0) &&
                                      (!psrc || (reinterpret_cast<uintptr_t>(psrc) & 15) == 0);
@@ -948,10 +1144,13 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
                         if (rsrc) { const float4 t = *reinterpret_cast<const float4*>(rsrc); rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
                         if (p.accumulate) { const float4 t = *reinterpret_cast<const float4*>(dst); ov[0] = t.x; ov[1] = t.y; ov[2] = t.z; ov[3] = t.w; }
                     } else {
-                        for (int j = 0; j < nv; ++j) {
-                            if (psrc) pv[j] = psrc[j];
-                            if (rsrc) rv[j] = rsrc[j];
-                            if (p.accumulate) ov[j] = dst[j];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (j < nv) {
+                                if (psrc) pv[j] = psrc[j];
+                                if (rsrc) rv[j] = rsrc[j];
+                                if (p.accumulate) ov[j] = dst[j];
+                            }
                         }
                     }
 #pragma unroll
@@ -964,11 +1163,11 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
                     if (vec) {
                         *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
-                        for (int j = 0; j < nv; ++j) dst[j] = v[j];
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j) if (j < nv) dst[j] = v[j];
                     }
                 }
             }
-            if (m + 1 < MB) __syncthreads();
+            if (m + 1 < MB) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (LDS only: the stores stay in flight)
         }
     } else if (!producer) {
 #pragma unroll
@@ -981,6 +1180,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
         const long opix = (long)oy * p.Wout + ox;
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
+            // (this path is taken by experiments only -- transposed layers run the synchronous kernel: the form of rounds 1-3)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = n0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
@@ -1000,6 +1200,14 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
     }
     }
 }
+
+// dynamic LDS limit of a kernel; a refusal (static + dynamic LDS beyond the CU's 160 KB) must not pass silently: every
+// launch above the 64 KB default would then fail with "invalid argument"
+#define CB_SET_LDS(KERNEL, BYTES)                                                                                           \
+    do {                                                                                                                    \
+        const hipError_t e_ = hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);   \
+        if (e_ != hipSuccess) fprintf(stderr, "ccvs_conv2d_bf16x3: LDS limit of %s refused: %s\n", #KERNEL, hipGetErrorString(e_)); \
+    } while (0)
 
 // workgroups of kernel `fn` that fit one CU (HIP occupancy query, cached per kernel and LDS size)
 static int conv_occupancy(const void* fn, int threads, size_t smem_bytes) {
@@ -1026,13 +1234,13 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
     }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_kernel<TW, MB, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_kernel<TW, MB, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, -2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, -8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        CB_SET_LDS((conv2d_bf16x3_kernel<TW, MB, 4>), 159 * 1024);
+        CB_SET_LDS((conv2d_bf16x3_kernel<TW, MB, 8>), 159 * 1024);
+        CB_SET_LDS((conv2d_bf16x3_pc_kernel<TW, MB, 0>), 159 * 1024);   // (+ the static bias block)
+        CB_SET_LDS((conv2d_bf16x3_pc_kernel<TW, MB, -2>), 159 * 1024);   // (+ the static bias block)
+        CB_SET_LDS((conv2d_bf16x3_pc_kernel<TW, MB, -8>), 159 * 1024);   // (+ the static bias block)
+        CB_SET_LDS((conv2d_bf16x3_pc_kernel<TW, MB, 1>), 159 * 1024);   // (+ the static bias block)
+        CB_SET_LDS((conv2d_bf16x3_pc_kernel<TW, MB, 3>), 159 * 1024);   // (+ the static bias block)
         attr_set = true;
     }
     static const int ablate_env = getenv("CCVS_CONV_ABLATE") ? atoi(getenv("CCVS_CONV_ABLATE")) : 0;  // timing experiments only (1: no staging, 2: no MFMA, 4: scalar staging, 128: no weight DMA, 256: no activation staging)
@@ -1111,8 +1319,8 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
                 k.xcd_chunk = (xcd_aware && total4 % 8 == 0 && total4 >= 64) ? (int)(total4 / 8) : 0;
                 static bool attr4 = false;
                 if (!attr4) {
-                    (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    CB_SET_LDS((conv2d_bf16x3_pc_kernel<TW, MB, 1, 4>), 159 * 1024);   // (+ the static bias block)
+                    CB_SET_LDS((conv2d_bf16x3_pc_kernel<TW, MB, 3, 4>), 159 * 1024);   // (+ the static bias block)
                     attr4 = true;
                 }
                 k.ktail = kt ? ktail_r : 0;
@@ -1130,7 +1338,7 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
             if (wpc2 && k.kh == 3 && k.kw == 3 && smem_v <= 80 * 1024 && k.cu_limit <= 0) {   // two workgroups per CU (see the kernel)
                 static bool attr2 = false;
                 if (!attr2) {
-                    (void)hipFuncSetAttribute((const void*)conv2d_bf16x3_pc_kernel<TW, MB, 3, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    CB_SET_LDS((conv2d_bf16x3_pc_kernel<TW, MB, 3, 2, 2>), 159 * 1024);   // (+ the static bias block)
                     attr2 = true;
                 }
                 k.ktail = kt ? ktail_r : 0;
@@ -1173,7 +1381,7 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
         return CCVS_ERR_ARG;
     }
     const size_t smem = (size_t)(4 * plane + ntx_max * 4 * NT) * 16;
-    if (smem > 160 * 1024) {
+    if (smem > 159 * 1024) {
         ccvs_set_error("ccvs_conv2d_bf16x3: %zu bytes of LDS needed", smem);
         return CCVS_ERR_ARG;
     }
