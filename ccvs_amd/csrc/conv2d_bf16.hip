@@ -66,7 +66,7 @@ extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const flo
     // Few input channels per output byte (the 49- and 99-channel layers in front of 128 outputs): 64 output channels per
     // workgroup and two workgroups per CU, so that one tile's prologue / epilogue runs beside the other's K loop
     // (conv2d_bf16_kernels.h, WPC).  CCVS_CONV_WPC2 = largest Cin that takes this form (0: off).
-    static const int wpc2_cin = getenv("CCVS_CONV_WPC2") ? atoi(getenv("CCVS_CONV_WPC2")) : 0;
+    static const int wpc2_cin = getenv("CCVS_CONV_WPC2") ? atoi(getenv("CCVS_CONV_WPC2")) : 64;   // 49->128: +6...7 %; 99->128: none (tools/conv_one.py)
     int wpc2 = 0;
     if (wpc2_cin > 0 && mb >= 2 && TW == 32 && d->Cin <= wpc2_cin && d->kh == 3 && d->kw == 3 && d->stride == 1 && !d->transposed && !d->in_p8 && !d->out_p8) {
         mb = 2;

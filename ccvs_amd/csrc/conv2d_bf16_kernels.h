@@ -362,6 +362,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
     const AxisTaps ay = axis_taps(p.kh, p.stride, p.pad, p.transposed, cls >> 1, p.Hout);
     const AxisTaps ax = axis_taps(p.kw, p.stride, p.pad, p.transposed, cls & 1, p.Wout);
     if (ty * TH >= ay.V || tx * TW >= ax.V) return;
+    if (ablate & 32768) return;   // timing experiments: the cost of dispatching the workgroups alone
     if (tid < 32 * MB) bias_s[tid] = (p.bias && n0 + tid < p.Cout) ? p.bias[n0 + tid] : 0.f;   // visible after the first step barrier
 
     const int IH = (TH - 1) * ay.s + ay.ext + 1;
@@ -633,6 +634,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
         }
     }
 
+    if (ablate & 4096) return;   // timing experiments: dispatch + address set-up + the first chunk / first weights, no step loop
     // Step -1 only lets the producers fetch the first register bundle (everyone meets at the barrier);
     // steps 0 .. nsteps-1 are the real ones.  (ci, a) = (chunk, tap row) of step s.
     // The two roles run SEPARATE loops that meet at the same barrier once per step: in one shared loop the register
@@ -966,6 +968,21 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
                 uint4* y4 = reinterpret_cast<uint4*>(p.y);
                 const int gout = (p.Cout + 7) >> 3;
                 const long hw_out = (long)p.Hout * p.Wout;
+                // (bias from LDS, the pre-activation addends of both items fetched first: no load between the stores -- see below)
+                float pv[2][8];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int item = tid + 512 * i;
+                    const int gq = item >> 8, px = item & 255;
+                    const int co0 = n0 + m * 32 + gq * 8;
+                    const int prow = px / TW, pcol = px - prow * TW;
+                    const int vy = ty * TH + prow, vx = tx * TW + pcol;
+                    const bool ok = co0 < p.Cout && vy < ay.V && vx < ax.V;
+                    const long opix = ok ? (long)vy * p.Wout + vx : 0;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        pv[i][c] = p.pre ? p.pre[(long)(n / p.pre_div) * p.pre_sN + (long)min(co0 + c, p.Cout - 1) * p.pre_sC + opix] : 0.f;
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int item = tid + 512 * i;
@@ -979,8 +996,8 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
                             float t = stage[(gq * 8 + c) * 256 + px];
-                            if (p.pre) t += p.pre[(long)(n / p.pre_div) * p.pre_sN + (long)(co0 + c) * p.pre_sC + opix];
-                            if (p.bias) t += p.bias[co0 + c];
+                            if (p.pre) t += pv[i][c];
+                            if (p.bias) t += bias_s[m * 32 + gq * 8 + c];
                             if (p.act == CCVS_ACT_LRELU) t = lrelu01(t);
                             v[c] = t * p.out_scale;
                         }
@@ -991,7 +1008,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
                         dst[hw_out] = lo;
                     }
                 }
-                if (m + 1 < MB) __syncthreads();
+                if (m + 1 < MB) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 continue;
             }
             // No wait on vector memory inside the store loop: `s_waitcnt vmcnt` counts stores too, so a wait for a load issued

@@ -1,6 +1,7 @@
 // Cost volume, bilinear back-warp and the confidence fusion / occlusion blend of the
 // decoder's InterBlock (reference skip_autoencoder.py:120-128,179-265).  HBM / LDS bound.
 #include "common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------
 // 7x7 displacement correlation (modules/correlation.py:11-100):
@@ -39,24 +40,46 @@ __global__ __launch_bounds__(256) void correlation7x7_kernel(const float* __rest
 #pragma unroll
     for (int d = 0; d < 49; ++d) acc[d] = 0.f;
 
-    for (int c0 = 0; c0 < C; c0 += CORR_CC) {
-        __syncthreads();
-        for (int e = tid; e < IH * IW; e += 256) {
+    // every global value of a channel chunk is requested in one burst, a whole chunk ahead of its use (see the two-pixel form)
+    constexpr int NE = (IH * IW + 255) / 256;
+    long eoff[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int e = tid + 256 * j;
+        eoff[j] = -2;
+        if (e < IH * IW) {
             const int r = e / IW, c = e - r * IW;
             const int gy = iy0 + r * S, gx = ix0 + c * S;
-            const bool ok = (gy >= 0 && gy < H && gx >= 0 && gx < W);
-            const long o = ok ? (long)gy * W + gx : 0;  // unconditional loads from a clamped address
-#pragma unroll
-            for (int cc = 0; cc < CORR_CC; ++cc) {
-                const float t = B[(long)min(c0 + cc, C - 1) * H * W + o];
-                bt[cc][e] = (ok && c0 + cc < C) ? t : 0.f;
-            }
+            eoff[j] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (long)gy * W + gx : -1;
         }
-        __syncthreads();
+    }
+    const long aoff = live ? (long)(oy * S) * W + ox * S : 0;
+    float breg[NE][CORR_CC], areg[CORR_CC];
+    auto fetch = [&](int c0) {
 #pragma unroll
         for (int cc = 0; cc < CORR_CC; ++cc) {
-            const float ta = A[(long)min(c0 + cc, C - 1) * H * W + (live ? (long)(oy * S) * W + ox * S : 0)];
-            const float a = (live && c0 + cc < C) ? ta : 0.f;
+            const long pl = (long)min(c0 + cc, C - 1) * H * W;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) breg[j][cc] = B[pl + (eoff[j] >= 0 ? eoff[j] : 0)];
+            areg[cc] = A[pl + aoff];
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < C; c0 += CORR_CC) {
+        __syncthreads();
+        float ac[CORR_CC];
+#pragma unroll
+        for (int cc = 0; cc < CORR_CC; ++cc) {
+            ac[cc] = (live && c0 + cc < C) ? areg[cc] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NE; ++j)
+                if (eoff[j] != -2) bt[cc][tid + 256 * j] = (eoff[j] >= 0 && c0 + cc < C) ? breg[j][cc] : 0.f;
+        }
+        __syncthreads();
+        if (c0 + CORR_CC < C) fetch(c0 + CORR_CC);
+#pragma unroll
+        for (int cc = 0; cc < CORR_CC; ++cc) {
+            const float a = ac[cc];
             const float* bp = &bt[cc][py * IW + px];
 #pragma unroll
             for (int dy = 0; dy < 7; ++dy)
@@ -105,26 +128,53 @@ __global__ __launch_bounds__(256) void correlation7x7x2_kernel(const float* __re
 #pragma unroll
     for (int d = 0; d < 49; ++d) { acc0[d] = 0.f; acc1[d] = 0.f; }
 
-    for (int c0 = 0; c0 < C; c0 += CORR_CC) {
-        __syncthreads();
-        for (int e = tid; e < IH * IW; e += 256) {
+    // The kernel holds 98 sums per lane: one workgroup per CU, ONE wave per SIMD -- nothing hides a load but the wave's own
+    // independent work.  Every global value of a channel chunk (this thread's share of the halo tile of `second`, and the two
+    // `first` values of each of its channels) is therefore requested in ONE burst, a whole chunk before it is used: the chunk
+    // c0 + CORR_CC is in flight while chunk c0 is multiplied.  (Rounds 1-3 fetched first[c] inside the channel loop, right in
+    // front of its use -- a full memory round trip per channel: 64 us per tile against 4 us of arithmetic.)
+    constexpr int NE = (IH * IW + 255) / 256;
+    long eoff[NE];      // offset of halo element e = tid + 256 j inside a channel plane; -1: outside the image, -2: no such element
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int e = tid + 256 * j;
+        eoff[j] = -2;
+        if (e < IH * IW) {
             const int r = e / IW, c = e - r * IW;
             const int gy = iy0 + r * S, gx = ix0 + c * S;
-            const bool ok = (gy >= 0 && gy < H && gx >= 0 && gx < W);
-            const long o = ok ? (long)gy * W + gx : 0;
-#pragma unroll
-            for (int cc = 0; cc < CORR_CC; ++cc) {
-                const float t = B[(long)min(c0 + cc, C - 1) * H * W + o];
-                bt[cc][e] = (ok && c0 + cc < C) ? t : 0.f;
-            }
+            eoff[j] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (long)gy * W + gx : -1;
         }
-        __syncthreads();
+    }
+    const long aoff = live ? (long)(oy * S) * W + ox * S : 0;
+    float breg[NE][CORR_CC], a0reg[CORR_CC], a1reg[CORR_CC];
+    auto fetch = [&](int c0) {
 #pragma unroll
         for (int cc = 0; cc < CORR_CC; ++cc) {
-            const float* ap = A + (long)min(c0 + cc, C - 1) * H * W + (live ? (long)(oy * S) * W + ox * S : 0);
-            const float ta0 = ap[0], ta1 = ap[live ? S : 0];
+            const long pl = (long)min(c0 + cc, C - 1) * H * W;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) breg[j][cc] = B[pl + (eoff[j] >= 0 ? eoff[j] : 0)];
+            a0reg[cc] = A[pl + aoff];
+            a1reg[cc] = A[pl + aoff + (live ? S : 0)];
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < C; c0 += CORR_CC) {
+        __syncthreads();
+        float a0c[CORR_CC], a1c[CORR_CC];
+#pragma unroll
+        for (int cc = 0; cc < CORR_CC; ++cc) {
             const bool on = live && c0 + cc < C;
-            const float a0 = on ? ta0 : 0.f, a1 = on ? ta1 : 0.f;
+            a0c[cc] = on ? a0reg[cc] : 0.f;
+            a1c[cc] = on ? a1reg[cc] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NE; ++j)
+                if (eoff[j] != -2) bt[cc][tid + 256 * j] = (eoff[j] >= 0 && c0 + cc < C) ? breg[j][cc] : 0.f;
+        }
+        __syncthreads();
+        if (c0 + CORR_CC < C) fetch(c0 + CORR_CC);
+#pragma unroll
+        for (int cc = 0; cc < CORR_CC; ++cc) {
+            const float a0 = a0c[cc], a1 = a1c[cc];
             const float* bp = &bt[cc][py * IW + px];
 #pragma unroll
             for (int dy = 0; dy < 7; ++dy) {
@@ -443,7 +493,44 @@ __global__ __launch_bounds__(256) void warp_proj4_kernel(CtxList ctx, long x_sC,
     for (int o = 0; o < CO; ++o)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[o][i] = 0.f;
-    for (int c = 0; c < Cin; ++c) {
+    // two channels per iteration: the 16 gather loads of both are in flight before the first is used (one channel at a time
+    // a thread had 8 loads of 8 bytes outstanding); the sums keep their order (channel c before c + 1)
+    int c = 0;
+    for (; c + 2 <= Cin; c += 2) {
+        const float* pl0 = x + (long)c * x_sC;
+        const float* pl1 = pl0 + x_sC;
+        F32Pair r00[4], r01[4], r10[4], r11[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r00[i] = *reinterpret_cast<const F32Pair*>(pl0 + q[i].o0);
+            r01[i] = *reinterpret_cast<const F32Pair*>(pl0 + q[i].o1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r10[i] = *reinterpret_cast<const F32Pair*>(pl1 + q[i].o0);
+            r11[i] = *reinterpret_cast<const F32Pair*>(pl1 + q[i].o1);
+        }
+        float v0[4], v1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v0[i] = ((r00[i].x * q[i].a0 + r00[i].y * q[i].b0) + r01[i].x * q[i].a1) + r01[i].y * q[i].b1;
+            v1[i] = ((r10[i].x * q[i].a0 + r10[i].y * q[i].b0) + r11[i].x * q[i].a1) + r11[i].y * q[i].b1;
+        }
+        const float* wr = wt + (long)c * CO;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            const float w0 = wr[o];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[o][i] += w0 * v0[i];
+        }
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            const float w1 = wr[CO + o];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[o][i] += w1 * v1[i];
+        }
+    }
+    for (; c < Cin; ++c) {
         const float* pl = x + (long)c * x_sC;
         float v[4];
 #pragma unroll
@@ -555,6 +642,7 @@ __global__ __launch_bounds__(256) void warp_fuse_blend_kernel(float* __restrict_
     GRID_WALK_END
 }
 
+template <int CCH, bool PREF>   // channels per thread; flows of the next context requested one context ahead
 __global__ __launch_bounds__(256) void warp_fuse_blend4_kernel(float* __restrict__ dec, long dec_sN, long dec_sC, CtxList ctx,
                                                                const float* __restrict__ flows, long flows_sN, const float* __restrict__ occs,
                                                                long occs_sN, float mult, int k, int C, int H, int W, GridWalk gw) {
@@ -562,20 +650,34 @@ __global__ __launch_bounds__(256) void warp_fuse_blend4_kernel(float* __restrict
     GRID_WALK_BEGIN(gw, bx, by, bz)
     const int pix = (bx * 256 + threadIdx.x) * 4;
     if (pix >= HW) continue;
-    const int n = bz, c0 = by * WARP4_CCH;
+    const int n = bz, c0 = by * CCH;
     const int py = pix / W, px = pix - py * W;
-    const int cn = min(WARP4_CCH, C - c0);
-    float acc[WARP4_CCH][4];
+    const int cn = min(CCH, C - c0);
+    float acc[CCH][4];
 #pragma unroll
-    for (int j = 0; j < WARP4_CCH; ++j)
+    for (int j = 0; j < CCH; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
     float sum_conf[4] = {0.f, 0.f, 0.f, 0.f}, sum_occ[4] = {0.f, 0.f, 0.f, 0.f};
+    // flows / occlusions of context kk + 1 are requested before context kk is sampled: fetched at the top of their own iteration
+    // they put a second memory round trip in front of every context's gathers (k = 15 of them per thread, one after the other)
+    F32Quad fx_n = *reinterpret_cast<const F32Quad*>(flows + (long)n * k * flows_sN + pix);
+    F32Quad fy_n = *reinterpret_cast<const F32Quad*>(flows + (long)n * k * flows_sN + HW + pix);
+    F32Quad oc_n = *reinterpret_cast<const F32Quad*>(occs + (long)n * k * occs_sN + pix);
     for (int kk = 0; kk < k; ++kk) {
-        const long nk = (long)n * k + kk;
-        const F32Quad fx = *reinterpret_cast<const F32Quad*>(flows + nk * flows_sN + pix);
-        const F32Quad fy = *reinterpret_cast<const F32Quad*>(flows + nk * flows_sN + HW + pix);
-        const F32Quad oc = *reinterpret_cast<const F32Quad*>(occs + nk * occs_sN + pix);
+        F32Quad fx = fx_n, fy = fy_n, oc = oc_n;
+        if (!PREF && kk > 0) {
+            const long nk = (long)n * k + kk;
+            fx = *reinterpret_cast<const F32Quad*>(flows + nk * flows_sN + pix);
+            fy = *reinterpret_cast<const F32Quad*>(flows + nk * flows_sN + HW + pix);
+            oc = *reinterpret_cast<const F32Quad*>(occs + nk * occs_sN + pix);
+        }
+        if (PREF && kk + 1 < k) {
+            const long nk1 = (long)n * k + kk + 1;
+            fx_n = *reinterpret_cast<const F32Quad*>(flows + nk1 * flows_sN + pix);
+            fy_n = *reinterpret_cast<const F32Quad*>(flows + nk1 * flows_sN + HW + pix);
+            oc_n = *reinterpret_cast<const F32Quad*>(occs + nk1 * occs_sN + pix);
+        }
         float conf[4];
         BilinPair q[4];
 #pragma unroll
@@ -587,7 +689,7 @@ __global__ __launch_bounds__(256) void warp_fuse_blend4_kernel(float* __restrict
         }
         const float* base = ctx.p[kk] + (long)n * ctx.sN[kk] + (long)c0 * HW;
 #pragma unroll
-        for (int j = 0; j < WARP4_CCH; ++j)
+        for (int j = 0; j < CCH; ++j)
             if (j < cn) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[j][i] += conf[i] * bilin_sample_pair(base + (long)j * HW, q[i]);
@@ -597,7 +699,7 @@ __global__ __launch_bounds__(256) void warp_fuse_blend4_kernel(float* __restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) m[i] = sigmoidf_((k > 1) ? sum_occ[i] / sum_conf[i] : sum_occ[i]);
 #pragma unroll
-    for (int j = 0; j < WARP4_CCH; ++j) {
+    for (int j = 0; j < CCH; ++j) {
         if (j < cn) {
             F32Quad* d = reinterpret_cast<F32Quad*>(dec + (long)n * dec_sN + (long)(c0 + j) * dec_sC + pix);
             F32Quad dv = *d;
@@ -615,9 +717,15 @@ __global__ __launch_bounds__(256) void warp_fuse_blend4_kernel(float* __restrict
 static void launch_warp_fuse_blend(float* dec, long dec_sN, long dec_sC, const CtxList& l, const float* flows, long flows_sN, const float* occs,
                                    long occs_sN, float mult, int N, int k, int C, int H, int W, void* stream) {
     if (W % 4 == 0) {
-        const GridWalk gw = grid_walk(cdiv(H * W / 4, 256), cdiv(C, WARP4_CCH), N);
-        hipLaunchKernelGGL(warp_fuse_blend4_kernel, dim3(limited_grid(gw.total, stream, 8)), dim3(256), 0, (hipStream_t)stream, dec, dec_sN, dec_sC, l,
-                           flows, flows_sN, occs, occs_sN, mult, k, C, H, W, gw);
+        static const int cch = getenv("CCVS_FUSE_CCH") ? atoi(getenv("CCVS_FUSE_CCH")) : 8;
+        static const int pref = getenv("CCVS_FUSE_PREF") ? atoi(getenv("CCVS_FUSE_PREF")) : 1;
+        const GridWalk gw = grid_walk(cdiv(H * W / 4, 256), cdiv(C, cch == 4 ? 4 : 8), N);
+#define WFB_LAUNCH(CCHv, PREFv)                                                                                                         \
+    hipLaunchKernelGGL((warp_fuse_blend4_kernel<CCHv, PREFv>), dim3(limited_grid(gw.total, stream, 8)), dim3(256), 0, (hipStream_t)stream, dec, \
+                       dec_sN, dec_sC, l, flows, flows_sN, occs, occs_sN, mult, k, C, H, W, gw)
+        if (cch == 4) { if (pref) WFB_LAUNCH(4, true); else WFB_LAUNCH(4, false); }
+        else { if (pref) WFB_LAUNCH(8, true); else WFB_LAUNCH(8, false); }
+#undef WFB_LAUNCH
     } else {
         const GridWalk gw = grid_walk(cdiv(H * W, 256), cdiv(C, WARP_CCH), N);
         hipLaunchKernelGGL(warp_fuse_blend_kernel, dim3(limited_grid(gw.total, stream, 8)), dim3(256), 0, (hipStream_t)stream, dec, dec_sN, dec_sC, l,

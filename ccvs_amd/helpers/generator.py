@@ -286,7 +286,8 @@ class Generator:
             return 1
         if getattr(opt, "beam_size", None) is not None:
             return 1
-        return max(1, min(int(lanes), 64 // max(batch, 1), 256 // max(batch, 1)))
+        max_rows = int(os.environ.get("CCVS_PIPELINE_MAX_ROWS", "64"))   # experiments: up to 256 (one decode step's limit)
+        return max(1, min(int(lanes), min(max_rows, 256) // max(batch, 1)))
 
     def _token_chain(self, k):
         """Token chain k: (Transformer, stream).  A chain runs one token group at a time; chains run beside each other.  Chain 0

@@ -29,7 +29,7 @@ def main():
     C = 1024
     SEQ = ops.GEMM_SEQ
     print("dense" if os.environ.get("CCVS_GEMM_SEQ_DENSE", "1") != "0" else "row-blocked", "sequence form")
-    for M in (1024, 3072, 4872, 20480):
+    for M in ([int(v) for v in sys.argv[1:]] or [1024, 3072, 4872, 20480]):
         total_ms, total_fl = 0.0, 0.0
         for name, n, k, ln, epi in [("qkv (ln)", 3 * C, C, True, ops.EPI_NONE), ("proj +res", C, C, False, ops.EPI_RESIDUAL),
                                     ("fc (ln, gelu)", 4 * C, C, True, ops.EPI_GELU), ("fc2 +res", C, 4 * C, False, ops.EPI_RESIDUAL)]:

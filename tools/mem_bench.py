@@ -48,6 +48,13 @@ def main():
     pb = torch.randn(n, 24, h, h, device="cuda")
     row("correlation s2 120x24x256^2", timeit(lambda: ops.correlation7x7(pa, pb, 2, first_div=15, lrelu=True)),
         pb.numel() * 4 + n * 49 * 128 * 128 * 4)
+    ctxs = [torch.randn(8, c, h, h, device="cuda") for _ in range(15)]
+    wproj = torch.randn(24, c, 1, 1, device="cuda")
+    w_t, cpad = ops.pack_proj_weight(wproj)
+    bproj = torch.randn(24, device="cuda")
+    row("warp + 1x1 proj 96->24, 120 pairs @256^2", timeit(lambda: ops.backwarp_proj(ctxs, flow, 32.0, w_t, cpad, bproj, 24, act=True)),
+        n * c * h * h * 4 + n * 24 * h * h * 4)
+    del ctxs
     t = torch.randn(n, 27, h, h + 8, device="cuda")
     fo = torch.randn(n, 3, h, h, device="cuda")
     import ctypes

@@ -27,7 +27,7 @@ json.dump(out, open("$ROOT/gpurun_out/conv_traffic_raw.json", "w"), indent=1)
 # with aligned dwordx4 loads / LDS-DMA and weights by LDS-DMA: x2; the scalar-staging ones (<.., 0|-2>, the synchronous
 # kernel) read dwords: x1.
 def wide(name):
-    m = re.search(r"pc_kernel<\\s*\\d+,\\s*\\d+,\\s*(-?\\d+)(?:,\\s*\\d+)?>", name)
+    m = re.search(r"pc_kernel<\\s*\\d+,\\s*\\d+,\\s*(-?\\d+)(?:,\\s*\\d+)*>", name)
     return bool(m) and int(m.group(1)) in (1, 3, -8)
 fetch = sum(v * (2.0 if wide(k) else 1.0) for k, v in out["FETCH_SIZE"]["per_kernel_KiB"].items()) * 1024
 write = out["WRITE_SIZE"]["total_KiB"] * 1024
