@@ -312,12 +312,13 @@ __global__ __launch_bounds__(64 * NW) void conv2d_bf16x3_kernel(ConvK p, const u
 template <int TW, int MB, int NTY, int PP = 2, int WPC = 1>
 __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
     static_assert(WPC == 1 || (WPC == 2 && MB == 2 && PP == 2 && NTY == 3), "two workgroups per CU: the 64-channel 3 x 3 form only");
-    static_assert(PP == 2 || (PP == 4 && NTY > 0 && MB == 2), "the 512-pixel tile exists for the VEC staging mode and 64 output channels");
+    static_assert(PP == 2 || (PP == 4 && (NTY > 0 || NTY == -83) && MB == 2), "the 512-pixel tile exists for the VEC / packed staging modes and 64 output channels");
     constexpr bool VEC = NTY > 0;
     // NTY == -8: the input is a packed split-bf16 activation (P8: [N][C/8][hi|lo][H][W] x 8 bf16, written by the epilogue of
     // the producing convolution): its halo tile is already in the LDS image's format, so the staging waves only issue
     // LDS-DMA (global_load_lds_dwordx4, zero source outside the image) -- no registers, no conversion.
-    constexpr bool P8IN = NTY == -8;
+    constexpr bool P8IN = NTY == -8 || NTY == -83;   // -83: packed input AND three tap rows known at compile time (3 x 3 layers)
+    constexpr bool TAP3 = NTY == 3 || NTY == -83;    // the tap loop of the MFMA waves written out
     constexpr bool DMAW = VEC || P8IN;   // weights by LDS-DMA from the MFMA waves
     constexpr int CB_XQ = (NTY == -2) ? 2 : 1;  // scalar staging: halo-tile pixel passes per thread and step (passes <= CB_XQ * nt)
     constexpr int NPIX = 128 * PP;        // pixels of the tile: 4 MFMA waves x PP blocks of 32
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
             if (rtw + NPW * i < wunits) *reinterpret_cast<u32x4*>(dst + rtw + NPW * i) = wraw[i];
     };
     // P8 input: slot s = rt + 256 j of the 4-plane LDS image [half][hi|lo][pixel] <- one uint4 of the packed tensor
-    constexpr int NJ = P8IN ? 8 : 1;
+    constexpr int NJ = P8IN ? (PP == 4 ? 10 : 8) : 1;   // 16-byte slots of the 4-plane halo image per staging thread
     int p8off[NJ], p8q[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
             }                                                                                                          \
         }                                                                                                              \
     }
-                if constexpr (NTY == 3) {   // (written out: see the 256-pixel form below)
+                if constexpr (TAP3) {   // (written out: see the 256-pixel form below)
                     CB_TAP4(0, 0, true)
                     CB_TAP4(1, 1, true)
                     CB_TAP4(0, 2, false)
@@ -859,7 +860,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
     }
             CB_LD_B(0, 0)
             CB_LD_A(0, 0, 0)
-            if constexpr (NTY == 3) {
+            if constexpr (TAP3) {
                 // 3 x 3 kernels (three taps per row, known at compile time): the tap loop is written out, so that no
                 // run-time branch sits between the fragment reads and the MFMAs.  In the loop form hipcc's wait-count pass
                 // puts `s_waitcnt lgkmcnt(0)` directly behind every prefetch (`ds_read x2; s_waitcnt lgkmcnt(0); v_mfma x6`:
@@ -954,26 +955,44 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
                               (add_kind != 2 || ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0 && (p.res_sN & 3) == 0 && (p.res_sC & 3) == 0));
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
+            const bool p8_out = (PP == 2 || P8IN) && p.out_p8;
             if (!producer) {
+                if (p8_out) {
+                    // packed output: the pass is staged [pixel][32 channels] (36 floats apart: conflict-free 16-byte accesses) -- a
+                    // lane writes its four groups of 4 consecutive channels as ds_write_b128, a reader fetches the 8 channels of its
+                    // pixel as two ds_read_b128 (channel-major staging cost the packed epilogue 8 ds_read_b32 per item: the
+                    // 128-channel producers ran 20 % slower than with fp32 output)
 #pragma unroll
-                for (int pp = 0; pp < PP; ++pp)
+                    for (int pp = 0; pp < PP; ++pp) {
+                        float* sp = stage + ((rw * PP + pp) * 32 + (lane & 31)) * 36 + 4 * khalf;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * NPIX + (rw * PP + pp) * 32 + (lane & 31)] = acc[m][pp][r];
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 q4 = {acc[m][pp][4 * g], acc[m][pp][4 * g + 1], acc[m][pp][4 * g + 2], acc[m][pp][4 * g + 3]};
+                            *reinterpret_cast<f32x4*>(sp + 8 * g) = q4;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int pp = 0; pp < PP; ++pp)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * NPIX + (rw * PP + pp) * 32 + (lane & 31)] = acc[m][pp][r];
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: the previous pass's stores stay in flight
-            if (PP == 2 && p.out_p8) {   // (packed output: 256-pixel tiles only; the launcher never pairs it with PP = 4)
+            if (p8_out) {   // (the 512-pixel tile writes packed output only in its packed-input form)
                 // packed output: a thread takes one pixel x 8 output channels of the staged 32 x 256 block, applies the
                 // epilogue, splits to hi / lo and writes two 16-byte units (lanes = consecutive pixels: coalesced)
                 uint4* y4 = reinterpret_cast<uint4*>(p.y);
                 const int gout = (p.Cout + 7) >> 3;
                 const long hw_out = (long)p.Hout * p.Wout;
-                // (bias from LDS, the pre-activation addends of both items fetched first: no load between the stores -- see below)
-                float pv[2][8];
+                // (bias from LDS, the pre-activation addends of all items fetched first: no load between the stores -- see below)
+                constexpr int NI8 = 4 * NPIX / 512;   // (pixel, 8 channels) items of a 32-channel pass per thread
+                float pv[NI8][8];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < NI8; ++i) {
                     const int item = tid + 512 * i;
-                    const int gq = item >> 8, px = item & 255;
+                    const int gq = item / NPIX, px = item - gq * NPIX;
                     const int co0 = n0 + m * 32 + gq * 8;
                     const int prow = px / TW, pcol = px - prow * TW;
                     const int vy = ty * TH + prow, vx = tx * TW + pcol;
@@ -984,18 +1003,20 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
                         pv[i][c] = p.pre ? p.pre[(long)(n / p.pre_div) * p.pre_sN + (long)min(co0 + c, p.Cout - 1) * p.pre_sC + opix] : 0.f;
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < NI8; ++i) {
                     const int item = tid + 512 * i;
-                    const int gq = item >> 8, px = item & 255;
+                    const int gq = item / NPIX, px = item - gq * NPIX;
                     const int co0 = n0 + m * 32 + gq * 8;
                     const int prow = px / TW, pcol = px - prow * TW;
                     const int vy = ty * TH + prow, vx = tx * TW + pcol;
                     if (co0 < p.Cout && vy < ay.V && vx < ax.V) {
                         const long opix = (long)vy * p.Wout + vx;
                         float v[8];
+                        const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + px * 36 + gq * 8);
+                        const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + px * 36 + gq * 8 + 4);
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
-                            float t = stage[(gq * 8 + c) * 256 + px];
+                            float t = c < 4 ? s0[c] : s1[c - 4];
                             if (p.pre) t += pv[i][c];
                             if (p.bias) t += bias_s[m * 32 + gq * 8 + c];
                             if (p.act == CCVS_ACT_LRELU) t = lrelu01(t);
@@ -1011,6 +1032,9 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
                 if (m + 1 < MB) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 continue;
             }
+            if constexpr (P8IN && PP == 4) {   // this instantiation writes packed output only (the launcher sees to it): its fp32
+                continue;                        // epilogue, compiled in as well, keeps hipcc from unrolling the pass loop
+            } else {
             // No wait on vector memory inside the store loop: `s_waitcnt vmcnt` counts stores too, so a wait for a load issued
             // after a store -- the bias value, the residual of the next piece -- also waits until that store has been
             // acknowledged by memory (~0.6 us).  With the loads of every piece interleaved with its store the tile's 131 KB left
@@ -1185,6 +1209,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
                 }
             }
             if (m + 1 < MB) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (LDS only: the stores stay in flight)
+            }
         }
     } else if (!producer) {
 #pragma unroll
@@ -1226,6 +1251,11 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
         if (e_ != hipSuccess) fprintf(stderr, "ccvs_conv2d_bf16x3: LDS limit of %s refused: %s\n", #KERNEL, hipGetErrorString(e_)); \
     } while (0)
 
+static int xcd_aware_p8() {
+    static const int v = getenv("CCVS_CONV_XCD") ? atoi(getenv("CCVS_CONV_XCD")) : 1;
+    return v;
+}
+
 // workgroups of kernel `fn` that fit one CU (HIP occupancy query, cached per kernel and LDS size)
 static int conv_occupancy(const void* fn, int threads, size_t smem_bytes) {
     struct Entry { const void* fn; size_t smem; int occ; };
@@ -1245,6 +1275,8 @@ template <int TW, int MB>
 static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* wktail, int CinG, int halo_h, int halo_w, int ntx_max, int gz, hipStream_t st, int wpc2) {
     constexpr int NT = 32 * MB;
     int plane = halo_h * halo_w;
+    // the packed-output epilogue stages a pass [pixel][36 floats]: the allocation must cover it (256- / 512-pixel tiles)
+    const size_t p8s2 = k_in.out_p8 ? (size_t)256 * 36 * 4 : 0, p8s4 = k_in.out_p8 ? (size_t)512 * 36 * 4 : 0;
     if (plane > 256 * CB_MAX_E) {
         ccvs_set_error("ccvs_conv2d_bf16x3: halo tile %dx%d too large", halo_h, halo_w);
         return CCVS_ERR_ARG;
@@ -1305,7 +1337,42 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
             ccvs_set_error("ccvs_conv2d_bf16x3: packed input with a %dx%d halo tile / %d taps per row is not supported", halo_h, halo_w, ntx_max);
             return CCVS_ERR_ARG;
         }
-        CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, -8>), 512, smem_p, (const uint4*)wsplit, CinG, ntx_max, ablate);
+        if constexpr (MB != 4) {   // (128 output channels per workgroup: the written-out form spills; no layer of the models needs it)
+            static bool attr_p = false;
+            if (!attr_p) {
+                CB_SET_LDS((conv2d_bf16x3_pc_kernel<TW, MB, -83>), 159 * 1024);
+                attr_p = true;
+            }
+        }
+        if constexpr (TW == 32 && MB == 2) {   // 64 output channels: the 512-pixel tile (see below), packed input
+            static const int pp4p = getenv("CCVS_CONV_PP4") ? atoi(getenv("CCVS_CONV_PP4")) : 1;
+            const int th4 = 16, halo_h4 = (th4 - 1) + k.kh, plane4 = halo_h4 * halo_w;
+            const size_t smem_4 = (size_t)(2 * 4 * plane4 + 2 * ntx_max * 4 * NT) * 16;
+            if (pp4p && k.out_p8 && k.kh == 3 && k.kw == 3 && k.cu_limit <= 0 && k.Hout >= 2 * th4 && 4 * plane4 <= 10 * 256 && smem_4 <= 156 * 1024 &&
+                smem_4 >= (size_t)32 * 512 * 4) {
+                k.tiles_y = cdiv(k.Hout, th4);
+                const dim3 grid4(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
+                const long total4 = (long)grid4.x * grid4.y * grid4.z;
+                k.nwork = 0; k.work0 = 0; k.gx = (int)grid4.x; k.gy = (int)grid4.y;
+                k.xcd_chunk = (xcd_aware_p8() && total4 % 8 == 0 && total4 >= 64) ? (int)(total4 / 8) : 0;
+                static bool attr4p = false;
+                if (!attr4p) {
+                    CB_SET_LDS((conv2d_bf16x3_pc_kernel<TW, MB, -83, 4>), 159 * 1024);
+                    attr4p = true;
+                }
+                hipLaunchKernelGGL((conv2d_bf16x3_pc_kernel<TW, MB, -83, 4>), grid4, dim3(512), (smem_4 > p8s4 ? smem_4 : p8s4), st, k, (const uint4*)wsplit, CinG, ntx_max, ablate);
+                CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
+                return CCVS_OK;
+            }
+        }
+        bool done3 = false;
+        if constexpr (MB != 4) {
+            if (k.kh == 3 && k.kw == 3) {
+                CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, -83>), 512, (smem_p > p8s2 ? smem_p : p8s2), (const uint4*)wsplit, CinG, ntx_max, ablate);
+                done3 = true;
+            }
+        }
+        if (!done3) CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, -8>), 512, (smem_p > p8s2 ? smem_p : p8s2), (const uint4*)wsplit, CinG, ntx_max, ablate);
         CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
         return CCVS_OK;
     }
@@ -1359,7 +1426,7 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
                     attr2 = true;
                 }
                 k.ktail = kt ? ktail_r : 0;
-                CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, 3, 2, 2>), 512, smem_v, (const uint4*)(kt ? wktail : wsplit), CinG, ntx_max, ablate);
+                CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, 3, 2, 2>), 512, (smem_v > p8s2 ? smem_v : p8s2), (const uint4*)(kt ? wktail : wsplit), CinG, ntx_max, ablate);
                 k.ktail = 0;
                 CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
                 return CCVS_OK;
@@ -1368,9 +1435,9 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
         if (smem_v <= 156 * 1024) {
             if (k.kh == 3) {
                 k.ktail = kt ? ktail_r : 0;
-                CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, 3>), 512, smem_v, (const uint4*)(kt ? wktail : wsplit), CinG, ntx_max, ablate);
+                CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, 3>), 512, (smem_v > p8s2 ? smem_v : p8s2), (const uint4*)(kt ? wktail : wsplit), CinG, ntx_max, ablate);
                 k.ktail = 0;
-            } else CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, 1>), 512, smem_v, (const uint4*)wsplit, CinG, ntx_max, ablate);
+            } else CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, 1>), 512, (smem_v > p8s2 ? smem_v : p8s2), (const uint4*)wsplit, CinG, ntx_max, ablate);
             CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
             return CCVS_OK;
         }
@@ -1384,12 +1451,12 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
     const bool regs_ok2 = (ntx_max <= (MB == 1 ? 9 : 3)) && (passes <= 2 * nt_min) && !(ablate & 32) && (!k.transposed || (ablate & 1024));
     // (8 staging waves for <= 64 output channels were measured slower: the steps are latency- not staging-bound)
     if (smem_pc <= 156 * 1024 && regs_ok) {  // double-buffered producer / consumer form, scalar staging
-        CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, 0>), 512, smem_pc, (const uint4*)wsplit, CinG, ntx_max, ablate);
+        CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, 0>), 512, (smem_pc > p8s2 ? smem_pc : p8s2), (const uint4*)wsplit, CinG, ntx_max, ablate);
         CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
         return CCVS_OK;
     }
     if (smem_pc <= 156 * 1024 && regs_ok2) {
-        CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, -2>), 512, smem_pc, (const uint4*)wsplit, CinG, ntx_max, ablate);
+        CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, -2>), 512, (smem_pc > p8s2 ? smem_pc : p8s2), (const uint4*)wsplit, CinG, ntx_max, ablate);
         CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
         return CCVS_OK;
     }

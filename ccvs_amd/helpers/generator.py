@@ -385,6 +385,8 @@ class Generator:
             return (chain, rows, groups, opt.vid_len, opt.z_len, opt.cond_len, bool(opt.p2p), bool(opt.sample), opt.top_k, float(opt.temperature),
                     chain_list[chain][0].sample_noise, ver)
 
+        abort = threading.Event()   # set on the error path: queued token stages are dropped instead of run
+
         def worker(chain):
             tr, s_tok = chain_list[chain]
             torch.cuda.set_device(dev)
@@ -392,6 +394,10 @@ class Generator:
                 job = queues[chain].get()
                 if job is None:
                     return
+                if abort.is_set():
+                    job["error"] = RuntimeError("run_pipelined: aborted")
+                    job["done"].set()
+                    continue
                 try:
                     with torch.cuda.stream(s_tok), torch.no_grad():
                         s_tok.wait_event(job["enc_done"])
@@ -472,7 +478,17 @@ class Generator:
             held.append(first)
             nb = first["vid"].shape[0]
             sizes = sorted({self._token_group_size(nb, g) for g in range(1, lanes + 1)})
-            cold = [(c, g) for c in range(chains) for g in sizes if capture_key(c, nb * g, g) not in self._warm_keys]
+            def is_cold(c, g):
+                # the captured steps live in the engine's cache of that row count: ask the engine, not only the side set (a serial
+                # generate_vid with the same rows but another group count or a longer sequence, the eviction at 8 entries or
+                # drop_engine_state() rebuild the cache and drop its graphs -- the capture would then happen in a worker thread)
+                cache = chain_list[c][0].net_t._caches.get(nb * g)
+                live = cache is not None and cache.get("G") == g and len(cache.get("graphs", {})) > 0
+                key = capture_key(c, nb * g, g)
+                if not live:
+                    self._warm_keys.discard(key)
+                return key not in self._warm_keys
+            cold = [(c, g) for c in range(chains) for g in sizes if is_cold(c, g)]
             if not cold:
                 return
             with torch.cuda.stream(s_dec):
@@ -537,15 +553,19 @@ class Generator:
                     print(f"[pipeline] batches {[m['i'] for m in cur['members']]} (chain {cur['chain']}): host ms -- wait for the token stage to be "
                           f"enqueued {1e3 * (t_join - t_round):.0f}, encode(next group) + decode enqueue {1e3 * (time.perf_counter() - t_join):.0f}",
                           file=sys.stderr, flush=True)
+        except BaseException:
+            abort.set()   # the workers drop what is still queued; the error surfaces now, not after every queued token loop has run
+            raise
         finally:
             for q_ in queues:
                 q_.put(None)
             for th in threads:
-                th.join(timeout)
+                th.join(30.0 if abort.is_set() else timeout)
             budget(0)
-        entry.wait_stream(s_dec)
-        for _, st in chain_list:
-            entry.wait_stream(st)
+            # (also on the error path: the caller's stream must not run ahead of work still queued on ours)
+            entry.wait_stream(s_dec)
+            for _, st in chain_list:
+                entry.wait_stream(st)
         self._pipeline_events = timings
         return results
 

@@ -641,6 +641,30 @@ def test_conv_packed_activation_chain(ops):
         assert torch.equal(a[-1], b[-1])
 
 
+def test_conv_packed_chain_of_the_interblocks(ops):
+    """The conv -> conv chain of Matching / Subpixel with packed (P8) intermediates at the tile forms the decoder uses: 49 -> 128
+    (128 channels per workgroup, packed output; and its two-workgroups-per-CU form), 128 -> 64 (the 512-pixel tile with packed input
+    AND output, tap loop written out), 64 -> 32 (32-channel kernel, packed in / out), 1 x 9 head (packed input, fp32 output) -- equal to
+    the fp32-intermediate chain bit for bit, with the shared pre-activation image in the first layer, ragged heights included."""
+    if ops.CONV_PRECISION != "bf16x3":
+        pytest.skip("packed activations are a split-bf16 format")
+    torch.manual_seed(6)
+    for n, h, w, div in ((4, 40, 64, 2), (2, 33, 96, 1), (3, 16, 32, 3)):
+        x = torch.randn(n, 49, h, w).cuda()
+        pre = torch.randn(n // div, 128, h, w).cuda()
+        specs = [(49, 128, 3, 3), (128, 64, 3, 3), (64, 32, 3, 3), (32, 27, 1, 9)]
+        ws = [torch.randn(co, ci, kh, kw).cuda() for ci, co, kh, kw in specs]
+        bs = [torch.randn(co).cuda() for _, co, _, _ in specs]
+        packs = [ops.pack_conv_weight(wt) for wt in ws]
+
+        def run2(packed):
+            t = ops.conv2d(x, packs[0], bs[0], 128, 3, pad=1, act=True, pre=pre, pre_div=div, out_p8=packed)
+            t = ops.conv2d(t, packs[1], bs[1], 64, 3, pad=1, act=True, out_p8=packed)
+            t = ops.conv2d(t, packs[2], bs[2], 32, 3, pad=1, act=True, out_p8=packed)
+            return ops.conv2d(t, packs[3], bs[3], 27, 1, pad=4)
+        assert torch.equal(run2(False), run2(True)), (n, h, w)
+
+
 def test_gemm_row_blocked_matches_plain(ops):
     """Up to 256 rows the weight-stream kernel runs (one workgroup per 16 rows x 16 columns): every 16-row slice equals the
     plain M = 16 launch bit for bit, with and without the folded LayerNorm, GELU / residual epilogues and ragged M, N.  Beyond

@@ -32,7 +32,7 @@ orig_conv2d = ops.conv2d
 
 
 def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, **kw):
-    xs = tuple(x.data.shape) if isinstance(x, ops.P8Act) else tuple(x.shape)
+    xs = tuple(x.shape)   # (P8Act.shape is the logical [n, c, h, w])
     census._key = (xs, cout, k, stride, bool(transposed), getattr(w_packed, "kw", k))
     return orig_conv2d(x, w_packed, bias, cout, k, stride, pad, transposed, **kw)
 
