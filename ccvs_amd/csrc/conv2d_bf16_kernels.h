@@ -986,49 +986,54 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
                 uint4* y4 = reinterpret_cast<uint4*>(p.y);
                 const int gout = (p.Cout + 7) >> 3;
                 const long hw_out = (long)p.Hout * p.Wout;
-                // (bias from LDS, the pre-activation addends of all items fetched first: no load between the stores -- see below)
+                // (bias from LDS; with a pre-activation image its values for all items are fetched first, WITHOUT one the code path holds
+                //  no vector-memory load at all: a load that is merely conditional still makes hipcc wait, vmcnt(0), where its value
+                //  would be used -- i.e. for the stores of the item before; see the fp32 epilogue below)
                 constexpr int NI8 = 4 * NPIX / 512;   // (pixel, 8 channels) items of a 32-channel pass per thread
-                float pv[NI8][8];
+#define CB_P8_ITEM(i)                                                                          \
+        const int item_ = tid + 512 * (i);                                                     \
+        const int gq_ = item_ / NPIX, px_ = item_ - gq_ * NPIX;                                \
+        const int co0_ = n0 + m * 32 + gq_ * 8;                                                \
+        const int prow_ = px_ / TW, pcol_ = px_ - prow_ * TW;                                  \
+        const int vy_ = ty * TH + prow_, vx_ = tx * TW + pcol_;                                \
+        const bool ok_ = co0_ < p.Cout && vy_ < ay.V && vx_ < ax.V;                            \
+        const long opix_ = ok_ ? (long)vy_ * p.Wout + vx_ : 0;
+#define CB_P8_FINISH(PRE)                                                                      \
+    _Pragma("unroll") for (int i = 0; i < NI8; ++i) {                                          \
+        CB_P8_ITEM(i)                                                                          \
+        if (ok_) {                                                                             \
+            float v[8];                                                                        \
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + px_ * 36 + gq_ * 8);      \
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + px_ * 36 + gq_ * 8 + 4);  \
+            _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                    \
+                float t = c < 4 ? s0[c] : s1[c - 4];                                           \
+                t += (PRE);                                                                    \
+                t += bias_s[m * 32 + gq_ * 8 + c];                                             \
+                if (p.act == CCVS_ACT_LRELU) t = lrelu01(t);                                   \
+                v[c] = t * p.out_scale;                                                        \
+            }                                                                                  \
+            uint4 hi, lo;                                                                      \
+            split8(v, hi, lo);                                                                 \
+            uint4* dst = y4 + ((long)n * gout + (co0_ >> 3)) * 2 * hw_out + opix_;             \
+            dst[0] = hi;                                                                       \
+            dst[hw_out] = lo;                                                                  \
+        }                                                                                      \
+    }
+                if (p.pre) {
+                    float pv[NI8][8];
+                    const float* pb = p.pre + (long)(n / p.pre_div) * p.pre_sN;
 #pragma unroll
-                for (int i = 0; i < NI8; ++i) {
-                    const int item = tid + 512 * i;
-                    const int gq = item / NPIX, px = item - gq * NPIX;
-                    const int co0 = n0 + m * 32 + gq * 8;
-                    const int prow = px / TW, pcol = px - prow * TW;
-                    const int vy = ty * TH + prow, vx = tx * TW + pcol;
-                    const bool ok = co0 < p.Cout && vy < ay.V && vx < ax.V;
-                    const long opix = ok ? (long)vy * p.Wout + vx : 0;
+                    for (int i = 0; i < NI8; ++i) {
+                        CB_P8_ITEM(i)
 #pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        pv[i][c] = p.pre ? p.pre[(long)(n / p.pre_div) * p.pre_sN + (long)min(co0 + c, p.Cout - 1) * p.pre_sC + opix] : 0.f;
-                }
-#pragma unroll
-                for (int i = 0; i < NI8; ++i) {
-                    const int item = tid + 512 * i;
-                    const int gq = item / NPIX, px = item - gq * NPIX;
-                    const int co0 = n0 + m * 32 + gq * 8;
-                    const int prow = px / TW, pcol = px - prow * TW;
-                    const int vy = ty * TH + prow, vx = tx * TW + pcol;
-                    if (co0 < p.Cout && vy < ay.V && vx < ax.V) {
-                        const long opix = (long)vy * p.Wout + vx;
-                        float v[8];
-                        const f32x4 s0 = *reinterpret_cast<const f32x4*>(stage + px * 36 + gq * 8);
-                        const f32x4 s1 = *reinterpret_cast<const f32x4*>(stage + px * 36 + gq * 8 + 4);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            float t = c < 4 ? s0[c] : s1[c - 4];
-                            if (p.pre) t += pv[i][c];
-                            if (p.bias) t += bias_s[m * 32 + gq * 8 + c];
-                            if (p.act == CCVS_ACT_LRELU) t = lrelu01(t);
-                            v[c] = t * p.out_scale;
-                        }
-                        uint4 hi, lo;
-                        split8(v, hi, lo);
-                        uint4* dst = y4 + ((long)n * gout + (co0 >> 3)) * 2 * hw_out + opix;
-                        dst[0] = hi;
-                        dst[hw_out] = lo;
+                        for (int c = 0; c < 8; ++c) pv[i][c] = pb[(long)min(co0_ + c, p.Cout - 1) * p.pre_sC + opix_];
                     }
+                    CB_P8_FINISH(pv[i][c])
+                } else {
+                    CB_P8_FINISH(0.f)
                 }
+#undef CB_P8_ITEM
+#undef CB_P8_FINISH
                 if (m + 1 < MB) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 continue;
             }

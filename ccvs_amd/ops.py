@@ -46,10 +46,12 @@ class KernelTimer:
 
 
 KERNEL_TIMER = None  # set to a KernelTimer() to time conv launches
-# Packed split-bf16 intermediates in the conv -> conv chains of the InterBlocks (P8Act).  Bit-identical, but OFF by default:
-# measured on a BAIR batch the consumers gain 41 ms (LDS-DMA staging, no conversion) while the 128-channel producers lose
-# 62 ms in their now serial split-and-store epilogue (tools/prof_p8_cmp.sh).
-CONV_P8 = __import__("os").environ.get("CCVS_CONV_P8", "0") == "1"
+# Packed split-bf16 intermediates in the conv -> conv chains of the InterBlocks (P8Act): 49|99 -> 128 -> 64 -> 32 -> heads.  Bit-identical
+# to fp32 intermediates.  ON since round 4 (CCVS_CONV_P8=0: fp32): the consumers stage by LDS-DMA with no conversion (128->64 at
+# 256^2 298 -> 382 TFLOP/s on the 512-pixel tile, 64->32 205 -> 250), the producers' packed epilogue no longer waits on vector memory
+# between its stores (it cost them 20 % in round 3: that, not the format, made P8 a net loss then); a BAIR batch's convolutions 617 ->
+# 570 ms alone, the default bench line 190.7 -> 200.4 frames/s on one box (profiles/r04_conv_p8_ab.txt).
+CONV_P8 = __import__("os").environ.get("CCVS_CONV_P8", "1") == "1"
 
 
 def _stream():
