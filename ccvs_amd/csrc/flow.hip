@@ -389,6 +389,111 @@ static void launch_backwarp(const CtxList& l, long x_sC, const float* flow, long
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Back-warp straight into the packed split-bf16 (P8) input of the first Subpixel convolution: [warped context | flow | occ]
+// (skip_autoencoder.py:222-224) as [N][C/8 + 1][hi|lo][H][W] units of 8 bf16 -- the form the convolution kernel stages by
+// LDS-DMA, no conversion.  A lane owns ONE pixel and 8 channels: its two 16-byte units are the store width the four-pixel form
+// was built for, and consecutive lanes write consecutive units.  Group C/8 holds (flow x, flow y, occlusion, 0 x 5) as stored
+// (the warp itself uses flow * mult).  Same samples as backwarp4_kernel (bilin_setup_pair / bilin_sample_pair), split like the
+// convolution's staging waves split them (round to nearest even twice): the convolution sees the same operands.
+// ---------------------------------------------------------------------------------------
+typedef __bf16 wp_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned wp_pk_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wp_bf16x2));
+}
+__device__ __forceinline__ void wp_split8(const float (&v)[8], uint4& hi, uint4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = wp_pk_bf16(v[2 * i], v[2 * i + 1]);
+        l[i] = wp_pk_bf16(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+__global__ __launch_bounds__(256) void backwarp_p8_kernel(CtxList ctx, long x_sC, const float* __restrict__ fo, long fo_sN, float mult,
+                                                          uint4* __restrict__ y, int C, int H, int W, GridWalk gw) {
+    // lane = 4 consecutive pixels x 8 channels, sampled exactly like backwarp4_kernel (same values bit for bit); the 32 results
+    // leave as 4 x (hi, lo) 16-byte units, one pixel each.  (One pixel per lane -- consecutive lanes writing consecutive units --
+    // was built first and lost 40-70 % on the LOAD side: 4.1-5.0 ms against 2.9 on 120 x 96 x 256^2.)
+    __shared__ uint4 wp_stage[2048];
+    const int HW = H * W;
+    const int G = C >> 3;
+    GRID_WALK_BEGIN(gw, bx, by, bz)
+    const int pix_raw = (bx * 256 + threadIdx.x) * 4;
+    const bool live = pix_raw < HW;       // (every thread reaches the barriers below)
+    const int pix = live ? pix_raw : 0;
+    const int n = bz, g = by;
+    const float* f = fo + (long)n * fo_sN + pix;
+    const F32Quad fx = *reinterpret_cast<const F32Quad*>(f);
+    const F32Quad fy = *reinterpret_cast<const F32Quad*>(f + HW);
+    float v[8][4];
+    if (g == G) {
+        const F32Quad oc = *reinterpret_cast<const F32Quad*>(f + 2 * (long)HW);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[0][i] = fx.v[i]; v[1][i] = fy.v[i]; v[2][i] = oc.v[i];
+#pragma unroll
+            for (int c = 3; c < 8; ++c) v[c][i] = 0.f;
+        }
+    } else {
+        const int jn = n % ctx.k;
+        const float* x = ctx.p[jn] + (long)(n / ctx.k) * ctx.sN[jn] + (long)(8 * g) * x_sC;
+        const int py = pix / W, px = pix - py * W;
+        BilinPair q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = bilin_setup_pair(px + i, py, fx.v[i] * mult, fy.v[i] * mult, H, W);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float* pl = x + (long)c * x_sC;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[c][i] = bilin_sample_pair(pl, q[i]);
+        }
+    }
+    // The workgroup's 1024 pixels x (hi, lo) units go through LDS so that consecutive lanes store consecutive units (a lane's own
+    // four units are 64 bytes apart from its neighbour's: written directly, every store instruction touched 32 lines for a quarter
+    // of each -- 4.3 ms against 2.9 for the fp32 form).
+    __syncthreads();   // (the previous block's reads of the staging area)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float vi[8] = {v[0][i], v[1][i], v[2][i], v[3][i], v[4][i], v[5][i], v[6][i], v[7][i]};
+        uint4 hi, lo;
+        wp_split8(vi, hi, lo);
+        wp_stage[i * 256 + threadIdx.x] = hi;          // pixel 4 t + i of the block
+        wp_stage[1024 + i * 256 + threadIdx.x] = lo;
+    }
+    __syncthreads();
+    const int pix0 = bx * 1024;
+    uint4* dst = y + (((long)n * (G + 1) + g) * 2) * HW + pix0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int u = threadIdx.x + 256 * j;            // pixel of the block: staged at (u % 4) * 256 + u / 4
+        if (pix0 + u < HW) {
+            dst[u] = wp_stage[(u & 3) * 256 + (u >> 2)];
+            dst[HW + u] = wp_stage[1024 + (u & 3) * 256 + (u >> 2)];
+        }
+    }
+    GRID_WALK_END
+}
+
+static int fill_ctx(CtxList& l, const ccvs_ctx_list* c, const char* name);
+
+extern "C" int ccvs_backwarp_p8_ctx(const ccvs_ctx_list* ctx, int64_t x_sC, const float* flow_occ, int64_t fo_sN, float flow_mult, void* y_p8,
+                                    int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    CCVS_REQUIRE(flow_occ && y_p8, "ccvs_backwarp_p8_ctx: null pointer");
+    CtxList l = {};
+    const int rc = fill_ctx(l, ctx, "ccvs_backwarp_p8_ctx");
+    if (rc != CCVS_OK) return rc;
+    CCVS_REQUIRE(N > 0 && N % l.k == 0 && C > 0 && C % 8 == 0 && H > 0 && W >= 4 && W % 4 == 0, "ccvs_backwarp_p8_ctx: bad shape (C %% 8 == 0, W %% 4 == 0)");
+    const GridWalk gw = grid_walk(cdiv(H * W / 4, 256), C / 8 + 1, N);
+    hipLaunchKernelGGL(backwarp_p8_kernel, dim3(limited_grid(gw.total, stream, 8)), dim3(256), 0, (hipStream_t)stream, l, (long)x_sC, flow_occ,
+                       (long)fo_sN, flow_mult, (uint4*)y_p8, C, H, W, gw);
+    CCVS_CHECK_LAUNCH("ccvs_backwarp_p8_ctx");
+    return CCVS_OK;
+}
+
 static int fill_ctx(CtxList& l, const ccvs_ctx_list* c, const char* name) {
     if (!c || c->k < 1 || c->k > CCVS_MAX_CTX) { ccvs_set_error("%s: context list of 1..%d entries expected", name, CCVS_MAX_CTX); return CCVS_ERR_ARG; }
     l.k = c->k;

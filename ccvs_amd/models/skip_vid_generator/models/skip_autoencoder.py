@@ -262,8 +262,16 @@ class InterBlock(nn.Module):
         # Subpixel input [dec | warped ctx | flow | occ] (skip_autoencoder.py:224): the `dec` block is the same
         # for the k contexts of a frame, so its share of the first Subpixel conv is computed ONCE per frame
         # (`pre`) and broadcast inside the conv epilogue; only [warped | flow | occ] is materialised per pair.
-        sp_in = torch.empty(n * k, s + 3, h, w, dtype=torch.float32, device=dec.device)
-        fo = sp_in[:, s:]
+        p8 = ops.CONV_PRECISION == "bf16x3" and ops.CONV_P8   # conv -> conv intermediates stay in the kernel's packed split-bf16 form
+        # ... and the back-warp writes the Subpixel input in that form too (`ops.backwarp_p8`: [warped | flow | occ | 0 x 5], s + 8
+        # channels): the 99-channel convolution, the largest of the level, then stages by LDS-DMA like the layers behind it
+        p8_warp = p8 and ops.P8_WARP and s % 8 == 0 and w % 4 == 0
+        if p8_warp:
+            sp_in = None
+            fo = torch.empty(n * k, 3, h, w, dtype=torch.float32, device=dec.device)
+        else:
+            sp_in = torch.empty(n * k, s + 3, h, w, dtype=torch.float32, device=dec.device)
+            fo = sp_in[:, s:]
         inter_w = None
         if fo_prev is not None:
             ops.dwconvT4x4s2(fo_prev, self._upsample_fo_weight(), out=fo)       # learned x2 of flow and occ
@@ -285,16 +293,20 @@ class InterBlock(nn.Module):
         corr = ops.correlation7x7(pa, pb, self.corr_stride, first_div=k, lrelu=True)
         if m.upsample_corr is not None:
             corr = ops.dwconvT4x4s2(corr, m.upsample_corr.weight.detach())
-        p8 = ops.CONV_PRECISION == "bf16x3" and ops.CONV_P8   # conv -> conv intermediates stay in the kernel's packed split-bf16 form
         feat = m.convs[2](m.convs[1](m.convs[0](corr, out_p8=p8), out_p8=p8), out_p8=p8)
         self._m_heads(feat, fo, accumulate=fo_prev is not None)
         del corr, feat, pa, pb, inter_w
         sp = self.subpixel
-        w_dec, w_rest = self._sub0_split()
+        w_dec, w_rest, w_rest8 = self._sub0_split()
         conv0 = sp.convs[0].conv
         pre = ops.conv2d(dec, w_dec, None, conv0.out_channel, 3, pad=1)          # [N,128,H,W], before dec is blended
-        ops.backwarp(ctxs, fo[:, :2], self.flow_mult, out=sp_in[:, :s])
-        feat = ops.conv2d(sp_in, w_rest, conv0.bias, conv0.out_channel, 3, pad=1, act=True, pre=pre, pre_div=k, out_p8=p8)
+        if p8_warp:
+            sp_p8 = ops.backwarp_p8(ctxs, fo, self.flow_mult)
+            feat = ops.conv2d(sp_p8, w_rest8, conv0.bias, conv0.out_channel, 3, pad=1, act=True, pre=pre, pre_div=k, out_p8=p8)
+            del sp_p8
+        else:
+            ops.backwarp(ctxs, fo[:, :2], self.flow_mult, out=sp_in[:, :s])
+            feat = ops.conv2d(sp_in, w_rest, conv0.bias, conv0.out_channel, 3, pad=1, act=True, pre=pre, pre_div=k, out_p8=p8)
         feat = sp.convs[2](sp.convs[1](feat, out_p8=p8), out_p8=p8)
         self._s_heads(feat, fo, accumulate=True)
         del feat, pre
@@ -317,8 +329,11 @@ class InterBlock(nn.Module):
         key = (w.data_ptr(), w._version, w.device, ops.CONV_PRECISION)
         if getattr(self, "_sub0", None) is None or self._sub0[0] != key:
             s = self.feat_size
-            self._sub0 = (key, ops.pack_conv_weight(w[:, :s], scale=conv.scale), ops.pack_conv_weight(w[:, s:], scale=conv.scale))
-        return self._sub0[1], self._sub0[2]
+            # (third form: the same block with five zero channels behind [warped | flow | occ]: s + 8 channels, the packed back-warp's)
+            w8 = torch.cat([w[:, s:].detach(), w.new_zeros(w.shape[0], 5, w.shape[2], w.shape[3])], dim=1)
+            self._sub0 = (key, ops.pack_conv_weight(w[:, :s], scale=conv.scale), ops.pack_conv_weight(w[:, s:], scale=conv.scale),
+                          ops.pack_conv_weight(w8, scale=conv.scale))
+        return self._sub0[1], self._sub0[2], self._sub0[3]
 
     def forward(self, input, inters, flows=None, occs=None, toffs=None, eps=1e-6):
         """Reference signature (skip_autoencoder.py:246): returns (fused input, flows, occs, toffs)."""

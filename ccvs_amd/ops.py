@@ -52,6 +52,11 @@ KERNEL_TIMER = None  # set to a KernelTimer() to time conv launches
 # between its stores (it cost them 20 % in round 3: that, not the format, made P8 a net loss then); a BAIR batch's convolutions 617 ->
 # 570 ms alone, the default bench line 190.7 -> 200.4 frames/s on one box (profiles/r04_conv_p8_ab.txt).
 CONV_P8 = __import__("os").environ.get("CCVS_CONV_P8", "1") == "1"
+# ... and the back-warp in front of the first Subpixel convolution can write that convolution's packed input (`backwarp_p8`).  OFF:
+# the convolution gains (99->128 at 256^2 268 -> 306 TFLOP/s, 13 ms per decode) what the packed back-warp loses (3.85 against 2.9 ms
+# per 120 x 96 x 256^2 call in its best form of three -- one pixel per lane, four pixels per lane, four pixels + LDS transposition);
+# the default line 197.0 against 197.1 frames/s (profiles/r04_p8_warp_ab.txt)
+P8_WARP = __import__("os").environ.get("CCVS_P8_WARP", "0") == "1"
 
 
 def _stream():
@@ -359,6 +364,23 @@ def pack_proj_weight(weight):
     out = torch.zeros(cin, pads[0], dtype=torch.float32, device=weight.device)
     out[:, :cout] = w
     return out.contiguous(), pads[0]
+
+
+def backwarp_p8(ctxs, flow_occ, flow_mult):
+    """[backwarp(ctx, flow * flow_mult) | flow | occ | 0 x 5] for the list of k context tensors [N/k,C,H,W] (see `backwarp`) as a P8Act of
+    C + 8 channels (`ccvs_backwarp_p8_ctx`): the packed input of the first Subpixel convolution.  flow_occ: [N,3,H,W]."""
+    _need_gpu(flow_occ)
+    if not _planes_dense(flow_occ):
+        flow_occ = flow_occ.contiguous()
+    cl, keep = _ctx_list(ctxs)
+    nf, c, h, w = keep[0].shape
+    n = nf * cl.k
+    assert flow_occ.shape == (n, 3, h, w) and c % 8 == 0 and w % 4 == 0
+    out = torch.empty(n * (c + 8) * h * w, dtype=torch.float32, device=flow_occ.device)
+    L = _lib.load()
+    _lib.check(L.ccvs_backwarp_p8_ctx(C.byref(cl), h * w, _p(flow_occ), flow_occ.stride(0), flow_mult, _p(out), n, c, h, w, _stream()),
+               "ccvs_backwarp_p8_ctx")
+    return P8Act(out, n, c + 8, h, w)
 
 
 def backwarp_proj(ctxs, flow, flow_mult, w_t, cout_pad, bias, cout, act=True):

@@ -151,6 +151,14 @@ int ccvs_warp_fuse_blend_ctx(float* dec, int64_t dec_sN, int64_t dec_sC, const c
                              int64_t flows_sN, const float* occs, int64_t occs_sN, float flow_mult, int32_t N, int32_t C,
                              int32_t H, int32_t W, void* stream);
 
+/* backwarp of the k contexts straight into the packed (P8, see ccvs_conv_desc.in_p8) input of Subpixel's first convolution,
+ * cat([warped, flow, occ]) of skip_autoencoder.py:222-224 without its dec block: y_p8 = [N][C/8 + 1][2 = hi,lo][H][W] units of 8
+ * bf16; groups 0 .. C/8 - 1 = backwarp(ctx, flow * flow_mult) (the same samples as ccvs_backwarp_ctx), group C/8 = (flow x, flow y,
+ * occ, 0, 0, 0, 0, 0) as stored in flow_occ [N,3,H,W] (batch stride fo_sN).  C % 8 == 0, W % 4 == 0.  The convolution that reads it has
+ * Cin = C + 8 with zero weights for the five padding channels. */
+int ccvs_backwarp_p8_ctx(const ccvs_ctx_list* ctx, int64_t x_sC, const float* flow_occ, int64_t fo_sN, float flow_mult, void* y_p8,
+                         int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+
 /* Matching's proj(backwarp(inter, flow * flow_mult)) (skip_autoencoder.py:186-190, ConvLayer(C, max(16, C/4), 1)) in one pass:
  * y[n][o] = act(bias[o] + sum_c w_t[c][o] * backwarp(ctx)[n][c]) -- the warped C-channel tensor is never written.
  * ctx as in ccvs_backwarp_ctx; w_t [Cin][CoutPad] fp32, the 1x1 weight transposed with the EqualConv2d scale multiplied in

@@ -665,6 +665,39 @@ def test_conv_packed_chain_of_the_interblocks(ops):
         assert torch.equal(run2(False), run2(True)), (n, h, w)
 
 
+@pytest.mark.parametrize("n,k,c,h,w", [(2, 3, 24, 40, 64), (1, 2, 96, 33, 36), (2, 1, 16, 8, 8), (1, 2, 8, 5, 4)])
+def test_backwarp_p8_feeds_the_first_subpixel_convolution(ops, n, k, c, h, w):
+    """`ccvs_backwarp_p8_ctx`: the k contexts warped straight into the packed input [warped | flow | occ | 0 x 5] of Subpixel's first
+    convolution.  The packed tensor decodes to the fp32 back-warp (hi + lo: 2^-16 relative), and the convolution on it equals the
+    convolution on the fp32 tensor of the same s + 8 channels bit for bit -- far flows (zero padding) and ragged sizes included."""
+    if ops.CONV_PRECISION != "bf16x3":
+        pytest.skip("packed activations are a split-bf16 format")
+    g = torch.Generator().manual_seed(n * 100 + c)
+    ctxs = [torch.randn(n, c, h, w, generator=g).cuda() for _ in range(k)]
+    fo = torch.randn(n * k, 3, h, w, generator=g).cuda()
+    fo[:, :2] *= 3.0
+    fo[0, :2, :2, :3] = 500.0          # far outside: zero padding
+    mult = 2.0
+    packed = ops.backwarp_p8(ctxs, fo, mult)
+    assert packed.shape == (n * k, c + 8, h, w)
+    want = torch.cat([ops.backwarp(ctxs, fo[:, :2].contiguous(), mult), fo, fo.new_zeros(n * k, 5, h, w)], dim=1)
+    dec = packed.float()
+    assert (dec - want).abs().max().item() <= 2e-5 * want.abs().max().item() + 1e-7
+    assert torch.equal(dec[:, c + 3:], want[:, c + 3:])
+    wt = torch.randn(128, c + 8, 3, 3, generator=g).cuda()
+    wt[:, c + 3:] = 0
+    b = torch.randn(128, generator=g).cuda()
+    pre = torch.randn(n, 128, h, w, generator=g).cuda()
+    pk = ops.pack_conv_weight(wt)
+    a = ops.conv2d(want, pk, b, 128, 3, pad=1, act=True, pre=pre, pre_div=k)
+    bb = ops.conv2d(packed, pk, b, 128, 3, pad=1, act=True, pre=pre, pre_div=k)
+    assert torch.equal(a, bb)     # same samples as backwarp4_kernel, same split as the staging waves: the same operands
+    # ... and against torch on the unpadded 99-channel form of the layer
+    ref = torch.nn.functional.conv2d(want[:, :c + 3].cpu(), (wt[:, :c + 3] * (1 / math.sqrt((c + 8) * 9))).cpu(), bias=b.cpu(), padding=1)
+    ref = torch.nn.functional.leaky_relu(ref + pre.cpu().repeat_interleave(k, dim=0), 0.1)
+    assert (bb.cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 2e-4
+
+
 def test_gemm_row_blocked_matches_plain(ops):
     """Up to 256 rows the weight-stream kernel runs (one workgroup per 16 rows x 16 columns): every 16-row slice equals the
     plain M = 16 launch bit for bit, with and without the folded LayerNorm, GELU / residual epilogues and ragged M, N.  Beyond

@@ -33,6 +33,10 @@ def main():
     occ = torch.randn(n, 1, h, h, device="cuda")
     out = torch.empty_like(x)
     row("backwarp 120x96x256^2", timeit(lambda: ops.backwarp(x, flow, 32.0, out=out)), 2 * x.numel() * 4)
+    ctx15 = [x.view(8, 15, c, h, h)[:, j] for j in range(15)]
+    fo3 = torch.cat([flow, occ], dim=1).contiguous()
+    row("backwarp (ctx list, fp32 out) 120x96x256^2", timeit(lambda: ops.backwarp(ctx15, flow, 32.0, out=out)), 2 * x.numel() * 4)
+    row("backwarp_p8 (packed out, +flow|occ group)", timeit(lambda: ops.backwarp_p8(ctx15, fo3, 32.0)), (2 * x.numel() + 11 * n * h * h) * 4)
     dec = torch.randn(8, 128, h, h, device="cuda")
     row("warp_fuse_blend k=15 8x96x256^2", timeit(lambda: ops.warp_fuse_blend(dec[:, :96], x, flow, occ, 32.0, 15)), x.numel() * 4)
     xb = torch.randn(16, 128, 257, 257, device="cuda")
