@@ -481,7 +481,9 @@ def main():
                                         + f"; every generate call is one batch of {args.batch} clips; "
                                         "K batches timed from resident inputs to gathered clips, fill and drain included") if args.schedule == "pipelined"
                                        else "serial: one batch at a time",
-                           "parallelism": f"dp{world} (batch sharded, one RCCL all-gather of uint8 clips on a side stream)"},
+                           "parallelism": f"dp{world} (batch sharded, one RCCL all-gather of uint8 clips on a side stream)",
+                           "conv_intermediates": ("packed split-bf16 (hi + lo, 4 bytes per element like fp32; bit-identical results) between the convolutions of "
+                                                  "Matching / Subpixel" if (ops.CONV_P8 and kind == "bf16x3") else "fp32")},
                 "stage_ms_per_step": {k: v / args.steps for k, v in stage.items() if k != "timeline"},
                 "timeline_ms": stage.get("timeline"),
                 "stage_note": "per-batch stage durations from HIP events on the stage's own stream" +

@@ -28,6 +28,7 @@ done
 unset CCVS_BENCH_SUPERVISE
 SHAPE="195 128 3 256 240" timeout 900 bash $ROOT/tools/pmc_conv_counters.sh > $OUT/${TAG}_pmc_conv_counters.txt 2>&1
 SHAPE="128 64 3 256 240" timeout 900 bash $ROOT/tools/pmc_conv_counters.sh > $OUT/${TAG}_pmc_conv_counters_128to64.txt 2>&1
+SHAPE="128 64 3 256 240 p8" timeout 900 bash $ROOT/tools/pmc_conv_counters.sh > $OUT/${TAG}_pmc_conv_counters_128to64_packed.txt 2>&1
 timeout 600 bash $ROOT/tools/pmc_attention.sh > $OUT/${TAG}_pmc_attention.txt 2>&1
 timeout 600 bash $ROOT/tools/pmc_gemm_seq.sh 3072 20480 > $OUT/${TAG}_pmc_gemm_seq.txt 2>&1
 timeout 900 bash $ROOT/tools/pmc_decoder_kernels.sh > $OUT/${TAG}_pmc_decoder_kernels.txt 2>&1
