@@ -514,6 +514,13 @@ def main():
                 lat = [t["d1"] - t["e0"] for t in tl]
                 line["latency_ms_per_batch"] = {"mean": sum(lat) / len(lat), "max": max(lat),
                                                 "note": "encode start to decode end of one batch (HIP events); the serial schedule's is its step time"}
+                if args.schedule == "pipelined":   # stream D: encodes + the pieces of the decodes, against its span in the timed region
+                    busy = stage["encode"] + stage["decode"]
+                    span = max(t["d1"] for t in tl) - min(t["e0"] for t in tl)
+                    line["decoder_stream"] = {"busy_ms": busy, "span_ms": span, "idle_frac": max(0.0, 1.0 - busy / span),
+                                              "first_decode_starts_ms": min(t["d0"] for t in tl), "token_stages_end_ms": max(t["t1"] for t in tl),
+                                              "note": "HIP events on stream D around every encode and every piece (conditioning frames / one frame) of every "
+                                                      "decode; the decoder takes a batch's tokens frame by frame while its token loop runs"}
             line["hbm_peak_allocated_gb"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30   # every batch in flight + weights + graphs' pools (torch allocator)
             # the token loop as a whole, in situ: weights ONCE per step of a token group + the keys and values of every batch in it,
             # against the HBM peak
@@ -541,6 +548,13 @@ def main():
                 "note": "HIP events on each token stream around the whole loop of every token group of the timed region (prefill of the conditioning frame "
                         "included); bytes = weights counted ONCE per step + mean KV bytes of every batch in the group; `frac` is ONE loop's stream while "
                         "`concurrent_token_loops` loops and the decoder share the memory system (aggregate_frac = loops x frac)"}
+            # everything that runs in the timed region shares one memory system: the algorithmic bytes of the two big consumers
+            conv_bytes_step = timer.total_bytes("conv2d_" + kind) / (1 if alone else args.steps)   # the convolutions of one batch
+            line["pipeline_hbm"] = {"token_loop_GB_per_step": loop_bytes / args.steps / 1e9, "conv_GB_per_step": conv_bytes_step / 1e9,
+                                    "GBps_of_these_two": (loop_bytes / args.steps + conv_bytes_step) / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBPS,
+                                    "note": "algorithmic bytes per batch of the token loops (weights once per step of a group + keys and values) and of the "
+                                            "decoder's convolutions over the measured step time; the stencil kernels of the decoder (~0.43 TB per BAIR batch, "
+                                            "profiles/r04_pmc_decoder_kernels.txt) and the encoder come on top -- DESIGN.md 4.6"}
             line["roofline_decode_kernels"] = decode_kernel_rooflines(gen, xopt, args.batch)
             line["multi_gpu"] = {"rccl_ranks": (torch.distributed.get_world_size() if engine.distributed else 1), "backend": engine.backend if engine.distributed else None,
                                  "stage_ms_per_step_by_rank": rank_stages,

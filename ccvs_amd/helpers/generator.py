@@ -28,6 +28,38 @@ from ccvs_amd.models.skip_vid_generator.models.transformer_model import Transfor
 from ccvs_amd import ops
 
 
+class _FrameFeed:
+    """The tokens of one token group on their way to the decoder, frame by frame (`Generator.run_pipelined`).  The token
+    stream copies every finished frame out of the loop's own buffer (which the chain's next group overwrites) and records an
+    event behind the copy; the decoder's thread sees `flags[f]` once `events[f]` exists and waits for it on its stream."""
+
+    def __init__(self, rows, frames, frame_tokens, device):
+        import threading
+        self.size = frame_tokens
+        self.codes = torch.empty(rows, frames * frame_tokens, dtype=torch.int64, device=device)
+        self.events = [None] * frames
+        self.flags = [threading.Event() for _ in range(frames)]
+        self.sent = 0
+
+    def on_tokens(self, n, codes):
+        """Columns [0, n) of `codes` are final in the order of the current (token) stream: pass on the frames they complete."""
+        f = min(n // self.size, len(self.events))
+        if f > self.sent:
+            lo, hi = self.sent * self.size, f * self.size
+            self.codes[:, lo:hi].copy_(codes[:, lo:hi])
+            ev = torch.cuda.Event()
+            ev.record()
+            for i in range(self.sent, f):
+                self.events[i] = ev
+                self.flags[i].set()
+            self.sent = f
+
+    def release(self):
+        """End of the token stage (also a failed one): nobody waits for a frame that will not come."""
+        for flag in self.flags:
+            flag.set()
+
+
 class Generator:
     def __init__(self, opt):
         self.opt = opt["transformer"]
@@ -210,6 +242,20 @@ class Generator:
             fake_data.update(self.state_model({"state_code": state_code}, mode='vid_decoder'))
         return fake_data
 
+    def _decode_codes_stream(self, ws, code_of, final):
+        """`decode_codes` as a generator for a clip whose tokens arrive frame by frame (`QVidModel.decode_stream`): `code_of(lo,
+        hi)` -> tokens of frames lo .. hi - 1, `final()` -> (code, state_code) of the whole clip once the token stage is done."""
+        opt = self.opt
+        dec_in = {k: v for k, v in ws["cropped"].items() if k != "code"}
+        fake_data = yield from self.vid_model.decode_stream(dec_in, code_of)
+        code, state_code = final()
+        fake_data["code"], fake_data["state_code"] = code, state_code
+        if opt.p2p:
+            fake_data["vid"] = torch.cat([fake_data["vid"], ws["data"]["vid"][:, -1:]], dim=1)
+        if opt.state and state_code is not None:                            # generator.py:168-169
+            fake_data.update(self.state_model({"state_code": state_code}, mode='vid_decoder'))
+        return fake_data
+
     @torch.no_grad()
     def reconstruct(self, ws):
         """The teacher-forced "rec" decode of the clip's own codes (generator.py:172-189)."""
@@ -304,7 +350,7 @@ class Generator:
                 lane._modules["net_t"] = net
                 tr = lane
             dev = torch.device("cuda", torch.cuda.current_device())
-            prio = int(os.environ.get("CCVS_PIPELINE_PRIORITIES", "-1,0").split(",")[0])
+            prio = int(os.environ.get("CCVS_PIPELINE_PRIORITIES", "0,-1").split(",")[0])
             self._chains.append((tr, torch.cuda.Stream(device=dev, priority=prio)))
         return self._chains[k]
 
@@ -317,10 +363,16 @@ class Generator:
           * the token loops of `lanes` consecutive batches run as ONE loop over their stacked rows ("token group": one KV cache
             of lanes x B rows, one captured decode step, per-group sampler words -- `ccvs_gpt_decode.groups`): the weights are
             streamed once per token for all of them instead of once per batch;
-          * `chains` such loops run beside each other on high-priority streams, each fed by its own worker thread (beside the
+          * `chains` such loops run beside each other on their own streams, each fed by its own worker thread (beside the
             decoder a dependent launch waits longer for its memory: independent chains hide each other's latency);
-          * meanwhile stream D decodes the batches of the finished groups, in order, and encodes those of the groups to come
-            (chains + 1 groups ahead, so that a chain never waits for its encoder behind a decoder).
+          * meanwhile stream D encodes the batches of the groups to come (chains + 1 groups in front of the decoder, so that a
+            chain never waits for its encoder) and decodes -- FRAME BY FRAME, as the tokens arrive: the decoder needs the tokens
+            of frame t only for frame t (`QVidModel.decode_frames`), so a running token loop hands every finished frame to a
+            `_FrameFeed` (a copy out of its buffer + an event, `GPT.progress`) and the decode of a batch is a generator advanced
+            one frame at a time, the oldest batch whose next frame is there first.  In the steady state that is the old
+            order (the oldest batch has all its tokens); at the start the decoder follows the first token loops one frame
+            behind instead of idling through a whole token stage (`CCVS_PIPELINE_STREAM=0`: decode when the stage is done).
+            The host stays `CCVS_PIPELINE_DEPTH` pieces ahead of stream D, so that "there" is judged late.
         `ramp`: sizes of the first groups (e.g. (1, 2): the decoder gets its first batch after one short token stage instead
         of idling through a full one); then every group has `lanes` batches.
 
@@ -355,7 +407,7 @@ class Generator:
             ramp = tuple(int(v) for v in os.environ.get("CCVS_PIPELINE_RAMP", "").split(",") if v)
         chains = max(1, chains)
         if getattr(self, "_dec_stream", None) is None:
-            prio = [int(v) for v in os.environ.get("CCVS_PIPELINE_PRIORITIES", "-1,0").split(",")]   # (token streams, decode stream)
+            prio = [int(v) for v in os.environ.get("CCVS_PIPELINE_PRIORITIES", "0,-1").split(",")]   # (token streams, decode stream)
             self._dec_stream = torch.cuda.Stream(device=dev, priority=prio[1])
         s_dec = self._dec_stream
         chain_list = [self._token_chain(k) for k in range(chains)]
@@ -386,6 +438,8 @@ class Generator:
                     chain_list[chain][0].sample_noise, ver)
 
         abort = threading.Event()   # set on the error path: queued token stages are dropped instead of run
+        stream_frames = os.environ.get("CCVS_PIPELINE_STREAM", "1") != "0"   # 0: a batch is decoded when its whole token stage is done
+        frame_tokens = int(self.qvid_opt.z_shape[0]) * int(self.qvid_opt.z_shape[1])
 
         def worker(chain):
             tr, s_tok = chain_list[chain]
@@ -397,22 +451,30 @@ class Generator:
                 if abort.is_set():
                     job["error"] = RuntimeError("run_pipelined: aborted")
                     job["done"].set()
+                    job["feed"].release()
                     continue
+                feed = job["feed"]
                 try:
                     with torch.cuda.stream(s_tok), torch.no_grad():
                         s_tok.wait_event(job["enc_done"])
                         members = job["members"]
                         tok_in = stack_inputs([m["ws"]["cropped"] for m in members])
                         self._seed_sampler_group(job["batch"], [m["i"] for m in members], tr.net_t)
+                        # one window of tokens, frame tokens only: the loop reports every finished frame (mingpt `progress`)
+                        by_frame = stream_frames and int(job["total_len"]) <= opt.z_len and not (opt.state or opt.stft)
+                        tr.net_t.progress = feed.on_tokens if by_frame else None
                         job["t0"].record()
                         out = tr(tok_in, mode='inference', total_len=job["total_len"])
+                        feed.on_tokens(out["code"].shape[1], out["code"])   # whatever the loop has not handed over itself
                         job["t1"].record()
                         job["codes"] = out
                 except BaseException as exc:   # re-raised by the main thread when it collects the job
                     job["error"] = exc
                 finally:
+                    tr.net_t.progress = None
                     tr.net_t.noise_key, tr.net_t.row_offset = None, 0
                     job["done"].set()
+                    feed.release()
 
         def wait_job(job, what):
             if not job["done"].wait(timeout):
@@ -455,9 +517,14 @@ class Generator:
                 raise RuntimeError("run_pipelined: the batches of a token group must share total_len")
             chain = n_groups % chains
             n_groups += 1
+            with torch.cuda.stream(s_dec):
+                feed = _FrameFeed(len(members) * members[0]["batch"], opt.vid_len, frame_tokens, dev)
+                feed.codes.record_stream(chain_list[chain][1])
+                enc_done = torch.cuda.Event()
+                enc_done.record()
             job = {"members": members, "batch": members[0]["batch"], "total_len": members[0]["ws"]["total_len"], "chain": chain,
-                   "enc_done": members[-1]["ev"]["e1"], "t0": torch.cuda.Event(enable_timing=True), "t1": torch.cuda.Event(enable_timing=True),
-                   "codes": None, "error": None, "done": threading.Event()}
+                   "enc_done": enc_done, "t0": torch.cuda.Event(enable_timing=True), "t1": torch.cuda.Event(enable_timing=True),
+                   "codes": None, "error": None, "done": threading.Event(), "feed": feed, "left": len(members)}
             queues[chain].put(job)
             return job
 
@@ -512,47 +579,133 @@ class Generator:
         threads = [threading.Thread(target=worker, args=(k,), name=f"ccvs-token-chain-{k}", daemon=True) for k in range(chains)]
         for th in threads:
             th.start()
-        pending = deque()
-        try:
-            for _ in range(chains + 1):
+        jobs = deque()        # submitted token groups with undecoded batches, oldest first
+        tasks = []            # the decodes of their batches, oldest first
+        in_flight = deque()   # events behind the pieces of decoder work enqueued last
+        finished = {}         # batch index -> (task, clip) decoded ahead of an earlier batch: handed out in index order
+        depth = max(1, int(os.environ.get("CCVS_PIPELINE_DEPTH", "2")))
+        state = {"exhausted": False, "next_out": first_iter, "budget": 0}
+
+        def top_up():
+            """Keep every chain busy and one more group encoded behind them (at most chains + 2 groups in flight)."""
+            while (not state["exhausted"] and len(jobs) < chains + 2 and sum(1 for j in jobs if not j["done"].is_set()) < chains + 1):
                 job = submit_group()
-                if job is not None:
-                    pending.append(job)
-            while pending:
-                t_round = time.perf_counter()
-                cur = pending.popleft()
-                wait_job(cur, "the token stage")
-                t_join = time.perf_counter()
-                nxt = submit_group()
-                if nxt is not None:
-                    pending.append(nxt)
-                s_dec.wait_event(cur["t1"])
-                codes = cur["codes"]
+                if job is None:
+                    state["exhausted"] = True
+                    break
+                jobs.append(job)
+                tasks.extend({"job": job, "k": k, "m": m, "gen": None, "need": None} for k, m in enumerate(job["members"]))
+
+        def start(task):
+            """The decode of one batch as a generator over its frames (`QVidModel.decode_frames`): it reads the tokens of a frame
+            from the group's feed and the whole sequence, as the token stage returns it, when it is done."""
+            job, k = task["job"], task["k"]
+            nb, feed = job["batch"], job["feed"]
+
+            def code_of(lo, hi):
+                return feed.codes[k * nb:(k + 1) * nb, lo * frame_tokens:hi * frame_tokens]
+
+            def final():
+                wait_job(job, "the token stage")
+                codes = job["codes"]
                 state_all = codes.get("state_code")
                 if state_all is not None and 0 in state_all.size():
                     state_all = None
                 for t in (codes["code"], state_all):
                     if torch.is_tensor(t):
                         t.record_stream(s_dec)
-                nb = cur["batch"]
-                for k, m in enumerate(cur["members"]):
-                    budget(cu_limit if pending else 0)
-                    code = codes["code"][k * nb:(k + 1) * nb]
-                    state_code = state_all[k * nb:(k + 1) * nb] if state_all is not None else None
-                    with torch.cuda.stream(s_dec):
-                        m["ev"]["d0"].record()
-                        fake = self.decode_codes(m["ws"], code, state_code)
-                        m["ev"]["d1"].record()
-                        done = finish(m["i"], fake) if finish is not None else None
-                        for t in (fake["vid"], fake["code"]):   # handed to the caller's stream
-                            t.record_stream(entry)
-                    results.append({"fake": fake, "enc_code": m["ws"]["encoded"]["code"], "finished": done, "index": m["i"]})
-                    timings.append(dict(m["ev"], t0=cur["t0"], t1=cur["t1"], group=len(cur["members"])))
-                    m["ws"] = None
+                s_dec.wait_event(job["t1"])
+                return codes["code"][k * nb:(k + 1) * nb], (state_all[k * nb:(k + 1) * nb] if state_all is not None else None)
+
+            task["m"]["segs"] = []
+            with torch.cuda.stream(s_dec):
+                task["gen"] = self._decode_codes_stream(task["m"]["ws"], code_of, final)
+                task["need"] = next(task["gen"])
+
+        def is_ready(task):
+            if task["gen"] is None:
+                start(task)
+            feed, f = task["job"]["feed"], task["need"] - 1
+            if not feed.flags[f].is_set():
+                return False
+            ev = feed.events[f]
+            return ev is None or ev.query()    # None: released without tokens (error path) -- `advance` raises
+
+        def pick():
+            """The oldest batch whose next frame of tokens is there; none: wait for one (the worker's error, if that is why)."""
+            t_end = time.perf_counter() + timeout
+            while True:
+                for task in tasks:
+                    if is_ready(task):
+                        return task
+                for job in jobs:
+                    if job["error"] is not None:
+                        raise job["error"]
+                if time.perf_counter() > t_end:
+                    wait_job(tasks[0]["job"], "the token stage")   # raises with the stacks if it was never enqueued
+                    raise RuntimeError(f"run_pipelined: no tokens for frame {tasks[0]['need'] - 1} of batch {tasks[0]['m']['i']} within {timeout:.0f} s")
+                time.sleep(2e-4)
+
+        def advance(task):
+            """One piece of a batch's decode (its conditioning frames / one new frame) behind the event of the tokens it reads."""
+            job, m = task["job"], task["m"]
+            ev = job["feed"].events[task["need"] - 1]
+            if ev is None:
+                if job["error"] is not None:
+                    raise job["error"]
+                raise RuntimeError(f"run_pipelined: the token stage of batch {m['i']} ended without frame {task['need'] - 1}")
+            want = cu_limit if any(not j["done"].is_set() for j in jobs) else 0
+            if want != state["budget"]:
+                budget(want)
+                state["budget"] = want
+            clip = None
+            with torch.cuda.stream(s_dec):
+                s_dec.wait_event(ev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                try:
+                    task["need"] = next(task["gen"])
+                except StopIteration as fin:
+                    clip = fin.value
+                e1.record()
+            m["segs"].append((e0, e1))
+            in_flight.append(e1)
+            if clip is not None:
+                tasks[:] = [t for t in tasks if t is not task]
+                finished[m["i"]] = (task, clip)
+                job["left"] -= 1
+                if job["left"] == 0:
+                    assert jobs[0] is job or any(j is job for j in jobs)
+                    keep = [j for j in jobs if j is not job]
+                    jobs.clear()
+                    jobs.extend(keep)
                 if debug:
-                    print(f"[pipeline] batches {[m['i'] for m in cur['members']]} (chain {cur['chain']}): host ms -- wait for the token stage to be "
-                          f"enqueued {1e3 * (t_join - t_round):.0f}, encode(next group) + decode enqueue {1e3 * (time.perf_counter() - t_join):.0f}",
-                          file=sys.stderr, flush=True)
+                    print(f"[pipeline] batch {m['i']} (chain {job['chain']}) decoded in {len(m['segs'])} pieces", file=sys.stderr, flush=True)
+
+        def hand_out():
+            while state["next_out"] in finished:
+                task, fake = finished.pop(state["next_out"])
+                job, m = task["job"], task["m"]
+                with torch.cuda.stream(s_dec):
+                    done = finish(m["i"], fake) if finish is not None else None
+                    for t in (fake["vid"], fake["code"]):   # handed to the caller's stream
+                        t.record_stream(entry)
+                m["ev"]["d0"], m["ev"]["d1"] = m["segs"][0][0], m["segs"][-1][1]
+                results.append({"fake": fake, "enc_code": m["ws"]["encoded"]["code"], "finished": done, "index": m["i"]})
+                timings.append(dict(m["ev"], t0=job["t0"], t1=job["t1"], group=len(job["members"]), segs=m["segs"],
+                                    hand_overs=len({id(e) for e in job["feed"].events if e is not None})))
+                m["ws"] = None
+                state["next_out"] += 1
+
+        try:
+            top_up()
+            while tasks:
+                while len(in_flight) > depth:     # the host stays `depth` pieces ahead of stream D, so that "ready" is judged late
+                    in_flight.popleft().synchronize()
+                task = pick()
+                advance(task)
+                hand_out()
+                top_up()
         except BaseException:
             abort.set()   # the workers drop what is still queued; the error surfaces now, not after every queued token loop has run
             raise
@@ -577,7 +730,7 @@ class Generator:
         for ev in self._pipeline_events:
             out["encode"] += ev["e0"].elapsed_time(ev["e1"])
             out["transformer"] += ev["t0"].elapsed_time(ev["t1"]) / ev["group"]
-            out["decode"] += ev["d0"].elapsed_time(ev["d1"])
+            out["decode"] += sum(a.elapsed_time(b) for a, b in ev["segs"])   # its pieces; other batches' may lie between them
         return out
 
     def pipeline_timeline(self):

@@ -159,6 +159,9 @@ class GPT(nn.Module):
         # warm_only: the decode steps of a call are CAPTURED (KV cache allocated, descriptor built, hipGraphs recorded) but not
         # replayed -- `Generator.run_pipelined` prepares every (token chain, group size) this way before its worker threads start
         self.warm_only = False
+        # progress(n, codes): called on the stream of a graph-replayed generate() whenever columns [0, n) of `codes` (the cache's
+        # token buffer) are final -- `Generator.run_pipelined` hands the finished frames to the decoder while the loop goes on
+        self.progress = None
 
     @property
     def _graphs(self):
@@ -539,24 +542,34 @@ class GPT(nn.Module):
 
     GRAPH_STEPS = 8   # decode steps per replay of the long form of the captured graph
 
-    def _replay_steps(self, sampler, key, n):
+    def _replay_steps(self, sampler, key, n, known=None):
         """n decode steps: replays of a hipGraph of GRAPH_STEPS steps (all per-step state is device-resident, so a graph of
         several steps is just the step captured several times; it costs the host 1/GRAPH_STEPS of the launches -- the token
-        stages of several batches are enqueued by concurrent host threads) and of the one-step graph for the remainder."""
+        stages of several batches are enqueued by concurrent host threads) and of the one-step graph for the remainder.
+        `known`: columns of c['codes'] that are final before the first step; with a `progress` callback set, it is told after
+        every replay how many are final then (a consumer may read them behind an event it records there)."""
         k = self.GRAPH_STEPS
         if self.warm_only:
             self._decode_graph(sampler, key + (k,), steps=k)
             self._decode_graph(sampler, key)
             return
+        report = self.progress if known is not None else None
+        codes = self._cache["codes"]
         if n >= 2 * k:
             long_graph = self._decode_graph(sampler, key + (k,), steps=k)
             for _ in range(n // k):
                 long_graph.replay()
+                if report is not None:
+                    known += k
+                    report(known, codes)
             n -= (n // k) * k
         if n:
             graph = self._decode_graph(sampler, key)
             for _ in range(n):
                 graph.replay()
+                if report is not None:
+                    known += 1
+                    report(known, codes)
 
     def _decode_graph(self, sampler, key, steps=1):
         """`steps` decode steps of the current cache captured in a hipGraph (once per key).  Captured on live state: a warm-up
@@ -769,7 +782,9 @@ class GPT(nn.Module):
             self._emit(logits, sampler, host_noise(b, logits.shape[1]).to(logits.device, non_blocking=True) if sample else None, t0)
 
         if not eager:
-            self._replay_steps(sampler, (bool(sample), top_k, float(temperature), n_pre + n_cond, b), add_len - 1)
+            if self.progress is not None:
+                self.progress(t0 + 1, c["codes"])
+            self._replay_steps(sampler, (bool(sample), top_k, float(temperature), n_pre + n_cond, b), add_len - 1, known=t0 + 1)
         else:
             for _ in range(add_len - 1):
                 nz = None

@@ -112,20 +112,44 @@ class QVidModel(torch.nn.Module):
             fake, _ = self.net_g(z, [inter])
             return {dtype: fake, "layout": None}
         frames = code.size(1) // (h * w)
-        z = self._embed(code, frames)
         if not (opt.use_inter and opt.dec_model == "skipgan" and inter[0].size(1) < opt.vid_len):
-            fake, _ = self.net_g(z, [inter])
+            fake, _ = self.net_g(self._embed(code, frames), [inter])
             return {dtype: fake, "layout": None}
+        gen = self.decode_frames(lambda lo, hi: code[:, lo * h * w:hi * h * w], inter, cond_inter)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as fin:
+                return {dtype: fin.value, "layout": None}
 
+    def decode_stream(self, data, code_of):
+        """`forward(mode='vid_decoder')` for a clip whose tokens arrive frame by frame (the token loop is still running): a generator
+        that yields, before each piece of work, how many frames of tokens that piece needs (`decode_frames`) and returns the decoder's
+        dict.  `data` as for the decoder, without "code"; `code_of(lo, hi)` -> the tokens [B, (hi - lo) * h * w] of frames lo .. hi - 1."""
+        opt = self.opt
+        _, _, _, _, inter, _, cond_inter = self.preprocess_input(data)
+        if not (opt.use_inter and opt.dec_model == "skipgan" and inter[0].size(1) < opt.vid_len):
+            raise NotImplementedError("decode_stream: the flow-guided video decode only")
+        vid = yield from self.decode_frames(code_of, inter, cond_inter)
+        return {"vid": vid, "layout": None}
+
+    def decode_frames(self, code_of, inter, cond_inter):
+        """The frame loop of the flow-guided decode (quantized_video_model.py:855-918) as a generator: before the conditioning
+        frames and before every new frame it yields the number of leading frames whose tokens it is about to read through
+        `code_of(lo, hi)`, so a caller can run it beside the token loop that produces them (`Generator.run_pipelined`) -- or
+        simply exhaust it (`decode`).  Every frame is embedded and decoded by the same launches either way.  Returns the clip."""
+        opt = self.opt
         ctx = inter[0].size(1)
+        batch = inter[0].size(0)
         fakes = []
         if ctx > 0:
-            fakes.append(self.net_g(z[:, :ctx].contiguous(), [inter])[0])   # conditioning frames, own skip features
+            yield ctx
+            fakes.append(self.net_g(self._embed(code_of(0, ctx), ctx), [inter])[0])   # conditioning frames, own skip features
         # context ring: `skip_memory` slots per level, newest last (quantized_video_model.py:864-866)
         mem = opt.skip_memory
         ring = []
         for feat in inter:
-            r = feat.new_zeros(code.size(0), mem, *feat.shape[2:])
+            r = feat.new_zeros(batch, mem, *feat.shape[2:])
             keep = min(ctx, mem)
             if keep:
                 r[:, mem - keep:] = feat[:, ctx - keep:]
@@ -140,11 +164,13 @@ class QVidModel(torch.nn.Module):
             ctx += 1
         n_new = opt.vid_len - ctx
         for step in range(n_new):
+            yield curr + 1
+            z = self._embed(code_of(curr, curr + 1), 1)
             inters = [[feat[:, order[mem - dt]: order[mem - dt] + 1] for feat in ring] for dt in opt.skip_context if dt <= curr]
             if has_cond:
                 inters.append(cond_inter)
             if opt.skip_mode == "enc":
-                fake_img, _ = self.net_g(z[:, curr:curr + 1], inters, has_ctx=curr > 0)
+                fake_img, _ = self.net_g(z, inters, has_ctx=curr > 0)
                 if step == n_new - 1:
                     # the ring is local to this call and no frame follows: the reference's re-encode of the last
                     # synthesized frame (quantized_video_model.py:890-891) feeds slots nobody reads -- not run
@@ -152,8 +178,7 @@ class QVidModel(torch.nn.Module):
                     break
                 new_inter = self.encode(fake_img, None, "vid", False, None, None, quantize=False)["inter"]
             elif opt.skip_mode == "dec":
-                fake_img, _, _, _, inter_dec = self.net_g(z[:, curr:curr + 1], inters, return_all=True, inter_pre_warping=False,
-                                                          has_ctx=curr > 0)
+                fake_img, _, _, _, inter_dec = self.net_g(z, inters, return_all=True, inter_pre_warping=False, has_ctx=curr > 0)
                 new_inter = list(reversed(inter_dec))
             else:
                 raise ValueError
@@ -163,7 +188,7 @@ class QVidModel(torch.nn.Module):
                 ring[i][:, order[-1]: order[-1] + 1] = new_inter[i]
             fakes.append(fake_img)
             curr += 1
-        return {dtype: torch.cat(fakes, dim=1), "layout": None}
+        return torch.cat(fakes, dim=1)
 
     @torch.no_grad()
     def vid_step_decode(self, code, inter, cond_inter):

@@ -8,11 +8,15 @@ from tests.test_e2e_gpu import tiny, TINY_ARGV  # noqa: F401  (fixture)
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("sample,cu_limit,lanes,chains,ramp", [(False, 0, 1, 1, ()), (True, 6, 2, 1, ()), (True, 200, 3, 2, ()), (True, 0, 2, 2, (1,)),
-                                                               (True, 0, 1, 3, ())])
-def test_pipelined_equals_serial(tiny, sample, cu_limit, lanes, chains, ramp):
+@pytest.mark.parametrize("sample,cu_limit,lanes,chains,ramp,by_frame", [
+    (False, 0, 1, 1, (), True), (True, 6, 2, 1, (), True), (True, 200, 3, 2, (), True), (True, 0, 2, 2, (1,), True), (True, 0, 1, 3, (), True),
+    (True, 0, 3, 2, (), False), (False, 0, 2, 1, (1,), False)])
+def test_pipelined_equals_serial(tiny, monkeypatch, sample, cu_limit, lanes, chains, ramp, by_frame):
+    """`by_frame`: the decoder takes the tokens of a batch frame by frame while its token loop is still running
+    (`CCVS_PIPELINE_STREAM`, the default) / when the whole token stage is done."""
     from ccvs_amd.helpers.generator import Generator
     from ccvs_amd import ops
+    monkeypatch.setenv("CCVS_PIPELINE_STREAM", "1" if by_frame else "0")
     xopt = tiny["xopt"]
     xopt.sample, xopt.top_k, xopt.rec_pass = sample, 10, False
     old_noise = tiny["tr"].sample_noise
@@ -38,6 +42,8 @@ def test_pipelined_equals_serial(tiny, sample, cu_limit, lanes, chains, ramp):
         assert all(v > 0 for v in ms.values())
         sizes = [g for g, _ in gen.pipeline_token_groups()]
         assert sum(sizes) == 5 and max(sizes) <= lanes and (not ramp or sizes[0] == ramp[0])
+        # 4 frames, 1 given: the decoder runs a batch in 1 + 3 pieces and got its tokens in 4 hand-overs (one when not by frame)
+        assert all(len(ev["segs"]) == 4 and ev["hand_overs"] == (4 if by_frame else 1) for ev in gen._pipeline_events)
     finally:
         xopt.sample, xopt.rec_pass = False, True
         tiny["tr"].sample_noise = old_noise
