@@ -49,6 +49,45 @@ def test_pipelined_equals_serial(tiny, monkeypatch, sample, cu_limit, lanes, cha
         tiny["tr"].sample_noise = old_noise
 
 
+def test_failed_token_stage_surfaces_and_the_next_run_is_clean(tiny, monkeypatch):
+    """A token stage that dies while the decoder is already consuming its frames: run_pipelined raises that error (no hang, no
+    wait for the other queued stages) and the same Generator then runs the same batches bit-equal to the serial schedule."""
+    import time
+    from ccvs_amd.helpers import generator as G
+    xopt = tiny["xopt"]
+    xopt.sample, xopt.top_k, xopt.rec_pass = True, 10, False
+    old_noise = tiny["tr"].sample_noise
+    tiny["tr"].sample_noise = "device"
+    try:
+        gen = G.Generator(tiny["opt"])
+        gen.vid_model, gen.transformer_model = tiny["qv"], tiny["tr"]
+        batches = [gen.synthetic_batch(2, seed=90 + i)["vid"] for i in range(5)]
+        serial = [gen.generate_vid({"vid": b.clone()}, global_iter=30 + i) for i, b in enumerate(batches)]
+        real = G._FrameFeed.on_tokens
+        calls = {"n": 0}
+
+        def failing(self, n, codes):
+            calls["n"] += 1
+            if calls["n"] == 3:          # the first group has handed over two frames
+                raise RuntimeError("token stage broke")
+            return real(self, n, codes)
+
+        monkeypatch.setattr(G._FrameFeed, "on_tokens", failing)
+        t0 = time.perf_counter()
+        with pytest.raises(RuntimeError, match="token stage broke"):
+            gen.run_pipelined(({"vid": b.clone()} for b in batches), first_iter=30, lanes=2, chains=2)
+        assert time.perf_counter() - t0 < 60
+        monkeypatch.setattr(G._FrameFeed, "on_tokens", real)
+        res = gen.run_pipelined(({"vid": b.clone()} for b in batches), first_iter=30, lanes=2, chains=2)
+        torch.cuda.synchronize()
+        for want, got in zip(serial, res):
+            assert torch.equal(got["fake"]["code"], want["fake"]["code"])
+            assert torch.equal(got["fake"]["vid"], want["fake"]["vid"])
+    finally:
+        xopt.sample, xopt.rec_pass = False, True
+        tiny["tr"].sample_noise = old_noise
+
+
 def test_decode_gemm_rows_do_not_depend_on_the_launch():
     """The weight-stream GEMM (`gemm16_kernel<RB>`): a row's result is the same bits whether it is computed in a launch of
     16 rows (RB = 1) or stacked with the rows of other batches (RB = 2, 3, 4, two workgroup rows): plain, split-K (K = 4096),
