@@ -517,6 +517,12 @@ class Generator:
                 raise RuntimeError("run_pipelined: the batches of a token group must share total_len")
             chain = n_groups % chains
             n_groups += 1
+            if is_cold(chain, members[0]["batch"], len(members)):
+                # a batch size warm_up() has not seen (ragged input): the capture must not race with a worker's launches --
+                # wait until every queued token stage is enqueued (the workers then sleep on their queues), capture here
+                for queued in jobs:
+                    wait_job(queued, "the token stage (before a capture for a new batch size)")
+                warm(chain, members[0]["batch"], len(members), members[0]["ws"])
             with torch.cuda.stream(s_dec):
                 feed = _FrameFeed(len(members) * members[0]["batch"], opt.vid_len, frame_tokens, dev)
                 feed.codes.record_stream(chain_list[chain][1])
@@ -535,45 +541,52 @@ class Generator:
                     tok_in[key] = cropped[0][key] if len(cropped) == 1 else torch.cat([c[key] for c in cropped], dim=0)
             return tok_in
 
+        def is_cold(c, nb, g):
+            # the captured steps live in the engine's cache of that row count: ask the engine, not only the side set (a serial
+            # generate_vid with the same rows but another group count or a longer sequence, the eviction at 8 entries or
+            # drop_engine_state() rebuild the cache and drop its graphs -- the capture would then happen in a worker thread)
+            cache = chain_list[c][0].net_t._caches.get(nb * g)
+            live = cache is not None and cache.get("G") == g and len(cache.get("graphs", {})) > 0
+            key = capture_key(c, nb * g, g)
+            if not live:
+                self._warm_keys.discard(key)
+            return key not in self._warm_keys
+
+        def warm(c, nb, g, ws):
+            """Capture the decode step of chain c for g stacked batches of nb clips (inputs: the working set of one such batch),
+            from this thread; nothing is replayed, the sampler words are put back."""
+            tr, s_tok = chain_list[c]
+            s_tok.wait_stream(s_dec)
+            with torch.cuda.stream(s_tok):
+                self._seed_sampler_group(nb, list(range(g)), tr.net_t)
+                tr.net_t.warm_only = True
+                try:
+                    tr(stack_inputs([ws["cropped"]] * g), mode='inference', total_len=ws["total_len"])
+                finally:
+                    tr.net_t.warm_only = False
+                    tr.net_t.noise_key, tr.net_t.row_offset = None, 0
+            s_tok.synchronize()
+            self._warm_keys.add(capture_key(c, nb * g, g))
+            s_dec.wait_stream(s_tok)
+
         def warm_up():
             """Capture the decode step of every (chain, group size) this run can use that is not captured yet, from this thread,
             before any worker exists: first-time launches and graph captures never race with another thread's launches, and
-            no capture falls into the steady state.  The first batch is encoded once more for it; results are discarded."""
+            no capture falls into the steady state.  The first batch is encoded once more for it; results are discarded.  (A
+            later batch of another size: `submit_group` waits until no worker is launching and captures then.)"""
             first = next(it, None)
             if first is None:
                 return
             held.append(first)
             nb = first["vid"].shape[0]
             sizes = sorted({self._token_group_size(nb, g) for g in range(1, lanes + 1)})
-            def is_cold(c, g):
-                # the captured steps live in the engine's cache of that row count: ask the engine, not only the side set (a serial
-                # generate_vid with the same rows but another group count or a longer sequence, the eviction at 8 entries or
-                # drop_engine_state() rebuild the cache and drop its graphs -- the capture would then happen in a worker thread)
-                cache = chain_list[c][0].net_t._caches.get(nb * g)
-                live = cache is not None and cache.get("G") == g and len(cache.get("graphs", {})) > 0
-                key = capture_key(c, nb * g, g)
-                if not live:
-                    self._warm_keys.discard(key)
-                return key not in self._warm_keys
-            cold = [(c, g) for c in range(chains) for g in sizes if is_cold(c, g)]
+            cold = [(c, g) for c in range(chains) for g in sizes if is_cold(c, nb, g)]
             if not cold:
                 return
             with torch.cuda.stream(s_dec):
                 ws = self.condition({k: (v.clone() if torch.is_tensor(v) else v) for k, v in first.items()})
             for c, g in cold:
-                tr, s_tok = chain_list[c]
-                s_tok.wait_stream(s_dec)
-                with torch.cuda.stream(s_tok):
-                    self._seed_sampler_group(nb, list(range(g)), tr.net_t)
-                    tr.net_t.warm_only = True
-                    try:
-                        tr(stack_inputs([ws["cropped"]] * g), mode='inference', total_len=ws["total_len"])
-                    finally:
-                        tr.net_t.warm_only = False
-                        tr.net_t.noise_key, tr.net_t.row_offset = None, 0
-                s_tok.synchronize()
-                self._warm_keys.add(capture_key(c, nb * g, g))
-            s_dec.wait_stream(s_tok)
+                warm(c, nb, g, ws)
 
         warm_up()
         threads = [threading.Thread(target=worker, args=(k,), name=f"ccvs-token-chain-{k}", daemon=True) for k in range(chains)]

@@ -49,6 +49,35 @@ def test_pipelined_equals_serial(tiny, monkeypatch, sample, cu_limit, lanes, cha
         tiny["tr"].sample_noise = old_noise
 
 
+def test_pipelined_ragged_batch_sizes(tiny):
+    """Batches of another size in the middle of a run: they start their own token groups, their decode steps are captured from
+    the calling thread once no worker is launching, and every clip still equals the serial schedule's."""
+    from ccvs_amd.helpers.generator import Generator
+    xopt = tiny["xopt"]
+    xopt.sample, xopt.top_k, xopt.rec_pass = True, 10, False
+    old_noise = tiny["tr"].sample_noise
+    tiny["tr"].sample_noise = "device"
+    try:
+        gen = Generator(tiny["opt"])
+        gen.vid_model, gen.transformer_model = tiny["qv"], tiny["tr"]
+        sizes = [2, 2, 3, 3, 3, 1, 2]
+        batches = [gen.synthetic_batch(n, seed=60 + i)["vid"] for i, n in enumerate(sizes)]
+        serial = [gen.generate_vid({"vid": b.clone()}, global_iter=50 + i) for i, b in enumerate(batches)]
+        for tr, _ in gen._chains:            # the serial calls above left captured steps behind: start cold
+            tr.net_t.drop_engine_state()
+        gen.transformer_model.net_t.drop_engine_state()
+        res = gen.run_pipelined(({"vid": b.clone()} for b in batches), first_iter=50, lanes=2, chains=2)
+        torch.cuda.synchronize()
+        assert [r["index"] for r in res] == list(range(50, 57))
+        assert [g for g, _ in gen.pipeline_token_groups()] == [2, 2, 1, 1, 1]     # 2+2 | 3+3 | 3 | 1 | 2
+        for want, got in zip(serial, res):
+            assert torch.equal(got["fake"]["code"], want["fake"]["code"])
+            assert torch.equal(got["fake"]["vid"], want["fake"]["vid"])
+    finally:
+        xopt.sample, xopt.rec_pass = False, True
+        tiny["tr"].sample_noise = old_noise
+
+
 def test_failed_token_stage_surfaces_and_the_next_run_is_clean(tiny, monkeypatch):
     """A token stage that dies while the decoder is already consuming its frames: run_pipelined raises that error (no hang, no
     wait for the other queued stages) and the same Generator then runs the same batches bit-equal to the serial schedule."""
