@@ -447,7 +447,9 @@ def main():
                 shared = {"achieved": achieved, "frac": achieved / (BF16_MFMA_PEAK_TFLOPS if kind == "bf16x3" else FP32_MFMA_PEAK_TFLOPS),
                           "launches": n_conv, "avg_launch_us": 1e3 * conv_ms / max(n_conv, 1), "share_of_step_time": conv_ms * 1e-3 / elapsed,
                           "note": f"HIP events around every convolution launch of the {args.steps} timed batches: the launches share the chip with "
-                                  f"{gen.last_chains} token loops (each over the stacked rows of up to {gen.last_lanes} other batches)"}
+                                  f"{gen.last_chains} token loops (each over the stacked rows of up to {gen.last_lanes} other batches) -- all of them: "
+                                  "the decoder follows the token loops frame by frame, so the run has no quiet tail in which the last decodes ran "
+                                  "alone (rounds 2-3 and the first half of round 4 averaged such a tail into this figure)"}
                 n_conv, conv_flops, conv_ms, achieved = n_a, f_a, ms_a, alone
                 timer = timer_alone
             # bf16x3: three bf16 MFMA products per algorithmic fp32 product; peak = dense bf16 MFMA
