@@ -38,6 +38,7 @@ int ccvs_cu_limit_of(void* stream);
 struct GridWalk {
     long total;
     int nx, ny;
+    int tiled;   // the four-pixel gather kernels: t > 0 -- block bx is a tile of 4t x 256/t pixels instead of 1024 consecutive pixels (quad_pixel)
 };
 #define GRID_WALK_BEGIN(gw, bx, by, bz)                                              \
     for (long w_ = blockIdx.x; w_ < (gw).total; w_ += gridDim.x) {                   \
@@ -48,7 +49,7 @@ struct GridWalk {
 
 static inline GridWalk grid_walk(long nx, long ny, long nz) {
     GridWalk g;
-    g.total = nx * ny * nz; g.nx = (int)nx; g.ny = (int)ny;
+    g.total = nx * ny * nz; g.nx = (int)nx; g.ny = (int)ny; g.tiled = 0;
     return g;
 }
 // workgroups to launch for `blocks` blocks of work on `stream`: all of them, or cu_limit x per_cu persistent ones

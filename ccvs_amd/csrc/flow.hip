@@ -284,7 +284,14 @@ struct BilinPair {
     float a0, b0, a1, b1;    // weights of (pair.x, pair.y) in row y0, row y1
 };
 
-__device__ __forceinline__ BilinPair bilin_setup_pair(int x, int y, float fx, float fy, int H, int W) {
+// the same set-up with the pair's column and the two rows kept as coordinates (the windowed kernels address an LDS copy of
+// the source window with them); bilin_setup_pair IS this function, so the weights cannot differ between the two forms
+struct BilinWin {
+    BilinPair q;
+    int xb, r0, r1;          // first column of the pairs; rows of the pairs (0 where the row is outside: its weights are 0)
+};
+
+__device__ __forceinline__ BilinWin bilin_setup_win(int x, int y, float fx, float fy, int H, int W) {
     const float gx = ((2.f * x + 1.f) / W - 1.f) + fx / ((W - 1.0f) / 2.0f);
     const float gy = ((2.f * y + 1.f) / H - 1.f) + fy / ((H - 1.0f) / 2.0f);
     const float ix = ((gx + 1.f) * W - 1.f) * 0.5f;
@@ -295,7 +302,8 @@ __device__ __forceinline__ BilinPair bilin_setup_pair(int x, int y, float fx, fl
     const float xc = fminf(fmaxf(x0f, -2.f), (float)W + 1.f), yc = fminf(fmaxf(y0f, -2.f), (float)H + 1.f);
     const int x0 = (int)xc, y0 = (int)yc, y1 = y0 + 1;
     const bool vy0 = (y0 >= 0 && y0 < H), vy1 = (y1 >= 0 && y1 < H);
-    BilinPair q;
+    BilinWin b;
+    BilinPair& q = b.q;
     int xb = 0;
     q.a0 = 0.f; q.b0 = 0.f; q.a1 = 0.f; q.b1 = 0.f;
     if (x0 >= 0 && x0 + 1 < W) {          // both columns inside
@@ -307,15 +315,27 @@ __device__ __forceinline__ BilinPair bilin_setup_pair(int x, int y, float fx, fl
     }
     if (!vy0) { q.a0 = 0.f; q.b0 = 0.f; }
     if (!vy1) { q.a1 = 0.f; q.b1 = 0.f; }
-    q.o0 = (vy0 ? y0 : 0) * W + xb;
-    q.o1 = (vy1 ? y1 : 0) * W + xb;
-    return q;
+    b.xb = xb;
+    b.r0 = vy0 ? y0 : 0;
+    b.r1 = vy1 ? y1 : 0;
+    q.o0 = b.r0 * W + xb;
+    q.o1 = b.r1 * W + xb;
+    return b;
+}
+
+__device__ __forceinline__ BilinPair bilin_setup_pair(int x, int y, float fx, float fy, int H, int W) {
+    return bilin_setup_win(x, y, fx, fy, H, W).q;
+}
+
+// the four products of a sample, summed in ONE order wherever the two pairs come from (global memory or an LDS window)
+__device__ __forceinline__ float bilin_mix(const F32Pair& r0, const F32Pair& r1, const BilinPair& q) {
+    return ((r0.x * q.a0 + r0.y * q.b0) + r1.x * q.a1) + r1.y * q.b1;
 }
 
 __device__ __forceinline__ float bilin_sample_pair(const float* __restrict__ plane, const BilinPair& q) {
     const F32Pair r0 = *reinterpret_cast<const F32Pair*>(plane + q.o0);
     const F32Pair r1 = *reinterpret_cast<const F32Pair*>(plane + q.o1);
-    return ((r0.x * q.a0 + r0.y * q.b0) + r1.x * q.a1) + r1.y * q.b1;
+    return bilin_mix(r0, r1, q);
 }
 
 #define WARP_CCH 16  // channels per thread
@@ -350,11 +370,36 @@ __global__ __launch_bounds__(256) void backwarp_kernel(CtxList ctx, long x_sC,
     GRID_WALK_END
 }
 
+// First pixel of a thread's quad in the four-pixel warp kernels.  Plain: block bx = 1024 consecutive pixels (4 rows of a 256-wide
+// image).  Tiled: block bx = a tile of 4 t x 256 / t pixels, t threads along a row (t = GridWalk.tiled = 16: 64 x 16; needs W % 4t == 0,
+// H % (256 / t) == 0).  The gathers of a workgroup then fall into ~20 rows x 3 cache lines per channel instead of ~8 rows x 8 lines
+// and a thread's neighbours above and below re-use its lines: with a smooth flow field of sigma 3.2 px at 256^2 the fusion / blend
+// tail (k = 15) 2.35 -> 1.46 ms, the back-warp 2.33 -> 1.98, warp + projection 2.02 -> 1.59; with per-pixel noise of the same
+// spread 4.02 -> 2.77, 3.53 -> 2.72, 3.42 -> 2.46; never slower (profiles/r04_warp_tile_ab.txt).  Same arithmetic per pixel either
+// way (tests/test_ops_gpu.py::test_warp_kernels_tiled_pixel_order).  An LDS copy of the source window (min / max of the pair
+// coordinates over the tile, 16-byte row loads, gathers from LDS) was built first and was SLOWER than the plain gathers on the same
+// tiles: 3.0 ms against 1.5 -- two barriers and a dependent load phase per context buy nothing the L1 does not already give.
+static int warp_tiled(int H, int W) {
+    static const int t = getenv("CCVS_WARP_TILED") ? atoi(getenv("CCVS_WARP_TILED")) : 16;   // threads along a tile row; 0: plain
+    if (t != 8 && t != 16 && t != 32 && t != 64) return 0;
+    return (W % (4 * t) == 0 && H % (256 / t) == 0) ? t : 0;
+}
+__device__ __forceinline__ int quad_pixel(const GridWalk& gw, int bx, int W) {
+    if (gw.tiled) {
+        const int t = gw.tiled;
+        const int tiles_x = W / (4 * t);
+        const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+        const int r = (int)threadIdx.x / t, c = (int)threadIdx.x - r * t;
+        return (ty * (256 / t) + r) * W + (tx * t + c) * 4;
+    }
+    return (bx * 256 + (int)threadIdx.x) * 4;
+}
+
 __global__ __launch_bounds__(256) void backwarp4_kernel(CtxList ctx, long x_sC, const float* __restrict__ flow, long flow_sN, float mult,
                                                         float* __restrict__ y, long y_sN, long y_sC, int C, int H, int W, GridWalk gw) {
     const int HW = H * W;
     GRID_WALK_BEGIN(gw, bx, by, bz)
-    const int pix = (bx * 256 + threadIdx.x) * 4;
+    const int pix = quad_pixel(gw, bx, W);
     if (pix >= HW) continue;
     const int n = bz, c0 = by * WARP4_CCH;
     const int jn = n % ctx.k;
@@ -379,7 +424,8 @@ __global__ __launch_bounds__(256) void backwarp4_kernel(CtxList ctx, long x_sC, 
 static void launch_backwarp(const CtxList& l, long x_sC, const float* flow, long flow_sN, float mult, float* y, long y_sN, long y_sC, int N, int C,
                             int H, int W, void* stream) {
     if (W % 4 == 0) {
-        const GridWalk gw = grid_walk(cdiv(H * W / 4, 256), cdiv(C, WARP4_CCH), N);
+        GridWalk gw = grid_walk(cdiv(H * W / 4, 256), cdiv(C, WARP4_CCH), N);
+        gw.tiled = warp_tiled(H, W);
         hipLaunchKernelGGL(backwarp4_kernel, dim3(limited_grid(gw.total, stream, 8)), dim3(256), 0, (hipStream_t)stream, l, x_sC, flow, flow_sN, mult,
                            y, y_sN, y_sC, C, H, W, gw);
     } else {
@@ -582,7 +628,7 @@ __global__ __launch_bounds__(256) void warp_proj4_kernel(CtxList ctx, long x_sC,
     const int HW = H * W;
     GRID_WALK_BEGIN(gw, bx, by, bz)
     (void)bz;
-    const int pix = (bx * 256 + threadIdx.x) * 4;
+    const int pix = quad_pixel(gw, bx, W);
     if (pix >= HW) continue;
     const int n = by;
     const int jn = n % ctx.k;
@@ -683,7 +729,8 @@ extern "C" int ccvs_backwarp_proj_ctx(const ccvs_ctx_list* ctx, int64_t x_sC, co
     hipLaunchKernelGGL((warp_proj_kernel<CO>), grid, dim3(256), 0, st, l, (long)x_sC, flow, (long)flow_sN, flow_mult, w_t, bias, y, Cin, Cout, \
                        H, W, act, gw)
     if (W % 4 == 0 && CoutPad <= 24) {
-        const GridWalk gw4 = grid_walk(cdiv(H * W / 4, 256), N, 1);
+        GridWalk gw4 = grid_walk(cdiv(H * W / 4, 256), N, 1);
+        gw4.tiled = warp_tiled(H, W);
         const dim3 grid4(limited_grid(gw4.total, stream, 4));
         if (CoutPad == 16)
             hipLaunchKernelGGL((warp_proj4_kernel<16>), grid4, dim3(256), 0, st, l, (long)x_sC, flow, (long)flow_sN, flow_mult, w_t, bias, y, Cin, Cout, H, W, act, gw4);
@@ -753,7 +800,7 @@ __global__ __launch_bounds__(256) void warp_fuse_blend4_kernel(float* __restrict
                                                                long occs_sN, float mult, int k, int C, int H, int W, GridWalk gw) {
     const int HW = H * W;
     GRID_WALK_BEGIN(gw, bx, by, bz)
-    const int pix = (bx * 256 + threadIdx.x) * 4;
+    const int pix = quad_pixel(gw, bx, W);
     if (pix >= HW) continue;
     const int n = bz, c0 = by * CCH;
     const int py = pix / W, px = pix - py * W;
@@ -824,7 +871,8 @@ static void launch_warp_fuse_blend(float* dec, long dec_sN, long dec_sC, const C
     if (W % 4 == 0) {
         static const int cch = getenv("CCVS_FUSE_CCH") ? atoi(getenv("CCVS_FUSE_CCH")) : 8;
         static const int pref = getenv("CCVS_FUSE_PREF") ? atoi(getenv("CCVS_FUSE_PREF")) : 1;
-        const GridWalk gw = grid_walk(cdiv(H * W / 4, 256), cdiv(C, cch == 4 ? 4 : 8), N);
+        GridWalk gw = grid_walk(cdiv(H * W / 4, 256), cdiv(C, cch == 4 ? 4 : 8), N);
+        gw.tiled = warp_tiled(H, W);
 #define WFB_LAUNCH(CCHv, PREFv)                                                                                                         \
     hipLaunchKernelGGL((warp_fuse_blend4_kernel<CCHv, PREFv>), dim3(limited_grid(gw.total, stream, 8)), dim3(256), 0, (hipStream_t)stream, dec, \
                        dec_sN, dec_sC, l, flows, flows_sN, occs, occs_sN, mult, k, C, H, W, gw)

@@ -341,6 +341,66 @@ def test_warp_fuse_blend(ops, k):
     close(d[:, c:], dec_full[:, c:], 0)
 
 
+_WARP_TILED_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from ccvs_amd import ops
+torch.manual_seed(11)
+out = []
+for (n, k, c, h, w, scale) in ((2, 3, 10, 32, 64, 2.0), (1, 5, 7, 48, 128, 6.0), (2, 2, 4, 16, 64, 40.0), (1, 15, 8, 64, 256, 3.0)):
+    dec = torch.randn(n, c + 3, h, w).cuda()
+    ctxs = [torch.randn(n, c, h, w).cuda() for _ in range(k)]
+    flow = (torch.randn(n * k, 2, h, w) * scale).cuda()
+    flow[0, :, :4, :8] = 300.0            # far outside the image: zero weights, clamped coordinates
+    occ = torch.randn(n * k, 1, h, w).cuda()
+    ops.warp_fuse_blend(dec[:, :c], ctxs, flow, occ, 0.5, k)
+    out.append(dec.cpu())
+    out.append(ops.backwarp(ctxs, flow, 0.5).cpu())
+    if c % 4 == 0:
+        w_t, cout_pad = ops.pack_proj_weight(torch.randn(24, c, 1, 1).cuda())
+        out.append(ops.backwarp_proj(ctxs, flow, 0.5, w_t, cout_pad, torch.randn(24).cuda(), 24, act=True).cpu())
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_warp_kernels_tiled_pixel_order(ops, tmp_path):
+    """The four-pixel warp kernels (back-warp, warp + projection, fusion / blend) with a workgroup = a 64 x 16 tile (W % 64 == 0,
+    H % 16 == 0: CCVS_WARP_TILED, the default) against 1024 consecutive pixels (=0): bit for bit -- small, moderate and huge
+    flows, k = 2 ... 15, ragged channel chunks; the fusion / blend and the back-warp of the first case also against the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("1", "0"):
+        path = str(tmp_path / f"warp_{mode}.pt")
+        env = dict(os.environ, CCVS_WARP_TILED=mode)
+        res = subprocess.run([sys.executable, "-c", _WARP_TILED_SCRIPT, root, path], capture_output=True, text=True, timeout=600, env=env)
+        assert res.returncode == 0, res.stderr[-3000:]
+        outs[mode] = torch.load(path)
+    assert len(outs["1"]) == 10
+    for a, b in zip(outs["1"], outs["0"]):
+        assert torch.equal(a, b), "a result depends on the pixel order of the workgroups"
+    # the first case against the oracle
+    torch.manual_seed(11)
+    n, k, c, h, w, scale = 2, 3, 10, 32, 64, 2.0
+    dec = torch.randn(n, c + 3, h, w)
+    ctxs = [torch.randn(n, c, h, w) for _ in range(k)]
+    flow = torch.randn(n * k, 2, h, w) * scale
+    flow[0, :, :4, :8] = 300.0
+    occ = torch.randn(n * k, 1, h, w)
+    stacked = torch.stack(ctxs, dim=1).reshape(n * k, c, h, w)
+    warped = O.backwarp(stacked, flow * 0.5, O.backwarp_grid(h, w))
+    confs = (1 - torch.sigmoid(occ)).view(-1, k, 1, h, w) + 1e-6
+    wi = (warped.view(-1, k, c, h, w) * confs).sum(1) / confs.sum(1)
+    oc = (occ.view(-1, k, 1, h, w) * confs).sum(1) / confs.sum(1)
+    m = torch.sigmoid(oc)
+    want = m * dec[:, :c] + (1 - m) * wi
+    close(outs["1"][0][:, :c], want, 1e-4)
+    close(outs["1"][0][:, c:], dec[:, c:], 0)
+    close(outs["1"][1], warped, 1e-4)
+
+
 # ------------------------------------------------------------------ VQ
 @pytest.mark.parametrize("name", ["default", "randn"])
 def test_vq_golden(ops, gold, name):

@@ -30,6 +30,9 @@ def main():
     n, c, h = 120, 96, 256
     x = torch.randn(n, c, h, h, device="cuda")
     flow = torch.randn(n, 2, h, h, device="cuda") * float(os.environ.get("FLOW_SCALE", "0.1"))
+    if os.environ.get("FLOW_SMOOTH", "0") == "1":   # a smooth field of the same spread (a real motion field; per-pixel noise is the worst case for the gathers)
+        flow = torch.nn.functional.interpolate(torch.randn(n, 2, h // 16, h // 16, device="cuda"), size=(h, h), mode="bicubic") * float(os.environ.get("FLOW_SCALE", "0.1"))
+        flow = flow.contiguous()
     occ = torch.randn(n, 1, h, h, device="cuda")
     out = torch.empty_like(x)
     row("backwarp 120x96x256^2", timeit(lambda: ops.backwarp(x, flow, 32.0, out=out)), 2 * x.numel() * 4)
