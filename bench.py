@@ -449,7 +449,10 @@ def main():
                           "note": f"HIP events around every convolution launch of the {args.steps} timed batches: the launches share the chip with "
                                   f"{gen.last_chains} token loops (each over the stacked rows of up to {gen.last_lanes} other batches) -- all of them: "
                                   "the decoder follows the token loops frame by frame, so the run has no quiet tail in which the last decodes ran "
-                                  "alone (rounds 2-3 and the first half of round 4 averaged such a tail into this figure)"}
+                                  "alone (rounds 2-3 and the first half of round 4 averaged such a tail into this figure)"
+                                  + (f"; and with the decodes of {gen.last_dec_streams} batches side by side on {gen.last_dec_streams} streams: a launch's "
+                                     "duration here is that of a kernel sharing the chip with the other decode's kernels as well -- a figure of the "
+                                     "schedule (compare `value`), not of the kernel (`achieved`)" if getattr(gen, "last_dec_streams", 1) > 1 else "")}
                 n_conv, conv_flops, conv_ms, achieved = n_a, f_a, ms_a, alone
                 timer = timer_alone
             # bf16x3: three bf16 MFMA products per algorithmic fp32 product; peak = dense bf16 MFMA
@@ -476,9 +479,10 @@ def main():
                                       else f"the {n_enc} conditioning frame(s) per clip that synthesis reads (`--encode cond`)"),
                            "rec_pass": ("also run, not counted" if args.rec_pass else "off: the reference's extra teacher-forced reconstruction decode is not part of "
                                         "the synthesized-frames metric (SURVEY 8d)"), "sampling": f"top-k {xopt.top_k}, T={xopt.temperature}, noise={args.sample_noise}",
-                           "schedule": (f"pipelined: up to {gen.last_lanes * gen.last_chains + 1} batches in flight per GPU -- {gen.last_chains} token loops on "
-                                        f"high-priority streams, each ONE loop over the stacked rows of {gen.last_lanes} consecutive batches (weights streamed "
-                                        f"once per token for all of them, per-batch KV rows and sampler words), beside the encoder/decoder of an earlier batch"
+                           "schedule": (f"pipelined: up to {gen.last_lanes * (gen.last_chains + 2)} batches in flight per GPU -- {gen.last_chains} token loops on "
+                                        f"their own streams, each ONE loop over the stacked rows of {gen.last_lanes} consecutive batches (weights streamed "
+                                        f"once per token for all of them, per-batch KV rows and sampler words), beside the encoder and {getattr(gen, 'last_dec_streams', 1)} decode streams "
+                                        f"(the decoder takes a batch's tokens frame by frame; the decode of batch i runs on stream i % {getattr(gen, 'last_dec_streams', 1)})"
                                         + (f", whose kernels are capped to {gen.last_cu_limit} of {n_cu} CUs" if gen.last_cu_limit else "")
                                         + f"; every generate call is one batch of {args.batch} clips; "
                                         "K batches timed from resident inputs to gathered clips, fill and drain included") if args.schedule == "pipelined"
@@ -521,8 +525,10 @@ def main():
                     span = max(t["d1"] for t in tl) - min(t["e0"] for t in tl)
                     line["decoder_stream"] = {"busy_ms": busy, "span_ms": span, "idle_frac": max(0.0, 1.0 - busy / span),
                                               "first_decode_starts_ms": min(t["d0"] for t in tl), "token_stages_end_ms": max(t["t1"] for t in tl),
-                                              "note": "HIP events on stream D around every encode and every piece (conditioning frames / one frame) of every "
-                                                      "decode; the decoder takes a batch's tokens frame by frame while its token loop runs"}
+                                              "decode_streams": getattr(gen, "last_dec_streams", 1),
+                                              "note": "HIP events around every encode and every piece (conditioning frames / one frame) of every decode, on the "
+                                                      "stream the piece runs on; with more than one decode stream the pieces of two batches overlap in time and "
+                                                      "busy_ms (their sum) exceeds the span: idle_frac is then a lower bound of 0"}
             line["hbm_peak_allocated_gb"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30   # every batch in flight + weights + graphs' pools (torch allocator)
             # the token loop as a whole, in situ: weights ONCE per step of a token group + the keys and values of every batch in it,
             # against the HBM peak

@@ -400,22 +400,32 @@ class Generator:
             raise NotImplementedError("run_pipelined covers the plain synthesis schedule (use generate_vid for step_by_step / rec_only)")
         dev = torch.device("cuda", torch.cuda.current_device())
         if lanes is None:
-            lanes = int(os.environ.get("CCVS_PIPELINE_LANES", "3"))
+            lanes = int(os.environ.get("CCVS_PIPELINE_LANES", "4"))
         if chains is None:
             chains = int(os.environ.get("CCVS_PIPELINE_CHAINS", "2"))
         if ramp is None:
             ramp = tuple(int(v) for v in os.environ.get("CCVS_PIPELINE_RAMP", "").split(",") if v)
         chains = max(1, chains)
-        if getattr(self, "_dec_stream", None) is None:
-            prio = [int(v) for v in os.environ.get("CCVS_PIPELINE_PRIORITIES", "0,-1").split(",")]   # (token streams, decode stream)
-            self._dec_stream = torch.cuda.Stream(device=dev, priority=prio[1])
-        s_dec = self._dec_stream
+        # stream D and its twins: the encodes run on the first, the decode of batch i on stream i % n (two decodes side by side:
+        # the small launches of one's coarse pyramid levels run under the other's large ones)
+        # (default: two for frames of 128^2 and more -- there the decoder is the longer stage; one for the 64^2 configurations, whose
+        # token loops are, and lose what a second decode takes: Kinetics 353 against 361 frames/s)
+        n_dec = os.environ.get("CCVS_PIPELINE_DEC_STREAMS", "")
+        n_dec = max(1, int(n_dec)) if n_dec else (2 if int(getattr(self.opt, "max_dim", 256)) >= 128 else 1)
+        if len(getattr(self, "_dec_streams", ())) < n_dec:
+            prio = [int(v) for v in os.environ.get("CCVS_PIPELINE_PRIORITIES", "0,-1").split(",")]   # (token streams, decode streams)
+            have = list(getattr(self, "_dec_streams", ()))
+            self._dec_streams = have + [torch.cuda.Stream(device=dev, priority=prio[1]) for _ in range(n_dec - len(have))]
+            self._dec_stream = self._dec_streams[0]
+        dec_streams = self._dec_streams[:n_dec]
+        s_dec = dec_streams[0]
         chain_list = [self._token_chain(k) for k in range(chains)]
         if cu_limit is None:   # 0 = no budget
             cu_limit = int(os.environ.get("CCVS_PIPELINE_CU_LIMIT", "0"))
         timeout = float(os.environ.get("CCVS_PIPELINE_TIMEOUT", "600"))
         entry = torch.cuda.current_stream()
-        s_dec.wait_stream(entry)
+        for st in dec_streams:
+            st.wait_stream(entry)
         for _, st in chain_list:
             st.wait_stream(entry)
         results, timings = [], []
@@ -425,10 +435,11 @@ class Generator:
         n_groups = 0
         debug = os.environ.get("CCVS_PIPELINE_DEBUG", "0") == "1"
         queues = [queue.Queue() for _ in range(chains)]
-        self.last_cu_limit, self.last_lanes, self.last_chains = cu_limit, lanes, chains
+        self.last_cu_limit, self.last_lanes, self.last_chains, self.last_dec_streams = cu_limit, lanes, chains, len(dec_streams)
 
-        def budget(n):   # CU budget of everything submitted to the decode stream from now on
-            ops.stream_cu_limit(s_dec, n)
+        def budget(n):   # CU budget of everything submitted to the decode streams from now on
+            for st in dec_streams:
+                ops.stream_cu_limit(st, n)
 
         def capture_key(chain, rows, groups):
             """What a captured decode step depends on (the cache length follows from the options): such a key is warmed once."""
@@ -594,7 +605,7 @@ class Generator:
             th.start()
         jobs = deque()        # submitted token groups with undecoded batches, oldest first
         tasks = []            # the decodes of their batches, oldest first
-        in_flight = deque()   # events behind the pieces of decoder work enqueued last
+        in_flight = [deque() for _ in dec_streams]   # per decode stream: events behind the pieces of decoder work enqueued last
         finished = {}         # batch index -> (task, clip) decoded ahead of an earlier batch: handed out in index order
         depth = max(1, int(os.environ.get("CCVS_PIPELINE_DEPTH", "2")))
         state = {"exhausted": False, "next_out": first_iter, "budget": 0}
@@ -607,7 +618,8 @@ class Generator:
                     state["exhausted"] = True
                     break
                 jobs.append(job)
-                tasks.extend({"job": job, "k": k, "m": m, "gen": None, "need": None} for k, m in enumerate(job["members"]))
+                tasks.extend({"job": job, "k": k, "m": m, "gen": None, "need": None, "sid": (m["i"] - first_iter) % len(dec_streams)}
+                             for k, m in enumerate(job["members"]))
 
         def start(task):
             """The decode of one batch as a generator over its frames (`QVidModel.decode_frames`): it reads the tokens of a frame
@@ -626,13 +638,23 @@ class Generator:
                     state_all = None
                 for t in (codes["code"], state_all):
                     if torch.is_tensor(t):
-                        t.record_stream(s_dec)
-                s_dec.wait_event(job["t1"])
+                        t.record_stream(st)
+                st.wait_event(job["t1"])
                 return codes["code"][k * nb:(k + 1) * nb], (state_all[k * nb:(k + 1) * nb] if state_all is not None else None)
 
-            task["m"]["segs"] = []
-            with torch.cuda.stream(s_dec):
-                task["gen"] = self._decode_codes_stream(task["m"]["ws"], code_of, final)
+            st = dec_streams[task["sid"]]
+            m = task["m"]
+            m["segs"] = []
+            if st is not s_dec:     # encoded on the first decode stream, decoded on this one
+                st.wait_event(m["ev"]["e1"])
+                for holder in (m["ws"]["cropped"], m["ws"]["encoded"], m["ws"]["data"]):
+                    for v in holder.values():
+                        for t in (v if isinstance(v, (list, tuple)) else (v,)):
+                            if torch.is_tensor(t) and t.is_cuda:
+                                t.record_stream(st)
+                feed.codes.record_stream(st)
+            with torch.cuda.stream(st):
+                task["gen"] = self._decode_codes_stream(m["ws"], code_of, final)
                 task["need"] = next(task["gen"])
 
         def is_ready(task):
@@ -644,13 +666,27 @@ class Generator:
             ev = feed.events[f]
             return ev is None or ev.query()    # None: released without tokens (error path) -- `advance` raises
 
+        def has_room(task):
+            """The host stays `depth` pieces ahead of a decode stream, so that "ready" is judged late."""
+            q = in_flight[task["sid"]]
+            while q and q[0].query():
+                q.popleft()
+            return len(q) <= depth
+
         def pick():
-            """The oldest batch whose next frame of tokens is there; none: wait for one (the worker's error, if that is why)."""
+            """The oldest batch whose next frame of tokens is there and whose stream has room; none: wait for one (the worker's
+            error, if that is why)."""
             t_end = time.perf_counter() + timeout
             while True:
+                blocked = None
                 for task in tasks:
                     if is_ready(task):
-                        return task
+                        if has_room(task):
+                            return task
+                        blocked = blocked or task
+                if blocked is not None:       # work is there, its stream is `depth` pieces behind: wait for a piece to finish
+                    in_flight[blocked["sid"]].popleft().synchronize()
+                    continue
                 for job in jobs:
                     if job["error"] is not None:
                         raise job["error"]
@@ -672,8 +708,9 @@ class Generator:
                 budget(want)
                 state["budget"] = want
             clip = None
-            with torch.cuda.stream(s_dec):
-                s_dec.wait_event(ev)
+            st = dec_streams[task["sid"]]
+            with torch.cuda.stream(st):
+                st.wait_event(ev)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 try:
@@ -682,7 +719,7 @@ class Generator:
                     clip = fin.value
                 e1.record()
             m["segs"].append((e0, e1))
-            in_flight.append(e1)
+            in_flight[task["sid"]].append(e1)
             if clip is not None:
                 tasks[:] = [t for t in tasks if t is not task]
                 finished[m["i"]] = (task, clip)
@@ -699,7 +736,7 @@ class Generator:
             while state["next_out"] in finished:
                 task, fake = finished.pop(state["next_out"])
                 job, m = task["job"], task["m"]
-                with torch.cuda.stream(s_dec):
+                with torch.cuda.stream(dec_streams[task["sid"]]):
                     done = finish(m["i"], fake) if finish is not None else None
                     for t in (fake["vid"], fake["code"]):   # handed to the caller's stream
                         t.record_stream(entry)
@@ -713,8 +750,6 @@ class Generator:
         try:
             top_up()
             while tasks:
-                while len(in_flight) > depth:     # the host stays `depth` pieces ahead of stream D, so that "ready" is judged late
-                    in_flight.popleft().synchronize()
                 task = pick()
                 advance(task)
                 hand_out()
@@ -729,7 +764,8 @@ class Generator:
                 th.join(30.0 if abort.is_set() else timeout)
             budget(0)
             # (also on the error path: the caller's stream must not run ahead of work still queued on ours)
-            entry.wait_stream(s_dec)
+            for st in dec_streams:
+                entry.wait_stream(st)
             for _, st in chain_list:
                 entry.wait_stream(st)
         self._pipeline_events = timings

@@ -8,15 +8,17 @@ from tests.test_e2e_gpu import tiny, TINY_ARGV  # noqa: F401  (fixture)
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("sample,cu_limit,lanes,chains,ramp,by_frame", [
-    (False, 0, 1, 1, (), True), (True, 6, 2, 1, (), True), (True, 200, 3, 2, (), True), (True, 0, 2, 2, (1,), True), (True, 0, 1, 3, (), True),
-    (True, 0, 3, 2, (), False), (False, 0, 2, 1, (1,), False)])
-def test_pipelined_equals_serial(tiny, monkeypatch, sample, cu_limit, lanes, chains, ramp, by_frame):
+@pytest.mark.parametrize("sample,cu_limit,lanes,chains,ramp,by_frame,dec_streams", [
+    (False, 0, 1, 1, (), True, 1), (True, 6, 2, 1, (), True, 2), (True, 200, 3, 2, (), True, 2), (True, 0, 2, 2, (1,), True, 1), (True, 0, 1, 3, (), True, 3),
+    (True, 0, 3, 2, (), False, 2), (False, 0, 2, 1, (1,), False, 1), (True, 0, 4, 2, (), True, 2)])
+def test_pipelined_equals_serial(tiny, monkeypatch, sample, cu_limit, lanes, chains, ramp, by_frame, dec_streams):
     """`by_frame`: the decoder takes the tokens of a batch frame by frame while its token loop is still running
-    (`CCVS_PIPELINE_STREAM`, the default) / when the whole token stage is done."""
+    (`CCVS_PIPELINE_STREAM`, the default) / when the whole token stage is done.  `dec_streams`: the decode of batch i runs on stream
+    i % dec_streams (the default: 2 for frames of 128^2 and more)."""
     from ccvs_amd.helpers.generator import Generator
     from ccvs_amd import ops
     monkeypatch.setenv("CCVS_PIPELINE_STREAM", "1" if by_frame else "0")
+    monkeypatch.setenv("CCVS_PIPELINE_DEC_STREAMS", str(dec_streams))
     xopt = tiny["xopt"]
     xopt.sample, xopt.top_k, xopt.rec_pass = sample, 10, False
     old_noise = tiny["tr"].sample_noise
@@ -49,7 +51,7 @@ def test_pipelined_equals_serial(tiny, monkeypatch, sample, cu_limit, lanes, cha
         tiny["tr"].sample_noise = old_noise
 
 
-def test_pipelined_ragged_batch_sizes(tiny):
+def test_pipelined_ragged_batch_sizes(tiny, monkeypatch):
     """Batches of another size in the middle of a run: they start their own token groups, their decode steps are captured from
     the calling thread once no worker is launching, and every clip still equals the serial schedule's."""
     from ccvs_amd.helpers.generator import Generator
@@ -66,6 +68,7 @@ def test_pipelined_ragged_batch_sizes(tiny):
         for tr, _ in gen._chains:            # the serial calls above left captured steps behind: start cold
             tr.net_t.drop_engine_state()
         gen.transformer_model.net_t.drop_engine_state()
+        monkeypatch.setenv("CCVS_PIPELINE_DEC_STREAMS", "2")
         res = gen.run_pipelined(({"vid": b.clone()} for b in batches), first_iter=50, lanes=2, chains=2)
         torch.cuda.synchronize()
         assert [r["index"] for r in res] == list(range(50, 57))
@@ -102,6 +105,7 @@ def test_failed_token_stage_surfaces_and_the_next_run_is_clean(tiny, monkeypatch
             return real(self, n, codes)
 
         monkeypatch.setattr(G._FrameFeed, "on_tokens", failing)
+        monkeypatch.setenv("CCVS_PIPELINE_DEC_STREAMS", "2")
         t0 = time.perf_counter()
         with pytest.raises(RuntimeError, match="token stage broke"):
             gen.run_pipelined(({"vid": b.clone()} for b in batches), first_iter=30, lanes=2, chains=2)

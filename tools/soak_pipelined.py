@@ -60,12 +60,13 @@ for r in range(runs):
     dt = time.perf_counter() - t0
     faulthandler.cancel_dump_traceback_later()
     tl = gen.pipeline_timeline()
-    gaps = [b["d0"] - a["d1"] for a, b in zip(tl[:-1], tl[1:])]
+    ends = sorted(t["d1"] for t in tl)      # (the decodes of consecutive batches overlap: frame by frame, two decode streams)
+    gaps = [b - a for a, b in zip(ends[:-1], ends[1:])]
     assert len(res) == n_batches and [x["index"] for x in res] == list(range(1000 * (r + 1), 1000 * (r + 1) + n_batches))
     total_b += n_batches
     total_s += dt
-    print(f"run {r + 1}/{runs}: {n_batches} batches in {dt:.1f} s = {15 * batch * n_batches / dt:.1f} frames/s; largest idle gap of the decode stream "
-          f"{max(gaps):.0f} ms (median {sorted(gaps)[len(gaps) // 2]:.0f} ms); load average {os.getloadavg()[0]:.1f}", flush=True)
+    print(f"run {r + 1}/{runs}: {n_batches} batches in {dt:.1f} s = {15 * batch * n_batches / dt:.1f} frames/s; longest time between two finished "
+          f"batches {max(gaps):.0f} ms (median {sorted(gaps)[len(gaps) // 2]:.0f} ms); load average {os.getloadavg()[0]:.1f}", flush=True)
 print(f"soak: {total_b} batches, {total_s:.0f} s, {15 * batch * total_b / total_s:.1f} frames/s, no stall, no time limit hit "
-      f"(lanes {gen.last_lanes}, chains {gen.last_chains})", flush=True)
+      f"(lanes {gen.last_lanes}, chains {gen.last_chains}, decode streams {gen.last_dec_streams})", flush=True)
 dist.destroy_process_group()
