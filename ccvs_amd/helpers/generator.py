@@ -372,7 +372,9 @@ class Generator:
             one frame at a time, the oldest batch whose next frame is there first.  In the steady state that is the old
             order (the oldest batch has all its tokens); at the start the decoder follows the first token loops one frame
             behind instead of idling through a whole token stage (`CCVS_PIPELINE_STREAM=0`: decode when the stage is done).
-            The host stays `CCVS_PIPELINE_DEPTH` pieces ahead of stream D, so that "there" is judged late.
+            The host stays `CCVS_PIPELINE_DEPTH` pieces ahead of a decode stream, so that "there" is judged late;
+          * the decode of batch i runs on decode stream i % D (`CCVS_PIPELINE_DEC_STREAMS`; the encodes on the first): the small
+            launches of one batch's coarse pyramid levels run under the large ones of another's fine levels.
         `ramp`: sizes of the first groups (e.g. (1, 2): the decoder gets its first batch after one short token stage instead
         of idling through a full one); then every group has `lanes` batches.
 
