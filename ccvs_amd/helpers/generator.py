@@ -421,12 +421,18 @@ class Generator:
             self._dec_stream = self._dec_streams[0]
         dec_streams = self._dec_streams[:n_dec]
         s_dec = dec_streams[0]
+        # the encodes: on the first decode stream, or (CCVS_PIPELINE_ENC_STREAM=1) on a stream of their own
+        s_enc = s_dec
+        if os.environ.get("CCVS_PIPELINE_ENC_STREAM", "0") == "1":
+            if getattr(self, "_enc_stream", None) is None:
+                self._enc_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CCVS_PIPELINE_PRIORITIES", "0,-1").split(",")[1]))
+            s_enc = self._enc_stream
         chain_list = [self._token_chain(k) for k in range(chains)]
         if cu_limit is None:   # 0 = no budget
             cu_limit = int(os.environ.get("CCVS_PIPELINE_CU_LIMIT", "0"))
         timeout = float(os.environ.get("CCVS_PIPELINE_TIMEOUT", "600"))
         entry = torch.cuda.current_stream()
-        for st in dec_streams:
+        for st in dec_streams + [s_enc]:
             st.wait_stream(entry)
         for _, st in chain_list:
             st.wait_stream(entry)
@@ -440,7 +446,7 @@ class Generator:
         self.last_cu_limit, self.last_lanes, self.last_chains, self.last_dec_streams = cu_limit, lanes, chains, len(dec_streams)
 
         def budget(n):   # CU budget of everything submitted to the decode streams from now on
-            for st in dec_streams:
+            for st in set(dec_streams + [s_enc]):
                 ops.stream_cu_limit(st, n)
 
         def capture_key(chain, rows, groups):
@@ -515,7 +521,7 @@ class Generator:
                     break
                 chain = n_groups % chains
                 ev = {k: torch.cuda.Event(enable_timing=True) for k in ("e0", "e1", "d0", "d1")}
-                with torch.cuda.stream(s_dec):
+                with torch.cuda.stream(s_enc):
                     ev["e0"].record()
                     ws = self.condition(data)
                     ev["e1"].record()
@@ -536,7 +542,7 @@ class Generator:
                 for queued in jobs:
                     wait_job(queued, "the token stage (before a capture for a new batch size)")
                 warm(chain, members[0]["batch"], len(members), members[0]["ws"])
-            with torch.cuda.stream(s_dec):
+            with torch.cuda.stream(s_enc):
                 feed = _FrameFeed(len(members) * members[0]["batch"], opt.vid_len, frame_tokens, dev)
                 feed.codes.record_stream(chain_list[chain][1])
                 enc_done = torch.cuda.Event()
@@ -569,7 +575,7 @@ class Generator:
             """Capture the decode step of chain c for g stacked batches of nb clips (inputs: the working set of one such batch),
             from this thread; nothing is replayed, the sampler words are put back."""
             tr, s_tok = chain_list[c]
-            s_tok.wait_stream(s_dec)
+            s_tok.wait_stream(s_enc)
             with torch.cuda.stream(s_tok):
                 self._seed_sampler_group(nb, list(range(g)), tr.net_t)
                 tr.net_t.warm_only = True
@@ -580,7 +586,7 @@ class Generator:
                     tr.net_t.noise_key, tr.net_t.row_offset = None, 0
             s_tok.synchronize()
             self._warm_keys.add(capture_key(c, nb * g, g))
-            s_dec.wait_stream(s_tok)
+            s_enc.wait_stream(s_tok)
 
         def warm_up():
             """Capture the decode step of every (chain, group size) this run can use that is not captured yet, from this thread,
@@ -596,7 +602,7 @@ class Generator:
             cold = [(c, g) for c in range(chains) for g in sizes if is_cold(c, nb, g)]
             if not cold:
                 return
-            with torch.cuda.stream(s_dec):
+            with torch.cuda.stream(s_enc):
                 ws = self.condition({k: (v.clone() if torch.is_tensor(v) else v) for k, v in first.items()})
             for c, g in cold:
                 warm(c, nb, g, ws)
@@ -647,7 +653,7 @@ class Generator:
             st = dec_streams[task["sid"]]
             m = task["m"]
             m["segs"] = []
-            if st is not s_dec:     # encoded on the first decode stream, decoded on this one
+            if st is not s_enc:     # encoded on one stream, decoded on this one
                 st.wait_event(m["ev"]["e1"])
                 for holder in (m["ws"]["cropped"], m["ws"]["encoded"], m["ws"]["data"]):
                     for v in holder.values():
@@ -766,7 +772,7 @@ class Generator:
                 th.join(30.0 if abort.is_set() else timeout)
             budget(0)
             # (also on the error path: the caller's stream must not run ahead of work still queued on ours)
-            for st in dec_streams:
+            for st in dec_streams + [s_enc]:
                 entry.wait_stream(st)
             for _, st in chain_list:
                 entry.wait_stream(st)
