@@ -562,7 +562,7 @@ def main():
                                     "GBps_of_these_two": (loop_bytes / args.steps + conv_bytes_step) / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBPS,
                                     "note": "algorithmic bytes per batch of the token loops (weights once per step of a group + keys and values) and of the "
                                             "decoder's convolutions over the measured step time; the stencil kernels of the decoder (~0.43 TB per BAIR batch, "
-                                            "profiles/r04_pmc_decoder_kernels.txt) and the encoder come on top -- DESIGN.md 4.6"}
+                                            "profiles/r04_pmc_decoder_kernels.txt) and the encoder come on top -- DESIGN.md 4.3"}
             line["roofline_decode_kernels"] = decode_kernel_rooflines(gen, xopt, args.batch)
             line["multi_gpu"] = {"rccl_ranks": (torch.distributed.get_world_size() if engine.distributed else 1), "backend": engine.backend if engine.distributed else None,
                                  "stage_ms_per_step_by_rank": rank_stages,
