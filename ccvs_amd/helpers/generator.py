@@ -326,13 +326,13 @@ class Generator:
     def _token_group_size(self, batch, lanes):
         """Batches whose token loops run as ONE loop (`lanes`, capped): the stacked rows must fit one decode step (256 rows)
         and be a few row blocks of the weight-stream GEMM at most (64 rows = one pass over the weights; more rows re-read them from
-        L2); host-drawn sampling noise is one generator stream per BATCH in the reference's order, so it is not stacked."""
+        L2: 128 by default); host-drawn sampling noise is one generator stream per BATCH in the reference's order, so it is not stacked."""
         opt = self.opt
         if getattr(opt, "sample", False) and getattr(self.transformer_model, "sample_noise", "host") != "device":
             return 1
         if getattr(opt, "beam_size", None) is not None:
             return 1
-        max_rows = int(os.environ.get("CCVS_PIPELINE_MAX_ROWS", "64"))   # experiments: up to 256 (one decode step's limit)
+        max_rows = int(os.environ.get("CCVS_PIPELINE_MAX_ROWS", "128"))   # (64 until Kinetics measured 2 x 64 rows x 3 chains: 362 -> 373 frames/s; up to 256)
         return max(1, min(int(lanes), min(max_rows, 256) // max(batch, 1)))
 
     def _token_chain(self, k):
