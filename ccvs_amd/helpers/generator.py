@@ -365,7 +365,7 @@ class Generator:
             streamed once per token for all of them instead of once per batch;
           * `chains` such loops run beside each other on their own streams, each fed by its own worker thread (beside the
             decoder a dependent launch waits longer for its memory: independent chains hide each other's latency);
-          * meanwhile stream D encodes the batches of the groups to come (chains + 1 groups in front of the decoder, so that a
+          * meanwhile the first decode stream encodes the batches of the groups to come (chains + 1 groups in front of the decoder, so that a
             chain never waits for its encoder) and decodes -- FRAME BY FRAME, as the tokens arrive: the decoder needs the tokens
             of frame t only for frame t (`QVidModel.decode_frames`), so a running token loop hands every finished frame to a
             `_FrameFeed` (a copy out of its buffer + an event, `GPT.progress`) and the decode of a batch is a generator advanced
@@ -382,7 +382,7 @@ class Generator:
         row's arithmetic does not depend on the rows it shares a launch with and every batch keeps its own sampler words
         (tests/test_pipeline_gpu.py checks bit-equality with the serial schedule).
 
-        `cu_limit` > 0 caps everything on D to that many CUs (`ccvs_stream_cu_limit`) while a token loop is in flight
+        `cu_limit` > 0 caps everything on the decode streams to that many CUs (`ccvs_stream_cu_limit`) while a token loop is in flight
         (default 0).  A token stage is enqueued by a worker thread because a hipGraph launch blocks its caller once the
         stream's queue is a few dozen steps deep, and the decoder's launches must not wait behind that.  Whenever a token
         stage would have to capture its decode step (first use of a chain with a group size, changed weights or sampler),
@@ -391,8 +391,8 @@ class Generator:
         limit (`CCVS_PIPELINE_TIMEOUT`, 600 s) and raises with the stage and batches it was waiting for, after dumping every
         thread's stack: the schedule cannot hang silently.
 
-        batches: iterable of data dicts.  finish(i, out) -> anything: called on stream D when batch i's clip is decoded
-        (pack / all-gather); its return values are collected.  Returns the list of per-batch results
+        batches: iterable of data dicts.  finish(i, out) -> anything: called on the decode stream of batch i when its clip is
+        decoded, in batch order on every rank (pack / all-gather); its return values are collected.  Returns the list of per-batch results
         ({"fake", "enc_code", "finished", "index"}); the rec pass is not run here."""
         import queue
         import threading
