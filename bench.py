@@ -440,7 +440,7 @@ def main():
             # Pipelined schedule: a launch duration in the timed region includes the time the convolution shares the chip with the
             # token loops of other batches -- a figure of the schedule, not of the kernel.  The kernel's roofline is taken from
             # the same launches of one more batch with nothing beside them (HIP events, right after the timed region; these are
-            # also the durations rocprofv3's kernel trace shows, which serialises dispatches across queues); the timed-region
+            # the durations rocprofv3's kernel trace shows for the serial schedule, where nothing runs beside a convolution); the timed-region
             # figure stays in the line as `in_timed_region`.
             shared = None
             if alone:
