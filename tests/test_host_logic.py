@@ -29,14 +29,21 @@ def test_token_windows_match_the_reference_loop(z_len, z_chunk, total):
     assert sum(z_chunk if a is None else a for _, a in want) == total - z_len
 
 
-def test_token_group_size_rules():
-    """Stacked rows fit one weight pass (64) and one decode step (256); host-drawn noise and beam search are never stacked."""
+def test_token_group_size_rules(monkeypatch):
+    """Stacked rows stay within the row cap (128 by default, CCVS_PIPELINE_MAX_ROWS; never more than one decode step's 256); host-drawn
+    noise and beam search are never stacked."""
     from ccvs_amd.helpers.generator import Generator
     g = Generator.__new__(Generator)
     g.opt = types.SimpleNamespace(sample=True, beam_size=None)
     g.transformer_model = types.SimpleNamespace(sample_noise="device")
-    assert g._token_group_size(16, 3) == 3 and g._token_group_size(16, 8) == 4 and g._token_group_size(64, 3) == 1
-    assert g._token_group_size(5, 3) == 3 and g._token_group_size(100, 3) == 1
+    monkeypatch.delenv("CCVS_PIPELINE_MAX_ROWS", raising=False)
+    assert g._token_group_size(16, 3) == 3 and g._token_group_size(16, 4) == 4 and g._token_group_size(16, 12) == 8
+    assert g._token_group_size(64, 3) == 2 and g._token_group_size(5, 3) == 3 and g._token_group_size(100, 3) == 1 and g._token_group_size(200, 3) == 1
+    monkeypatch.setenv("CCVS_PIPELINE_MAX_ROWS", "64")
+    assert g._token_group_size(16, 8) == 4 and g._token_group_size(64, 3) == 1
+    monkeypatch.setenv("CCVS_PIPELINE_MAX_ROWS", "1024")
+    assert g._token_group_size(16, 32) == 16          # one decode step takes 256 rows
+    monkeypatch.delenv("CCVS_PIPELINE_MAX_ROWS")
     g.transformer_model.sample_noise = "host"
     assert g._token_group_size(16, 3) == 1            # one generator stream per batch, in the reference's order
     g.opt.sample = False
