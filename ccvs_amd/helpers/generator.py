@@ -335,6 +335,17 @@ class Generator:
         max_rows = int(os.environ.get("CCVS_PIPELINE_MAX_ROWS", "128"))   # (64 until Kinetics measured 2 x 64 rows x 3 chains: 362 -> 373 frames/s; up to 256)
         return max(1, min(int(lanes), min(max_rows, 256) // max(batch, 1)))
 
+    @staticmethod
+    def _lanes_that_fit(lanes, chains, batch, height, width, total_bytes, frac=0.7, bytes_per_clip_pixel=10.0e3):
+        """Lanes per token group such that the batches in flight -- up to lanes x (chains + 2): two groups in the token loops, one
+        encoded behind them, one being decoded -- fit `frac` of the device memory.  A batch in flight holds its context rings, skip
+        features, token caches and the decoder's intermediates: ~10 KB per clip and pixel measured (BAIR: 174 GB at 16 batches of
+        16 x 256^2 in flight, weights and captured steps included).  BAIR at batch 16 keeps 4 lanes on 288 GB; batch 32 gets 2."""
+        per_batch = float(batch) * height * width * bytes_per_clip_pixel
+        while lanes > 1 and lanes * (chains + 2) * per_batch > frac * total_bytes:
+            lanes -= 1
+        return lanes
+
     def _token_chain(self, k):
         """Token chain k: (Transformer, stream).  A chain runs one token group at a time; chains run beside each other.  Chain 0
         is the model itself, the others are shallow copies that SHARE its parameters (and their packed forms) but own their
@@ -598,6 +609,14 @@ class Generator:
                 return
             held.append(first)
             nb = first["vid"].shape[0]
+            nonlocal lanes
+            fit = self._lanes_that_fit(lanes, chains, nb, first["vid"].shape[-2], first["vid"].shape[-1], torch.cuda.mem_get_info(dev)[1],
+                                       frac=float(os.environ.get("CCVS_PIPELINE_MEM_FRAC", "0.7")))
+            if fit < lanes:
+                print(f"[pipeline] {lanes} -> {fit} batches per token group: {lanes * (chains + 2)} batches of {nb} clips in flight would not fit "
+                      "the device memory (CCVS_PIPELINE_MEM_FRAC)", file=sys.stderr, flush=True)
+                lanes = fit
+                self.last_lanes = lanes
             sizes = sorted({self._token_group_size(nb, g) for g in range(1, lanes + 1)})
             cold = [(c, g) for c in range(chains) for g in sizes if is_cold(c, nb, g)]
             if not cold:

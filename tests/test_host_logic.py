@@ -52,6 +52,18 @@ def test_token_group_size_rules(monkeypatch):
     assert g._token_group_size(16, 3) == 1
 
 
+def test_lanes_that_fit_the_device_memory():
+    """Batches in flight = lanes x (chains + 2); the lanes shrink until they fit 0.7 of the device memory."""
+    from ccvs_amd.helpers.generator import Generator
+    total = 288 * 2 ** 30
+    assert Generator._lanes_that_fit(4, 2, 16, 256, 256, total) == 4          # the benchmark: 16 batches, ~168 GB
+    assert Generator._lanes_that_fit(4, 2, 32, 256, 256, total) == 2          # twice the clips: 8 batches
+    assert Generator._lanes_that_fit(4, 2, 64, 256, 256, total) == 1
+    assert Generator._lanes_that_fit(2, 3, 64, 64, 64, total) == 2            # Kinetics: small frames
+    assert Generator._lanes_that_fit(4, 2, 16, 256, 256, 64 * 2 ** 30) == 1   # a smaller device
+    assert Generator._lanes_that_fit(1, 2, 512, 256, 256, total) == 1         # never below one
+
+
 def test_frames_the_encoder_has_to_see():
     """`--encode_all false`: only the frames the conditioning crop keeps (helpers/generator.py:93-99) -- and only when nothing else
     reads the rest of the clip; the default is the reference's encode of every frame."""
