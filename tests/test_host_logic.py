@@ -112,3 +112,78 @@ def test_reference_launch_line_presets():
     assert p.p2p and p.vid_len == 16 and p.cond_len == 64
     k = Options().parse(load_qvid_generator=True, load_transformer=True, argv=list(KINETICS_ARGV))["transformer"]
     assert k.z_num == 16384 and k.cond_len == 320
+
+
+def test_frame_feed_hands_over_whole_frames(monkeypatch):
+    """`_FrameFeed` (run_pipelined): the token loop reports how many columns of its buffer are final; every frame those complete is
+    copied out once, gets an event, and its flag is set -- partial frames wait, release() wakes whoever waits for the rest."""
+    import torch
+    from ccvs_amd.helpers import generator as G
+
+    class FakeEvent:
+        n = 0
+
+        def record(self):
+            FakeEvent.n += 1
+
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    feed = G._FrameFeed(rows=3, frames=4, frame_tokens=5, device="cpu")
+    live = torch.arange(3 * 20).view(3, 20)                 # the loop's own buffer, final up to column n
+    feed.on_tokens(6, live)                                  # frame 0 complete, one token of frame 1
+    assert [f.is_set() for f in feed.flags] == [True, False, False, False] and feed.sent == 1 and FakeEvent.n == 1
+    assert torch.equal(feed.codes[:, :5], live[:, :5])
+    feed.on_tokens(9, live)                                  # still inside frame 1: nothing happens
+    assert feed.sent == 1 and FakeEvent.n == 1
+    feed.on_tokens(16, live)                                 # frames 1 and 2 at once: one copy, one event for both
+    assert [f.is_set() for f in feed.flags] == [True, True, True, False] and FakeEvent.n == 2
+    assert feed.events[1] is feed.events[2] and feed.events[0] is not feed.events[1]
+    assert torch.equal(feed.codes[:, :15], live[:, :15])
+    feed.on_tokens(400, live)                                # more columns than the clip has frames: capped
+    assert feed.sent == 4 and torch.equal(feed.codes, live)
+    short = G._FrameFeed(rows=1, frames=4, frame_tokens=5, device="cpu")
+    short.on_tokens(5, live[:1])
+    short.release()                                          # a failed stage: the flags wake the waiter, the events say "never came"
+    assert all(f.is_set() for f in short.flags) and short.events[0] is not None and short.events[1:] == [None] * 3
+
+
+def test_decode_frames_asks_for_tokens_frame_by_frame():
+    """`QVidModel.decode_frames` yields, before each piece of work, how many leading frames of tokens it is about to read: first the
+    conditioning frames, then one more per synthesized frame -- and reads exactly those through `code_of`."""
+    import torch
+    from ccvs_amd.models.skip_vid_generator.models.quantized_video_model import QVidModel
+
+    class Stub(QVidModel):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.opt = types.SimpleNamespace(vid_len=5, skip_memory=3, skip_context=[1, 2, 3], skip_mode="enc", z_shape=(2, 2), z_size=4,
+                                             n_first=1, keep_first=False)
+            self.asked = []
+
+        def _embed(self, code, frames):
+            return code.float().view(code.size(0), frames, 1, 2, 2)
+
+        def net_g(self, z, inters, has_ctx=True):
+            return z.sum(dim=(2, 3, 4)).view(z.size(0), z.size(1), 1, 1, 1).expand(-1, -1, 3, 2, 2).clone(), None
+
+        def encode(self, data, layout, dtype, log, suffix, global_iter, quantize=True):
+            return {"inter": [torch.zeros(data.size(0), 1, 2, 2, 2)]}
+
+    m = Stub()
+    code = torch.arange(2 * 5 * 4).view(2, 20)
+    inter = [torch.zeros(2, 2, 2, 2, 2)]                       # two conditioning frames
+
+    def code_of(lo, hi):
+        m.asked.append((lo, hi))
+        return code[:, lo * 4:hi * 4]
+
+    gen = m.decode_frames(code_of, inter, [])
+    needs = []
+    while True:
+        try:
+            needs.append(next(gen))
+        except StopIteration as fin:
+            vid = fin.value
+            break
+    assert needs == [2, 3, 4, 5] and m.asked == [(0, 2), (2, 3), (3, 4), (4, 5)]
+    assert vid.shape == (2, 5, 3, 2, 2)
+    assert torch.equal(vid[:, :, 0, 0, 0], code.float().view(2, 5, 4).sum(-1))
