@@ -44,7 +44,11 @@ def parse_args():
     ap.add_argument("--config", type=str, default="bair", choices=["bair", "kinetics", "bair-p2p", "drums"],
                     help="bair = BASELINE.json configs[1] (the metric); kinetics / bair-p2p / drums = configs[2] / [3] / [4] at their real geometry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sample-noise", type=str, default="device", choices=["device", "host"])
+    ap.add_argument("--sample-noise", type=str, default="host", choices=["device", "host"],
+                    help="host (default): the Exp(1) stream torch.multinomial draws from the process generator under the reference's seed, pre-drawn "
+                         "per batch on a noise thread and read inside the captured decode step -- the sampler every token-for-token oracle test "
+                         "pins; device: in-kernel Philox keyed by the global clip index (reported beside the headline as `sampling_device_noise`)")
+    ap.add_argument("--no-other-noise-leg", action="store_true", help="skip the second timed pass (same K batches) with the other noise source")
     ap.add_argument("--conv-precision", type=str, default=None, choices=["bf16x3", "f32"])
     ap.add_argument("--schedule", type=str, default=os.environ.get("CCVS_BENCH_SCHEDULE", "pipelined"), choices=["serial", "pipelined"],
                     help="serial: batches one after the other; pipelined: token loop of batch i+1 beside the decoder of batch i")
@@ -52,7 +56,7 @@ def parse_args():
     ap.add_argument("--lanes", type=int, default=None, help="pipelined: batches whose token loops run as ONE loop over their stacked rows (a token group)")
     ap.add_argument("--chains", type=int, default=None, help="pipelined: token groups that run beside each other (one stream each)")
     ap.add_argument("--ramp", type=str, default=None, help="pipelined: sizes of the first token groups, e.g. 1,2 (then --lanes)")
-    ap.add_argument("--no-strict-f32", action="store_true", help="skip the exact-fp32-convolution leg reported as strict_f32 (2 serial batches after the timed region)")
+    ap.add_argument("--no-strict-f32", action="store_true", help="skip the exact-fp32-convolution leg reported as strict_f32 (the same K batches on the same schedule)")
     ap.add_argument("--rec-pass", action="store_true", help="also run the reference's teacher-forced reconstruction decode (not counted)")
     ap.add_argument("--encode", choices=["cond", "all"], default="all",
                     help="frames of the input clip the encoder sees: all of them, as the reference's generate_vid does (default; its rec pass reads those "
@@ -346,6 +350,8 @@ def main():
         sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    from ccvs_amd.tools.affinity import pin_rank
+    cpu_set = pin_rank()      # N > 1: this rank's own block of cores (NUMA-local to its GPU when rocm-smi says so), before the first GPU call
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     from ccvs_amd import lib, ops
     from ccvs_amd.tools.engine import Engine
@@ -371,12 +377,19 @@ def main():
         # the same clips on every rank (global clips 0-1 of seed 1): the codebook scale, hence the replica, is identical everywhere
         calibrate_codebook(gen, {"vid": gen.synthetic_batch(2, seed=1, first_clip=0)["vid"].to(dev)})
 
+        kept = {}
+
         def finish(step, fake):
             """uint8 pack on the decode stream, then the RCCL all-gather on a side stream (it overlaps the next batch)."""
+            if step == kept.get("step"):     # the self-check below compares this batch with a serial run of the same inputs
+                kept["fake"] = fake
             return engine.all_gather_clips_async(ops.pack_u8(fake["vid"]))
+
+        NOISE_SEED = 20261004    # host-drawn sampling noise: the process generator is re-seeded in front of every pass, like a fresh reference process
 
         def run(first, batches):
             """K batches from resident inputs to all-gathered uint8 clips; returns the gathered clips of the last one."""
+            torch.manual_seed(NOISE_SEED)
             if args.schedule == "pipelined":
                 ramp = tuple(int(v) for v in args.ramp.split(",") if v) if args.ramp is not None else None
                 res = gen.run_pipelined(iter(batches), first_iter=first, cu_limit=args.cu_limit, finish=finish, lanes=args.lanes, chains=args.chains,
@@ -402,6 +415,7 @@ def main():
             run(-args.warmup, [make_batch(1000 + w) for w in range(args.warmup)])
         batches = [make_batch(i) for i in range(args.steps)]   # inputs resident in HBM before the clock starts
         timer = ops.KernelTimer()
+        kept["step"] = 0
         torch.cuda.synchronize()
         engine.barrier()
         ops.KERNEL_TIMER = timer
@@ -411,6 +425,7 @@ def main():
         engine.barrier()
         elapsed = engine.all_reduce_max(time.perf_counter() - t0)
         ops.KERNEL_TIMER = None
+        kept["step"] = None
         assert clips.shape[0] == args.batch * world
 
         # per-rank stage times (rank order) for the line: which rank, and which stage of it, bounds a multi-GPU run
@@ -420,17 +435,33 @@ def main():
             gathered = [None] * world
             dist.all_gather_object(gathered, rank_stages[0])
             rank_stages = gathered
-        alone = None
+        alone, self_check = None, None
         if engine.is_main and args.schedule == "pipelined":
-            # the same convolution launches with the chip to themselves (one more batch, serial schedule, outside the timed
-            # region): in the pipelined schedule the figure above is measured beside the token loops of other batches
+            # timed batch 0 once more, ALONE on the serial schedule (generate_vid: same inputs, same iteration index, the process
+            # generator re-seeded as in front of the timed pass -- batch 0 is its first consumer in both), outside the timed region:
+            # (1) the self-check of the line -- the clip the pipelined schedule produced for batch 0 beside up to 15 other batches
+            #     in flight must be the serial clip, bit for bit (tokens and fp32 pixels);
+            # (2) the same convolution launches with the chip to themselves: the kernel's roofline (in the pipelined schedule
+            #     the launches are timed beside the token loops of other batches)
             timer_alone = ops.KernelTimer()
             ops.KERNEL_TIMER = timer_alone
-            gen.generate_vid(make_batch(2000), 2000)
+            torch.manual_seed(NOISE_SEED)
+            out_s = gen.generate_vid({k: v.clone() for k, v in batches[0].items()}, 0)
             torch.cuda.synchronize()
             ops.KERNEL_TIMER = None
             n_a, f_a, ms_a = timer_alone.summary("conv2d_" + ops.CONV_PRECISION)
             alone = f_a / (ms_a * 1e-3) / 1e12 if ms_a > 0 else None
+            if "fake" in kept:
+                same_tok = bool(torch.equal(kept["fake"]["code"], out_s["fake"]["code"]))
+                d = (kept["fake"]["vid"] - out_s["fake"]["vid"]).abs().max().item()
+                self_check = {"pipelined_equals_serial": bool(same_tok and d == 0.0), "tokens_equal": same_tok, "max_abs": d,
+                              "what": f"timed batch 0 ({args.batch} clips x {xopt.vid_len} frames, produced with up to {gen.last_lanes * (gen.last_chains + 2)} "
+                                      f"batches in flight: token groups of {gen.last_lanes} x {gen.last_chains} chains, {getattr(gen, 'last_dec_streams', 1)} decode "
+                                      "streams) against generate_vid of the same inputs alone, same noise seed: tokens and fp32 pixels"}
+                if not self_check["pipelined_equals_serial"]:
+                    print(f"bench.py: SELF-CHECK FAILED: {self_check}", file=sys.stderr, flush=True)
+            kept.pop("fake", None)
+            del out_s
         if engine.is_main:
             n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
             frames = predicted * args.batch * world * args.steps
@@ -478,7 +509,10 @@ def main():
                            "encode": (f"all {xopt.vid_len} frames of every input clip, as the reference's generate_vid does (helpers/generator.py:69)" if n_enc == xopt.vid_len
                                       else f"the {n_enc} conditioning frame(s) per clip that synthesis reads (`--encode cond`)"),
                            "rec_pass": ("also run, not counted" if args.rec_pass else "off: the reference's extra teacher-forced reconstruction decode is not part of "
-                                        "the synthesized-frames metric (SURVEY 8d)"), "sampling": f"top-k {xopt.top_k}, T={xopt.temperature}, noise={args.sample_noise}",
+                                        "the synthesized-frames metric (SURVEY 8d)"), "sampling": f"top-k {xopt.top_k}, T={xopt.temperature}, noise={args.sample_noise}" + (
+                               " (the Exp(1) blocks torch.multinomial draws from the process generator, transformer_model.py:395-409: pre-drawn batch after "
+                               "batch by a noise thread, read inside the captured decode step of every token group)" if args.sample_noise == "host" else
+                               " (in-kernel Philox4x32-10 keyed by the global clip index)"),
                            "schedule": (f"pipelined: up to {gen.last_lanes * (gen.last_chains + 2)} batches in flight per GPU -- {gen.last_chains} token loops on "
                                         f"their own streams, each ONE loop over the stacked rows of {gen.last_lanes} consecutive batches (weights streamed "
                                         f"once per token for all of them, per-batch KV rows and sampler words), beside the encoder and {getattr(gen, 'last_dec_streams', 1)} decode streams "
@@ -490,6 +524,7 @@ def main():
                            "parallelism": f"dp{world} (batch sharded, one RCCL all-gather of uint8 clips on a side stream)",
                            "conv_intermediates": ("packed split-bf16 (hi + lo, 4 bytes per element like fp32; bit-identical results) between the convolutions of "
                                                   "Matching / Subpixel" if (ops.CONV_P8 and kind == "bf16x3") else "fp32")},
+                "self_check": self_check,
                 "stage_ms_per_step": {k: v / args.steps for k, v in stage.items() if k != "timeline"},
                 "timeline_ms": stage.get("timeline"),
                 "stage_note": "per-batch stage durations from HIP events on the stage's own stream" +
@@ -566,7 +601,11 @@ def main():
             line["roofline_decode_kernels"] = decode_kernel_rooflines(gen, xopt, args.batch)
             line["multi_gpu"] = {"rccl_ranks": (torch.distributed.get_world_size() if engine.distributed else 1), "backend": engine.backend if engine.distributed else None,
                                  "stage_ms_per_step_by_rank": rank_stages,
-                                 "host_threads_per_rank": {"torch_intra_op": torch.get_num_threads(), "launch_threads": 1 + (gen.last_chains if args.schedule == "pipelined" else 0)},
+                                 "host_threads_per_rank": {"torch_intra_op": torch.get_num_threads(), "launch_threads": 1 + (gen.last_chains if args.schedule == "pipelined" else 0),
+                                                           "noise_thread": int(args.schedule == "pipelined" and args.sample_noise == "host")},
+                                 "cpu_affinity": ({"cores_of_rank_0": cpu_set, "note": "every rank pins itself to its own block of cores before its first GPU call "
+                                                   "(ccvs_amd/tools/affinity.py: NUMA-local to its GPU when `rocm-smi --showtoponuma` parses, else contiguous blocks)"}
+                                                  if cpu_set is not None else "one rank: not pinned"),
                                  "scaling_curve": "not measured by this run: one line per N; the driver derives efficiency from the N = 1, 2, 4, 8 lines (tools/scale_sweep.sh runs them)"}
             if args.encode == "all" and args.config == "bair" and world == 1 and not args.no_encode_cond_leg and not args.rec_pass:
                 # the same K batches and schedule with only the conditioning frame of every clip encoded: synthesis reads nothing else
@@ -587,25 +626,73 @@ def main():
                                                         "the synthesized clips are the same bits (tests/test_features_gpu.py::test_encode_conditioning_frames_only)"}
                 finally:
                     xopt.encode_all = True
-            if args.config == "bair" and world == 1 and not args.conv_precision and not args.no_strict_f32:
-                # the same path with EXACT fp32 convolutions (v_mfma_f32_32x32x2_f32 instead of the split-bf16 products), serial
-                # schedule, outside the timed region: what the arithmetic choice of `dtype` buys, in the driver's own line
-                ops.CONV_PRECISION = "f32"
+            if args.config == "bair" and world == 1 and not args.no_other_noise_leg and args.schedule == "pipelined" and not args.rec_pass:
+                # the same K batches and schedule with the OTHER noise source: reference-seed sampling (host) must cost the schedule nothing
+                other = "device" if args.sample_noise == "host" else "host"
+                trs = [gen.transformer_model] + [tr_ for tr_, _ in gen._chains]
+                for tr_ in trs:
+                    tr_.sample_noise = other
                 try:
-                    gen.generate_vid(make_batch(3000), 3000)
-                    t32 = ops.KernelTimer()
+                    run(6000, [make_batch(6000 + w) for w in range(max(1, min(args.warmup, 3)))])   # untimed (captures the other sampler's step)
                     torch.cuda.synchronize()
-                    ops.KERNEL_TIMER = t32
                     t0 = time.perf_counter()
-                    for i in range(2):
-                        gen.generate_vid(make_batch(3001 + i), 3001 + i)
+                    _, stage_o = run(0, batches)
                     torch.cuda.synchronize()
                     dt = time.perf_counter() - t0
+                    line["sampling_" + other + "_noise"] = {
+                        "value": frames / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / args.steps, "vs_headline": (frames / dt) / line["value"],
+                        "stage_ms_per_step": {k: v / args.steps for k, v in stage_o.items() if k != "timeline"},
+                        "note": f"same {args.steps} batches, same schedule, noise={other}" + (
+                            ": in-kernel Philox keyed by the global clip index (validated distributionally; world-size invariant)" if other == "device" else
+                            ": the reference's seeded torch.multinomial stream, pre-drawn per batch by the noise thread")}
+                finally:
+                    for tr_ in trs:
+                        tr_.sample_noise = args.sample_noise
+            if args.config == "bair" and world == 1 and not args.conv_precision and not args.no_strict_f32:
+                # the same path with EXACT fp32 convolutions (v_mfma_f32_32x32x2_f32 instead of the split-bf16 products): what the
+                # arithmetic choice of `dtype` buys, on the SAME schedule and the same K batches, in the driver's own line; plus the
+                # one B = 16 comparison of the two arithmetics: timed batch 0 decoded by both (GPU vs GPU, teacher-forced on the
+                # headline's tokens so that a VQ near-tie flipped by the encoder's arithmetic cannot hide the pixel difference)
+                torch.manual_seed(NOISE_SEED)
+                ref_out = gen.generate_vid({k: v.clone() for k, v in batches[0].items()}, 0)          # split-bf16, batch 0 (= the self-check's clip)
+                ops.CONV_PRECISION = "f32"
+                try:
+                    t32 = ops.KernelTimer()
+                    ops.KERNEL_TIMER = t32
+                    ws32 = gen.condition({k: v.clone() for k, v in batches[0].items()})
+                    vid32 = gen.decode_codes(ws32, ref_out["fake"]["code"])["vid"]
+                    torch.cuda.synchronize()
                     ops.KERNEL_TIMER = None
                     n32, f32flops, ms32 = t32.summary("conv2d_f32")
                     tf = f32flops / (ms32 * 1e-3) / 1e12 if ms32 > 0 else 0.0
-                    line["strict_f32"] = {"frames_per_s": predicted * args.batch * 2 / dt, "schedule": "serial, 2 batches after one untimed", "conv_tflops": tf,
-                                          "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS, "conv_launches": n32}
+                    line["dtype_check"] = {
+                        "max_abs_pixel_diff": (vid32 - ref_out["fake"]["vid"]).abs().max().item(), "bound": 1e-3,
+                        "vq_codes_equal": bool(torch.equal(ws32["encoded"]["code"], ref_out["enc_code"])),
+                        "what": f"timed batch 0, {args.batch} clips x {xopt.vid_len} frames at 256x256: split-bf16 x3 convolutions (the headline) against exact "
+                                "fp32 convolutions, both on the GPU, both decoding the headline's sampled tokens through the 15-frame recurrence "
+                                "(every synthesized frame re-encoded into the context ring); north_star's bound is 1e-3 against the fp32 CPU path"}
+                    del ws32, vid32, ref_out
+                    if args.schedule == "pipelined":
+                        run(3000, [make_batch(3000 + w) for w in range(max(1, min(args.warmup, 2)))])   # untimed: fp32 weight forms packed
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        _, stage32 = run(0, batches)
+                        torch.cuda.synchronize()
+                        dt = time.perf_counter() - t0
+                        n_b, sched = args.steps, f"pipelined, the same {args.steps} batches and schedule as the headline"
+                    else:
+                        torch.manual_seed(NOISE_SEED)
+                        t0 = time.perf_counter()
+                        for i in range(2):
+                            gen.generate_vid({k: v.clone() for k, v in batches[i % len(batches)].items()}, i)
+                        torch.cuda.synchronize()
+                        dt = time.perf_counter() - t0
+                        n_b, sched, stage32 = 2, "serial, 2 batches", None
+                    line["strict_f32"] = {"frames_per_s": predicted * args.batch * n_b / dt, "vs_headline": (predicted * args.batch * n_b / dt) / line["value"],
+                                          "schedule": sched, "ms_per_step": 1e3 * dt / n_b,
+                                          "stage_ms_per_step": ({k: v / n_b for k, v in stage32.items() if k != "timeline"} if stage32 else None),
+                                          "conv_tflops": tf, "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS, "conv_launches": n32,
+                                          "conv_measured": "HIP events around every convolution launch of one batch (encode + 15-frame decode) with nothing beside it"}
                 finally:
                     ops.CONV_PRECISION = kind
                     ops.KERNEL_TIMER = None

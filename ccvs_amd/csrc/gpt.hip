@@ -1034,6 +1034,7 @@ struct Advance {       // decode-step bookkeeping folded into the sampling kerne
     unsigned imm[5];   // rng == 2: immediate Philox words (key0, key1, global row of row 0, step, call) instead of `state`
     int* state;        // int32[8]: [0] completed steps, [2] arrival ticket of this kernel's rows, [3] call index, [4..5] Philox key, [6] global index of row 0
     int grp_rows;      // > 0: rows [g * grp_rows, (g+1) * grp_rows) form group g with its own widx[g], len[g] and state[8g .. 8g+7]
+    const float* const* noise_stream;   // host-drawn noise as a whole stream: entry g -> [steps][rows of group g][V]; the block read is state[0] of the group
 };
 
 // k-th largest key of xs[0..V) by a 4-pass radix-256 descent (LDS histogram + suffix scan per pass).
@@ -1120,11 +1121,15 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
         k0 = (unsigned)adv.state[4]; k1 = (unsigned)adv.state[5]; step = (unsigned)adv.state[0];
         call = (unsigned)adv.state[3]; row0 = (unsigned)adv.state[6];
     }
+    // host-drawn noise: the [B, V] block of an eager pick, or this row's slice of block `state[0]` (the steps its group has
+    // completed) of the group's pre-drawn stream -- the captured step then consumes the reference's generator stream in order
+    const float* nrow = noise ? noise + (long)b * V : nullptr;
+    if (adv.noise_stream) nrow = adv.noise_stream[grp] + ((long)adv.state[0] * nrows + brow) * V;
     float best = -1.f;
     int bi = 0x7fffffff;
     for (int j = tid; j < V; j += 256) {
         float p = xs[j] / tot;
-        if (noise) p = p / noise[(long)b * V + j];
+        if (nrow) p = p / nrow[j];
         else if (adv.rng) {
             const float u = ((float)philox_first((unsigned)j, row0 + (unsigned)brow, step, call, k0, k1) + 0.5f) * 2.3283064365386963e-10f;  // (0, 1]
             p = p / fmaxf(-logf(u), 1e-30f);
@@ -1372,7 +1377,8 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream) {
     {   // pick + bookkeeping
         Advance adv = {};
         adv.codes = d->codes; adv.codes_sB = (long)d->codes_sB; adv.widx = d->widx; adv.len = d->len;
-        adv.rng = (d->rng && !d->noise) ? 1 : 0; adv.state = d->state; adv.grp_rows = grp_rows;
+        adv.rng = (d->rng && !d->noise && !d->noise_stream) ? 1 : 0; adv.state = d->state; adv.grp_rows = grp_rows;
+        adv.noise_stream = d->noise ? nullptr : d->noise_stream;
         hipLaunchKernelGGL(sample_topk_kernel, dim3(d->B), dim3(256), smem_pick, st, d->logits, (long)d->V, d->noise, d->tok, 1L, d->V,
                            d->top_k, d->temperature, adv);
         CCVS_CHECK_LAUNCH("ccvs_gpt_decode_step(pick)");

@@ -62,6 +62,7 @@ class GptDecode(C.Structure):
         ("x", C.c_void_p), ("q", C.c_void_p), ("att", C.c_void_p), ("h", C.c_void_p), ("logits", C.c_void_p),
         ("noise", C.c_void_p), ("rng", C.c_int32), ("top_k", C.c_int32), ("temperature", C.c_float),
         ("workspace", C.c_void_p), ("state", C.c_void_p), ("groups", C.c_int32),
+        ("noise_stream", C.c_void_p),
     ]
 
 

@@ -162,6 +162,10 @@ class GPT(nn.Module):
         # progress(n, codes): called on the stream of a graph-replayed generate() whenever columns [0, n) of `codes` (the cache's
         # token buffer) are final -- `Generator.run_pipelined` hands the finished frames to the decoder while the loop goes on
         self.progress = None
+        # host-drawn sampling noise of the NEXT generate() call, pre-drawn: one device tensor [add_len, rows of the group, V] per row
+        # group, block i = the [rows, V] Exp(1) draw of pick i in the order of the reference's generator (`Generator.run_pipelined`
+        # draws them on a noise thread, batch after batch).  None: generate() draws its own through `host_noise` (one group only).
+        self.noise_streams = None
 
     @property
     def _graphs(self):
@@ -357,6 +361,8 @@ class GPT(nn.Module):
                 "x": torch.empty(batch, C, **f32), "q": torch.empty(batch, C, **f32), "att": torch.empty(batch, C, **f32),
                 "h": torch.empty(batch, 4 * C, **f32), "logits": torch.empty(batch, V, **f32), "noise": torch.empty(batch, V, **f32),
                 "state": torch.zeros(groups, 8, dtype=torch.int32, device=dev),    # per group: [0] steps done, [4..5] Philox key (ccvs_hip.h)
+                "noise_ptrs": torch.zeros(groups, dtype=torch.int64, device=dev),  # per group: its pre-drawn noise stream (ccvs_gpt_decode.noise_stream)
+                "noise_keep": None,
                 "desc": None, "graphs": {},
             }
         self._cache = c
@@ -500,8 +506,9 @@ class GPT(nn.Module):
         folded = [blk.folded() for blk in self.blocks]
         head_key, (hw, hb, hs) = self._head_packed()
         device_rng = sampler["sample"] and sampler["noise"] == "device"
+        host_stream = bool(sampler["sample"] and not device_rng and sampler.get("stream"))   # host noise read from a pre-drawn stream
         key = (tuple(blk._folded[0] for blk in self.blocks), head_key, sampler["sample"], sampler["top_k"],
-               sampler["temperature"], device_rng, c["frame_pos0"])
+               sampler["temperature"], device_rng, host_stream, c["frame_pos0"])
         if c["desc"] is None or c["desc"][0] != key:
             layers = []
             for i, blk in enumerate(self.blocks):
@@ -514,7 +521,8 @@ class GPT(nn.Module):
                 tok_emb=self._token_table(), pos_table=c["pos_table"], pos_off=-c["frame_pos0"], head=(hw, hb, hs),
                 tok=c["tok"], codes=c["codes"], widx=c["widx"], length=c["len_dev"],
                 x=c["x"], q=c["q"], att=c["att"], h=c["h"], logits=c["logits"],
-                noise=c["noise"] if (sampler["sample"] and not device_rng) else None, rng=device_rng,
+                noise=c["noise"] if (sampler["sample"] and not device_rng and not host_stream) else None, rng=device_rng,
+                noise_stream=c["noise_ptrs"] if host_stream else None,
                 top_k=sampler["top_k"], temperature=sampler["temperature"], state=c["state"])
             c["desc"] = (key, desc)
             c["graphs"] = {}   # captured graphs replay the OLD descriptor's pointers (packed weights are freed with it)
@@ -534,8 +542,8 @@ class GPT(nn.Module):
         next token, advance the counters -- one `ccvs_gpt_decode_step` call (include/ccvs_hip.h)."""
         c = self._cache
         desc = self._decode_desc(sampler)
-        if sampler["sample"] and sampler["noise"] != "device":
-            c["noise"].copy_(noise, non_blocking=True)   # host-drawn Exp(1) noise (reference-reproducible stream)
+        if sampler["sample"] and sampler["noise"] != "device" and not sampler.get("stream"):
+            c["noise"].copy_(noise, non_blocking=True)   # host-drawn Exp(1) noise (reference-reproducible stream), one block per eager step
         desc.launch()
         if trace is not None:
             trace.append(c["logits"].clone())
@@ -751,9 +759,11 @@ class GPT(nn.Module):
         With an ancillary stream (`state_code` [B,ns], `state_sampler` = dict(sample, top_k, temperature, vocab)) the
         add_len new tokens are split between the two streams as the reference does and (code, state_code) is returned.
 
-        With device (or no) noise and no trace the decode step is captured ONCE in a hipGraph and
-        replayed.  With host-supplied noise (`host_noise(b, v) -> [B,V]`, reference-reproducible) the same
-        step runs eagerly."""
+        Without a trace the decode step is captured ONCE in a hipGraph and replayed, whatever the sampler: greedy, in-kernel
+        Philox noise, or host-supplied noise (`host_noise(b, v) -> [B,V]` Exp(1) blocks, the reference-reproducible stream) -- the
+        call's whole noise stream is then drawn up front, in the reference's order, and the captured step reads block after block
+        of it (`ccvs_gpt_decode.noise_stream`); `noise_streams` (set by the caller) supplies pre-drawn streams instead, one per row
+        group.  With a trace, `use_graph=False` or fewer than three new tokens the same step runs eagerly."""
         b, t0 = code.shape
         use_cond = cond_idx is not None and 0 not in cond_idx.size()
         n_cond = cond_idx.shape[1] if use_cond else 0
@@ -764,7 +774,17 @@ class GPT(nn.Module):
                 raise NotImplementedError("label / start tokens together with an ancillary token stream")
             return self._generate_stream(code, state_code, add_len, cond_idx if use_cond else None,
                                          delta_length_cond if use_cond else None, sampler, state_sampler, host_noise, trace, use_graph)
-        eager = trace is not None or (sample and noise != "device") or not use_graph or add_len < 3
+        eager = trace is not None or not use_graph or add_len < 3
+        host = bool(sample) and noise != "device"
+        if host and eager and self.noise_streams is not None:   # pre-drawn streams, eager steps: block i of every group for pick i
+            streams, self.noise_streams = self.noise_streams, None
+            blocks = iter(range(add_len))
+
+            def host_noise(nb, nv):
+                i = next(blocks)
+                return streams[0][i] if len(streams) == 1 else torch.cat([s_[i] for s_ in streams], dim=0)
+        # host-drawn noise inside the captured step: the call's whole noise stream is on the device before the first replay
+        sampler["stream"] = host and not eager
         max_len = n_pre + n_cond + t0 + add_len
         c = self.begin(b, max_len)
 
@@ -775,9 +795,11 @@ class GPT(nn.Module):
             trace.append(logits.clone())
         c["codes"][:, :t0] = code
         c["len_dev"].fill_(n_pre + n_cond + t0)
-        self._set_decode_state(words)     # the step counter (a Philox counter word) restarts with the call
+        self._set_decode_state(words)     # the step counter (a Philox counter word / the block index of a noise stream) restarts with the call
         if device_rng:                    # first pick: step word 0xffffffff (the decode steps count 0, 1, ...)
             self._emit(logits, sampler, None, t0, words=words, step=(0xffffffff, 0))
+        elif sampler["stream"]:           # block 0 of every group's stream; the decode steps read blocks 1, 2, ... (pointer table)
+            self._emit(logits, sampler, self._stage_noise_streams(b, add_len, logits.shape[1], host_noise), t0)
         else:
             self._emit(logits, sampler, host_noise(b, logits.shape[1]).to(logits.device, non_blocking=True) if sample else None, t0)
 
@@ -788,11 +810,39 @@ class GPT(nn.Module):
         else:
             for _ in range(add_len - 1):
                 nz = None
-                if sample and noise != "device":
+                if host:
                     nz = host_noise(b, self.head.weight.shape[0]).to(code.device, non_blocking=True)
                 self._decode_body(sampler, noise=nz, trace=trace)
         c["len"] = n_pre + n_cond + t0 + add_len - 1
         return c["codes"][:, :t0 + add_len].clone()
+
+    def _stage_noise_streams(self, b, add_len, v, host_noise):
+        """The host-drawn noise of a graph-replayed generate() call: the stream of every row group ([add_len, rows, V] Exp(1)
+        blocks in the reference generator's order -- `noise_streams` set by the caller, else drawn here, one group only) is made
+        resident, the cache's pointer table is set to block 1 of each (the captured steps read block `steps completed`), and the
+        [B, V] block of the first pick is returned.  A warm-only call (graph capture) consumes nothing of the generator."""
+        c = self._cache
+        dev = c["noise_ptrs"].device
+        groups = c["G"]
+        rows = b // groups
+        streams, self.noise_streams = self.noise_streams, None
+        if self.warm_only:
+            streams = [torch.ones(2, rows, v, dtype=torch.float32, device=dev)] * groups
+        elif streams is None:
+            assert groups == 1, "host-drawn sampling noise of stacked batches is pre-drawn per batch (GPT.noise_streams)"
+            buf = torch.empty(add_len, b, v, dtype=torch.float32, pin_memory=True)
+            for i in range(add_len):      # one [B, V] block per pick, exactly the draws torch.multinomial makes
+                buf[i].copy_(host_noise(b, v))
+            streams = [buf.to(dev, non_blocking=True)]
+        assert len(streams) == groups, (len(streams), groups)
+        cur = torch.cuda.current_stream()
+        for s_ in streams:
+            assert s_.is_cuda and s_.dtype == torch.float32 and s_.is_contiguous() and tuple(s_.shape[1:]) == (rows, v) and s_.shape[0] >= min(add_len, 2), s_.shape
+            s_.record_stream(cur)
+        ptrs = torch.tensor([s_.data_ptr() + 4 * rows * v for s_ in streams], dtype=torch.int64)
+        c["noise_ptrs"].copy_(ptrs, non_blocking=True)
+        c["noise_keep"] = streams         # alive until the next call replaces them (stream-ordered behind this call's replays)
+        return streams[0][0] if groups == 1 else torch.cat([s_[0] for s_ in streams], dim=0)
 
     # ------------------------------------------------------------------ reference-shaped forward
     @torch.no_grad()

@@ -15,7 +15,7 @@ Training modes, layout decoders and continuous codes are outside the hot path an
 """
 import torch
 
-from .skip_autoencoder import SkipGANDecoder, SkipGANEncoder
+from .skip_autoencoder import SkipGANDecoder, SkipGANEncoder, prepare_packed_modules
 from ..modules.quantize import VectorQuantizer
 from ccvs_amd.tools.utils import to_cuda
 from ccvs_amd.models import load_network, print_network
@@ -83,6 +83,15 @@ class QVidModel(torch.nn.Module):
             self.net_e = load_network(self.net_e, "qvid_e" + sfx, opt)
             self.net_q = load_network(self.net_q, "qvid_q" + sfx, opt, required=load_ema)
 
+    @torch.no_grad()
+    def prepare_packed(self):
+        """Build, on the current stream, every kernel-ready weight form the networks cache lazily on first use (packed
+        convolution weights of the chosen precision, fused heads, split Subpixel weights, the quantiser's transposed codebook).
+        A caller that is about to use the model from SEVERAL streams (`Generator.run_pipelined`: the decode of batch i on decode
+        stream i % D) calls this once and orders those streams behind it: the caches are plain Python attributes, nothing else
+        orders a pack kernel on one stream before a reader on another.  Cheap when everything is already packed."""
+        prepare_packed_modules(self)
+
     # ------------------------------------------------------------------ encode
     @torch.no_grad()
     def encode(self, data, layout, dtype, log, suffix, global_iter, quantize=True):
@@ -122,14 +131,19 @@ class QVidModel(torch.nn.Module):
             except StopIteration as fin:
                 return {dtype: fin.value, "layout": None}
 
-    def decode_stream(self, data, code_of):
+    def decode_stream(self, data, code_of, frames=None):
         """`forward(mode='vid_decoder')` for a clip whose tokens arrive frame by frame (the token loop is still running): a generator
         that yields, before each piece of work, how many frames of tokens that piece needs (`decode_frames`) and returns the decoder's
-        dict.  `data` as for the decoder, without "code"; `code_of(lo, hi)` -> the tokens [B, (hi - lo) * h * w] of frames lo .. hi - 1."""
+        dict.  `data` as for the decoder, without "code"; `code_of(lo, hi)` -> the tokens [B, (hi - lo) * h * w] of frames lo .. hi - 1.
+        Without the flow-guided frame loop (no `--q_use_inter`, or every frame given) the clip is ONE decoder call, as in `decode`
+        (quantized_video_model.py:849-853): one piece that needs all `frames` frames of tokens."""
         opt = self.opt
         _, _, _, _, inter, _, cond_inter = self.preprocess_input(data)
         if not (opt.use_inter and opt.dec_model == "skipgan" and inter[0].size(1) < opt.vid_len):
-            raise NotImplementedError("decode_stream: the flow-guided video decode only")
+            frames = int(frames if frames is not None else opt.vid_len)
+            yield frames
+            fake, _ = self.net_g(self._embed(code_of(0, frames), frames), [inter])
+            return {"vid": fake, "layout": None}
         vid = yield from self.decode_frames(code_of, inter, cond_inter)
         return {"vid": vid, "layout": None}
 

@@ -217,13 +217,17 @@ class _FusedHeads:
         self.fh, self.oh = flow_head.conv, occ_head.conv
         self._cache = None
 
-    def __call__(self, feat, out, accumulate):
+    def packed(self):
         fw, ow = self.fh.weight, self.oh.weight
         key = (fw.data_ptr(), fw._version, ow.data_ptr(), ow._version, fw.device, ops.CONV_PRECISION)
         if self._cache is None or self._cache[0] != key:
             b = torch.cat([self.fh.bias.detach(), self.oh.bias.detach()], dim=0).contiguous()
             self._cache = (key, ops.pack_head_weights(fw, ow), b)
-        return ops.conv_heads(feat, self._cache[1], self._cache[2], out, accumulate)
+        return self._cache[1], self._cache[2]
+
+    def __call__(self, feat, out, accumulate):
+        w, b = self.packed()
+        return ops.conv_heads(feat, w, b, out, accumulate)
 
 
 class InterBlock(nn.Module):
@@ -241,6 +245,17 @@ class InterBlock(nn.Module):
         self._m_heads = _FusedHeads(self.matching.flow_head, self.matching.occ_head)
         self._s_heads = _FusedHeads(self.subpixel.flow_head, self.subpixel.occ_head)
         self._up_w = None
+
+    def prepare_packed(self):
+        """Build every kernel-ready weight form this block caches lazily (the fused heads, the projection of the fused warp, the
+        split first Subpixel convolution, the stacked flow / occlusion up-sampling filter), on the current stream."""
+        self._m_heads.packed()
+        self._s_heads.packed()
+        if self.matching.proj is not None and ops.FUSE_WARP_PROJ:
+            self._proj_weight()
+        if self.matching.upsample_flow is not None:
+            self._upsample_fo_weight()
+        self._sub0_split()
 
     def _upsample_fo_weight(self):
         m = self.matching
@@ -326,13 +341,13 @@ class InterBlock(nn.Module):
         with the FULL fan-in scale 1/sqrt((2s+3)*9) of the unsplit layer."""
         conv = self.subpixel.convs[0].conv
         w = conv.weight
-        key = (w.data_ptr(), w._version, w.device, ops.CONV_PRECISION)
+        key = (w.data_ptr(), w._version, w.device, ops.CONV_PRECISION, ops.P8_WARP)
         if getattr(self, "_sub0", None) is None or self._sub0[0] != key:
             s = self.feat_size
-            # (third form: the same block with five zero channels behind [warped | flow | occ]: s + 8 channels, the packed back-warp's)
-            w8 = torch.cat([w[:, s:].detach(), w.new_zeros(w.shape[0], 5, w.shape[2], w.shape[3])], dim=1)
-            self._sub0 = (key, ops.pack_conv_weight(w[:, :s], scale=conv.scale), ops.pack_conv_weight(w[:, s:], scale=conv.scale),
-                          ops.pack_conv_weight(w8, scale=conv.scale))
+            w8 = None
+            if ops.P8_WARP:   # third form, only for the packed back-warp (off by default): the same block with five zero channels behind [warped | flow | occ]
+                w8 = ops.pack_conv_weight(torch.cat([w[:, s:].detach(), w.new_zeros(w.shape[0], 5, w.shape[2], w.shape[3])], dim=1), scale=conv.scale)
+            self._sub0 = (key, ops.pack_conv_weight(w[:, :s], scale=conv.scale), ops.pack_conv_weight(w[:, s:], scale=conv.scale), w8)
         return self._sub0[1], self._sub0[2], self._sub0[3]
 
     def forward(self, input, inters, flows=None, occs=None, toffs=None, eps=1e-6):
@@ -451,6 +466,20 @@ class SkipGANDecoder(nn.Module):
         if return_all:
             return out1, out2, inter_flows, inter_occs, [unflatten_vid(f, vid_size) for f in inter_dec]
         return out1, out2
+
+
+def prepare_packed_modules(root):
+    """Fill the lazily built weight caches of every sub-module of `root` on the current stream: `packed()` of the convolutions /
+    linears, `prepare_packed()` of the InterBlocks, the transposed codebook of a VectorQuantizer (`QVidModel.prepare_packed`)."""
+    for mod in root.modules():
+        if mod is root:
+            continue
+        if hasattr(mod, "prepare_packed"):
+            mod.prepare_packed()
+        elif hasattr(mod, "packed"):
+            mod.packed()
+        elif hasattr(mod, "_tables"):
+            mod._tables()
 
 
 class EqualLinear(nn.Module):

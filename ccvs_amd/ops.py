@@ -608,9 +608,9 @@ class GptDecodeStep:
     `launch()` enqueues one whole decode step on the current stream."""
 
     def __init__(self, layers, B, C, H, Tmax, ln_eps, tok_emb, pos_table, pos_off, head, tok, codes, widx, length,
-                 x, q, att, h, logits, noise, top_k, temperature, state, rng=False, groups=1):
+                 x, q, att, h, logits, noise, top_k, temperature, state, rng=False, groups=1, noise_stream=None):
         hw, hb, hs = head
-        keep = [tok_emb, pos_table, hw, hb, hs, tok, codes, widx, length, x, q, att, h, logits, noise, state]
+        keep = [tok_emb, pos_table, hw, hb, hs, tok, codes, widx, length, x, q, att, h, logits, noise, state, noise_stream]
         for t in keep:
             if t is not None:
                 _need_gpu(t)
@@ -620,6 +620,8 @@ class GptDecodeStep:
         assert widx.dtype == torch.int32 and length.dtype == torch.int32 and state.dtype == torch.int32
         assert groups >= 1 and B % groups == 0 and widx.numel() == groups and length.numel() == groups and state.numel() == 8 * groups
         assert widx.is_contiguous() and length.is_contiguous() and state.is_contiguous()
+        if noise_stream is not None:   # device table of `groups` device pointers (ccvs_gpt_decode.noise_stream)
+            assert noise is None and noise_stream.dtype == torch.int64 and noise_stream.numel() == groups and noise_stream.is_contiguous()
         arr = (_lib.GptLayer * len(layers))()
         for i, lay in enumerate(layers):
             for name, t in lay.items():
@@ -641,7 +643,8 @@ class GptDecodeStep:
         d.widx, d.len = _p(widx), _p(length)
         d.x, d.q, d.att, d.h, d.logits = _p(x), _p(q), _p(att), _p(h), _p(logits)
         d.noise = _p(noise)
-        d.rng = 1 if (rng and noise is None) else 0
+        d.rng = 1 if (rng and noise is None and noise_stream is None) else 0
+        d.noise_stream = _p(noise_stream)
         d.top_k, d.temperature = 0 if top_k is None else int(top_k), float(temperature)
         d.workspace, d.state = _p(self.ws), _p(state)
         d.groups = groups

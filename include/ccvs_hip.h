@@ -317,6 +317,13 @@ typedef struct ccvs_gpt_decode {
      * to be picked advances that group's words.  A row's arithmetic does not depend on the rows it shares a step with:
      * the result is bit-identical to `groups` separate steps (tests/test_pipeline_gpu.py).  B <= 256. */
     int32_t groups;
+    /* Host-drawn sampling noise as a whole STREAM (ABI 5; NULL = none; used when `noise` is NULL, overrides `rng`): a DEVICE array of
+     * max(groups, 1) device pointers; entry g -> float [steps][B / groups][V], the Exp(1) blocks torch.multinomial would draw for
+     * group g's batch (transformer_model.py:395-409: one [rows, V] block per pick, in the order of the process generator).  The
+     * step reads block state[g][0] -- the steps that group has completed -- so a captured step replays through the stream and
+     * the host only rewrites the pointer table (stream-ordered) when a new sequence starts: reference-seed sampling inside
+     * hipGraph replays and inside row groups. */
+    const float* const* noise_stream;
 } ccvs_gpt_decode;
 int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream);
 

@@ -15,8 +15,20 @@ from tests.test_capi_host import TINY_ARGV  # noqa: E402
 
 
 def main():
+    # per-rank CPU placement, before anything else (bench.py does the same before its first GPU call): disjoint equal blocks
+    from ccvs_amd.tools.affinity import pin_rank
+    allowed = sorted(os.sched_getaffinity(0))
+    cores = pin_rank(numa=False)
     with Engine(backend="gloo") as eng:
         assert eng.distributed and eng.world_size == 2
+        import torch.distributed as dist
+        assert cores is not None and set(cores) == os.sched_getaffinity(0)
+        both = [None, None]
+        dist.all_gather_object(both, cores)
+        if len(allowed) >= 2:
+            per = len(allowed) // 2
+            assert both[0] == allowed[:per] and both[1] == allowed[per:2 * per], (both, allowed)
+            assert not set(both[0]) & set(both[1])
         gen = Generator(Options().parse(True, True, argv=TINY_ARGV))
         gen.engine = eng
         lo, hi = eng.shard_batch(4)

@@ -30,11 +30,13 @@ def test_token_windows_match_the_reference_loop(z_len, z_chunk, total):
 
 
 def test_token_group_size_rules(monkeypatch):
-    """Stacked rows stay within the row cap (128 by default, CCVS_PIPELINE_MAX_ROWS; never more than one decode step's 256); host-drawn
-    noise and beam search are never stacked."""
+    """Stacked rows stay within the row cap (128 by default, CCVS_PIPELINE_MAX_ROWS; never more than one decode step's 256); beam
+    search is never stacked; host-drawn noise is stacked when a batch's draws are one plain stream of [B, V] blocks (no ancillary
+    token stream, no sliding window): each batch of the group then reads its own pre-drawn stream."""
     from ccvs_amd.helpers.generator import Generator
     g = Generator.__new__(Generator)
-    g.opt = types.SimpleNamespace(sample=True, beam_size=None)
+    g.opt = types.SimpleNamespace(sample=True, beam_size=None, state=False, stft=False, vid_len=16, z_len=1024)
+    g.qvid_opt = types.SimpleNamespace(z_shape=[8, 8])
     g.transformer_model = types.SimpleNamespace(sample_noise="device")
     monkeypatch.delenv("CCVS_PIPELINE_MAX_ROWS", raising=False)
     assert g._token_group_size(16, 3) == 3 and g._token_group_size(16, 4) == 4 and g._token_group_size(16, 12) == 8
@@ -45,7 +47,14 @@ def test_token_group_size_rules(monkeypatch):
     assert g._token_group_size(16, 32) == 16          # one decode step takes 256 rows
     monkeypatch.delenv("CCVS_PIPELINE_MAX_ROWS")
     g.transformer_model.sample_noise = "host"
-    assert g._token_group_size(16, 3) == 1            # one generator stream per batch, in the reference's order
+    assert g._host_noise_streams_ok() and g._token_group_size(16, 3) == 3   # one pre-drawn generator stream per batch, in the reference's order
+    g.opt.vid_len = 45                                # the token window slides (Drums): several fill_code calls per batch
+    assert not g._host_noise_streams_ok() and g._token_group_size(16, 3) == 1
+    g.opt.vid_len, g.opt.stft = 16, True              # ancillary picks draw blocks of another width
+    assert not g._host_noise_streams_ok() and g._token_group_size(16, 3) == 1
+    g.opt.stft, g.opt.use_graph = False, False        # eager steps draw for themselves
+    assert g._token_group_size(16, 3) == 1
+    g.opt.use_graph = True
     g.opt.sample = False
     assert g._token_group_size(16, 3) == 3            # greedy: nothing is drawn
     g.opt.beam_size = 4
@@ -62,6 +71,9 @@ def test_lanes_that_fit_the_device_memory():
     assert Generator._lanes_that_fit(2, 3, 64, 64, 64, total) == 2            # Kinetics: small frames
     assert Generator._lanes_that_fit(4, 2, 16, 256, 256, 64 * 2 ** 30) == 1   # a smaller device
     assert Generator._lanes_that_fit(1, 2, 512, 256, 256, total) == 1         # never below one
+    assert Generator._lanes_that_fit(4, 2, 16, 256, 256, total, taken=60 * 2 ** 30) == 3   # another process holds 60 GB of the device
+    assert Generator._lanes_that_fit(4, 2, 16, 256, 256, total, dec_streams=4) == 4 and Generator._lanes_that_fit(4, 2, 16, 256, 256, 235 * 2 ** 30, dec_streams=6) == 3
+    assert Generator._lanes_that_fit(4, 2, 16, 256, 256, 235 * 2 ** 30, dec_streams=2) == 4
 
 
 def test_frames_the_encoder_has_to_see():
@@ -187,3 +199,24 @@ def test_decode_frames_asks_for_tokens_frame_by_frame():
     assert needs == [2, 3, 4, 5] and m.asked == [(0, 2), (2, 3), (3, 4), (4, 5)]
     assert vid.shape == (2, 5, 3, 2, 2)
     assert torch.equal(vid[:, :, 0, 0, 0], code.float().view(2, 5, 4).sum(-1))
+
+
+def test_rank_cpu_sets():
+    """Per-rank core blocks (ccvs_amd/tools/affinity.py): contiguous equal blocks of the allowed cores; NUMA-local blocks when the
+    GPU -> node map is known (the ranks of a node split that node's cores); never empty."""
+    from ccvs_amd.tools import affinity as A
+    assert A._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    allowed = list(range(16))
+    assert [A.rank_cpu_set(r, 4, allowed) for r in range(4)] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]]
+    assert A.rank_cpu_set(0, 1, allowed) == allowed
+    assert A.rank_cpu_set(5, 8, [0, 1, 2]) == [2]                       # fewer cores than ranks: shared round-robin
+    text = "GPU[0]\t\t: (Topology) Numa Node: 0\nGPU[0]\t\t: (Topology) Numa Affinity: 0\nGPU[1]\t\t: (Topology) Numa Node: 0\n" \
+           "GPU[2]\t\t: (Topology) Numa Node: 1\nGPU[3]\t\t: (Topology) Numa Node: 1\n"
+    gpu_node = A.parse_showtoponuma(text)
+    assert gpu_node == {0: 0, 1: 0, 2: 1, 3: 1}
+    node_cpus = {0: list(range(0, 8)) + list(range(16, 24)), 1: list(range(8, 16)) + list(range(24, 32))}
+    sets = [A.rank_cpu_set(r, 4, list(range(32)), gpu_node, node_cpus) for r in range(4)]
+    assert sets[0] == [0, 1, 2, 3, 4, 5, 6, 7] and sets[1] == [16, 17, 18, 19, 20, 21, 22, 23]
+    assert sets[2] == [8, 9, 10, 11, 12, 13, 14, 15] and sets[3] == [24, 25, 26, 27, 28, 29, 30, 31]
+    assert A.rank_cpu_set(2, 4, list(range(32)), {0: 0, 1: 0}, node_cpus) == list(range(16, 24))   # incomplete map: contiguous blocks
+    assert A.parse_showtoponuma("garbage") == {}

@@ -270,3 +270,69 @@ def test_full_size_gpt_p2p_prefix_and_decode_steps_vs_oracle(big_gpt):
     for t in range(93, 96):
         lg = net.step(idx[:, t:t + 1].cuda())
         assert maxdiff(lg, want[:, t]) < 2e-4, t
+
+
+@slow
+def test_bair_batch16_free_running_host_noise_audit_vs_oracle():
+    """The BENCHED configuration against the oracle: BAIR geometry, batch 16, sampled (top-k 100), host-drawn noise -- the
+    reference's seeded torch.multinomial stream -- on the default schedule (token groups of 4 batches x 2 chains beside two decode
+    streams), 8 batches free-running.  For 9 sampled (batch, clip, position) triples at T in {64, 512, 1023} -- the first pick of
+    a clip (eager, block 0 of its noise stream), a mid pick and the last (graph replays reading blocks 448 and 959) -- the
+    oracle's `gpt_forward` runs on the HIP-generated prefix: its logits agree with the HIP path's teacher-forced logits within
+    2e-4, and the token the HIP loop picked at T is the oracle's `get_icode` pick from those logits on the SAME noise row
+    (torch.multinomial = argmax(probs / Exp(1) block), checked against torch.multinomial itself below)."""
+    from ccvs_amd.tools.options import Options, BAIR_ARGV
+    from ccvs_amd.helpers.generator import Generator
+    opt = Options().parse(load_qvid_generator=True, load_transformer=True,
+                          argv=list(BAIR_ARGV) + ["--batch_size_vid", "16", "--x_sample_noise", "host", "--rec_pass", "false"])
+    xopt = opt["transformer"]
+    torch.manual_seed(0)
+    gen = Generator(opt).build_models()
+    net = gen.transformer_model.net_t
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        net.s_emb.copy_(torch.randn(net.s_emb.shape, generator=g) * 0.02)
+        net.t_emb.copy_(torch.randn(net.t_emb.shape, generator=g) * 0.02)
+    _calibrate(gen.vid_model, gen.synthetic_batch(2, seed=1)["vid"][:, :1])
+    n_batches, B, V, steps = 8, 16, 1024, 960
+    batches = [{"vid": gen.synthetic_batch(B, seed=1 + i)["vid"].cuda()} for i in range(n_batches)]
+    torch.manual_seed(77)
+    res = gen.run_pipelined(iter(batches))
+    torch.cuda.synchronize()
+    assert gen.last_lanes == 4 and gen.last_chains == 2 and [n for n, _ in gen.pipeline_token_groups()] == [4, 4]
+    codes = [r["fake"]["code"].cpu() for r in res]
+    assert all(c.shape == (B, 1024) for c in codes)
+
+    # the generator stream of the run, re-drawn: batch after batch, one [16, 1024] block per new token
+    picks = [(0, 0), (3, 7), (6, 15)]                       # (batch, clip): first group / its last member / the other chain
+    torch.manual_seed(77)
+    rows = {}
+    for i in range(n_batches):
+        for s in range(steps):
+            blk = torch.empty(B, V).exponential_(1)
+            for bi, clip in picks:
+                if bi == i and 64 + s in (64, 512, 1023):
+                    rows[(bi, clip, 64 + s)] = blk[clip].clone()
+    # torch.multinomial(p, 1) IS argmax(p / Exp(1) block of the generator): the formula the audit applies per row
+    p16 = torch.softmax(torch.randn(16, V, generator=torch.Generator().manual_seed(5)), dim=-1)
+    g1, g2 = torch.Generator().manual_seed(6), torch.Generator().manual_seed(6)
+    assert torch.equal(torch.multinomial(p16, 1, generator=g1)[:, 0], torch.argmax(p16 / torch.empty_like(p16).exponential_(1, generator=g2), dim=-1))
+
+    sd = cpu_sd(net)
+    cfg = O.namespace(z_shape=[8, 8], emb_mode="temporal", n_layer=24, n_head=16, z_len=1024, num_blocks=xopt.num_blocks, state_size=0)
+    t0 = time.time()
+    worst = 0.0
+    for T in (64, 512, 1023):
+        prefix = torch.stack([codes[bi][clip, :T] for bi, clip in picks])             # [3, T] tokens the HIP loop generated
+        got = net(prefix.cuda())[:, -1].cpu()                                          # HIP teacher-forced logits at T - 1
+        with torch.no_grad():
+            want = O.gpt_forward(sd, cfg, prefix)[:, -1]
+        worst = max(worst, maxdiff(got, want))
+        assert maxdiff(got, want) < 2e-4, (T, maxdiff(got, want))
+        logits = O.top_k_logits(want / xopt.temperature, xopt.top_k)
+        probs = torch.softmax(logits, dim=-1)
+        for j, (bi, clip) in enumerate(picks):
+            pick = int(torch.argmax(probs[j] / rows[(bi, clip, T)]))
+            assert pick == int(codes[bi][clip, T]), f"batch {bi} clip {clip} position {T}: HIP picked {int(codes[bi][clip, T])}, the oracle {pick}"
+    print(f"\nBAIR B=16 free-running audit: 9 (batch, clip, T) picks equal the oracle's on the same noise rows; logits max|diff| {worst:.2e} "
+          f"({time.time() - t0:.0f}s of oracle)")
