@@ -364,6 +364,18 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
     const AxisTaps ax = axis_taps(p.kw, p.stride, p.pad, p.transposed, cls & 1, p.Wout);
     if (ty * TH >= ay.V || tx * TW >= ax.V) return;
     if (ablate & 32768) return;   // timing experiments: the cost of dispatching the workgroups alone
+    {   // Phase stagger (bits 18-23 of `ablate`, CCVS_CONV_STAGGER): the first workgroup of every CU starts ph x stg x ~3.8 us late,
+        // ph = 0..7 by dispatch order, so that the CUs do not run their tiles -- whose prologues read and whose epilogues write in
+        // bursts -- in lock-step from the launch on
+        const int stg = (ablate >> 18) & 63;
+        if (stg) {
+            const int lin = p.nwork > 0 ? (int)blockIdx.x : (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+            if (lin < 256) {
+                const int ph = (lin >> 3) & 7;
+                for (int i = 0; i < ph * stg; ++i) __builtin_amdgcn_s_sleep(127);
+            }
+        }
+    }
     if (tid < 32 * MB) bias_s[tid] = (p.bias && n0 + tid < p.Cout) ? p.bias[n0 + tid] : 0.f;   // visible after the first step barrier
 
     const int IH = (TH - 1) * ay.s + ay.ext + 1;
@@ -1299,7 +1311,8 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
     }
     static const int ablate_env = getenv("CCVS_CONV_ABLATE") ? atoi(getenv("CCVS_CONV_ABLATE")) : 0;  // timing experiments only (1: no staging, 2: no MFMA, 4: scalar staging, 128: no weight DMA, 256: no activation staging)
     static const int conv_prio = getenv("CCVS_CONV_PRIO") ? atoi(getenv("CCVS_CONV_PRIO")) : 0;   // s_setprio of the producer / consumer kernels (0-3)
-    const int ablate = (ablate_env & 0xffff) | ((conv_prio & 3) << 16);
+    static const int conv_stagger = getenv("CCVS_CONV_STAGGER") ? atoi(getenv("CCVS_CONV_STAGGER")) : 0;   // experiments: phase stagger of the first workgroups (units of ~3.8 us)
+    const int ablate = (ablate_env & 0xffff) | ((conv_prio & 3) << 16) | ((conv_stagger & 63) << 18);
     ConvK k = k_in;
     const dim3 grid3(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
     // cu_limit > 0: the tiles go out as consecutive 1-D chunks of cu_limit x (workgroups of this instantiation that fit one
