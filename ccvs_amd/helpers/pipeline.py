@@ -164,6 +164,11 @@ class PipelinedRun:
             if getattr(gen, "_enc_stream", None) is None:
                 gen._enc_stream = torch.cuda.Stream(device=self.dev, priority=prio[1])
             self.s_enc = gen._enc_stream
+        # CCVS_PIPELINE_ENC_SPREAD=1 (experiments): the encode of batch i on the decode stream that does NOT decode batch i ((i + 1) % D),
+        # so that every decode stream carries the same share of encodes.  Measured +-0 (profiles/r05_enc_spread_ab.txt: 203.8 / 207.0
+        # against 206.8 / 206.7 frames/s): an encode beside the other stream's decode takes 146-204 ms instead of 83 -- the chip, not the
+        # longer stream, is what is full.  Default: all encodes on the first decode stream.
+        self.enc_spread = env("CCVS_PIPELINE_ENC_SPREAD", "0") == "1" and self.s_enc is self.dec_streams[0] and len(self.dec_streams) > 1
         self.chain_list = [gen._token_chain(k) for k in range(self.chains)]
         self.entry = torch.cuda.current_stream()
         self.it = iter(batches)
@@ -245,7 +250,8 @@ class PipelinedRun:
         from this thread; nothing is replayed, the sampler words are put back, nothing is drawn from the host generator."""
         gen = self.gen
         tr, s_tok = self.chain_list[c]
-        s_tok.wait_stream(self.s_enc)
+        for st in set(self.dec_streams + [self.s_enc]):     # `ws` was encoded on one of them
+            s_tok.wait_stream(st)
         with torch.cuda.stream(s_tok):
             gen._seed_sampler_group(nb, list(range(g)), tr.net_t)
             tr.net_t.warm_only = True
@@ -329,14 +335,15 @@ class PipelinedRun:
             if self.noise_feed is not None and opt.cat and "vid_lbl" not in data:
                 self.noise_feed.drain()        # `condition` draws the labels from the same generator: behind the previous batch's noise
             ev = {k: torch.cuda.Event(enable_timing=True) for k in ("e0", "e1", "d0", "d1")}
-            with torch.cuda.stream(self.s_enc):
+            s_enc = self.dec_streams[(self.index - self.first_iter + 1) % len(self.dec_streams)] if self.enc_spread else self.s_enc
+            with torch.cuda.stream(s_enc):
                 ev["e0"].record()
                 ws = gen.condition(data)
                 ev["e1"].record()
             for t in (ws["cropped"]["code"], ws["cropped"].get("cond_code"), ws["cropped"].get("state_code")):
                 if torch.is_tensor(t) and t.is_cuda:
                     t.record_stream(s_tok)
-            m = {"i": self.index, "ws": ws, "ev": ev, "batch": data["vid"].shape[0], "noise": None}
+            m = {"i": self.index, "ws": ws, "ev": ev, "batch": data["vid"].shape[0], "noise": None, "s_enc": s_enc}
             if self.noise_feed is not None:    # this batch's draws, in batch order: one [B, V] block per new token
                 n_cond = ws["cropped"]["cond_code"].shape[1] if "cond_code" in ws["cropped"] else 0
                 add_len = int(ws["total_len"]) - ws["cropped"]["code"].shape[1] - n_cond
@@ -358,10 +365,8 @@ class PipelinedRun:
         with torch.cuda.stream(self.s_enc):
             feed = FrameFeed(len(members) * nb, opt.vid_len, self.frame_tokens, self.dev)
             feed.codes.record_stream(s_tok)
-            enc_done = torch.cuda.Event()
-            enc_done.record()
         job = {"members": members, "batch": nb, "total_len": members[0]["ws"]["total_len"], "chain": chain,
-               "enc_done": enc_done, "t0": torch.cuda.Event(enable_timing=True), "t1": torch.cuda.Event(enable_timing=True),
+               "enc_done": [m["ev"]["e1"] for m in members], "t0": torch.cuda.Event(enable_timing=True), "t1": torch.cuda.Event(enable_timing=True),
                "codes": None, "error": None, "done": threading.Event(), "feed": feed, "left": len(members)}
         self.queues[chain].put(job)
         return job
@@ -395,7 +400,8 @@ class PipelinedRun:
                 continue
             try:
                 with torch.cuda.stream(s_tok), torch.no_grad():
-                    s_tok.wait_event(job["enc_done"])
+                    for enc_done in job["enc_done"]:     # every member's encode (they run on different streams)
+                        s_tok.wait_event(enc_done)
                     members = job["members"]
                     tok_in = self._stack_inputs([m["ws"]["cropped"] for m in members])
                     gen._seed_sampler_group(job["batch"], [m["i"] for m in members], tr.net_t)
@@ -462,14 +468,14 @@ class PipelinedRun:
 
         m = task["m"]
         m["segs"] = []
-        if st is not self.s_enc:     # encoded on one stream, decoded on this one
+        if st is not m["s_enc"]:     # encoded on one stream, decoded on this one
             st.wait_event(m["ev"]["e1"])
             for holder in (m["ws"]["cropped"], m["ws"]["encoded"], m["ws"]["data"]):
                 for v in holder.values():
                     for t in (v if isinstance(v, (list, tuple)) else (v,)):
                         if torch.is_tensor(t) and t.is_cuda:
                             t.record_stream(st)
-            feed.codes.record_stream(st)
+        feed.codes.record_stream(st)
         with torch.cuda.stream(st):
             task["gen"] = self.gen._decode_codes_stream(m["ws"], code_of, final)
             task["need"] = next(task["gen"])
