@@ -44,10 +44,12 @@ def parse_args():
     ap.add_argument("--config", type=str, default="bair", choices=["bair", "kinetics", "bair-p2p", "drums"],
                     help="bair = BASELINE.json configs[1] (the metric); kinetics / bair-p2p / drums = configs[2] / [3] / [4] at their real geometry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sample-noise", type=str, default="host", choices=["device", "host"],
-                    help="host (default): the Exp(1) stream torch.multinomial draws from the process generator under the reference's seed, pre-drawn "
-                         "per batch on a noise thread and read inside the captured decode step -- the sampler every token-for-token oracle test "
-                         "pins; device: in-kernel Philox keyed by the global clip index (reported beside the headline as `sampling_device_noise`)")
+    ap.add_argument("--sample-noise", type=str, default=None, choices=["device", "host"],
+                    help="host (default for bair / bair-p2p): the Exp(1) stream torch.multinomial draws from the process generator under the reference's "
+                         "seed, pre-drawn per batch on a noise thread and read inside the captured decode step -- the sampler every token-for-token "
+                         "oracle test pins; device (default for kinetics / drums): in-kernel Philox keyed by the global clip index (bair: reported "
+                         "beside the headline as `sampling_device_noise`).  Kinetics draws 704 x 64 x 16384 values = 3 GB of host noise per batch "
+                         "(~10 s of one CPU thread, what the reference's CPU path spends too); Drums' ancillary picks are not one plain stream")
     ap.add_argument("--no-other-noise-leg", action="store_true", help="skip the second timed pass (same K batches) with the other noise source")
     ap.add_argument("--conv-precision", type=str, default=None, choices=["bf16x3", "f32"])
     ap.add_argument("--schedule", type=str, default=os.environ.get("CCVS_BENCH_SCHEDULE", "pipelined"), choices=["serial", "pipelined"],
@@ -342,6 +344,8 @@ def conv_traffic(args, kind, launches):
 
 def main():
     args = parse_args()
+    if args.sample_noise is None:
+        args.sample_noise = "host" if args.config in ("bair", "bair-p2p") else "device"
     profiled = bool(os.environ.get("ROCP_TOOL_LIBRARIES")) or "rocprof" in os.environ.get("LD_PRELOAD", "")   # under rocprofv3: measure in THIS process
     if ("WORLD_SIZE" not in os.environ and os.environ.get("CCVS_BENCH_CHILD") != "1" and os.environ.get("CCVS_BENCH_SUPERVISE", "1") != "0"
             and not (profiled and args.gpus == 1)):

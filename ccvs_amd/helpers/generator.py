@@ -294,7 +294,7 @@ class Generator:
         net_t.row_offset = [self.first_clip(batch)] * len(iters)
         net_t.noise_call = 0
 
-    def _host_noise_streams_ok(self):
+    def _host_noise_streams_ok(self, batch=None):
         """Host-drawn sampling noise (`--x_sample_noise host`: the reference's seeded torch.multinomial stream) of a batch can be
         pre-drawn as ONE stream of [B, V] blocks, one per new token, when the batch's tokens are one graph-replayed `fill_code`
         call over frame tokens only: no ancillary (state / STFT) picks with their own widths, no sliding token window (several
@@ -302,8 +302,18 @@ class Generator:
         reading its own stream (`ccvs_gpt_decode.noise_stream`), and several loops run beside each other."""
         opt = self.opt
         size = int(self.qvid_opt.z_shape[0]) * int(self.qvid_opt.z_shape[1])
-        return (not (opt.state or opt.stft) and getattr(opt, "beam_size", None) is None and getattr(opt, "use_graph", True)
-                and opt.vid_len * size <= opt.z_len)
+        if not (not (opt.state or opt.stft) and getattr(opt, "beam_size", None) is None and getattr(opt, "use_graph", True)
+                and opt.vid_len * size <= opt.z_len):
+            return False
+        if batch is not None:
+            # ... and when a batch's stream is of a size worth holding (pinned host memory + device memory per batch in flight):
+            # BAIR 960 x 16 x 1024 floats = 63 MB; Kinetics 704 x 64 x 16384 = 3 GB (CCVS_NOISE_STREAM_MAX_MB, default 1024) -- beyond
+            # it every pick draws its own block, one batch per loop, one loop at a time (the reference's order needs nothing else)
+            steps = opt.vid_len * size - int(opt.cond_len) - (size if opt.p2p else 0)
+            mb = 4.0 * steps * batch * int(getattr(opt, "z_num", 1024)) / 2 ** 20
+            if mb > float(os.environ.get("CCVS_NOISE_STREAM_MAX_MB", "1024")):
+                return False
+        return True
 
     def _token_group_size(self, batch, lanes):
         """Batches whose token loops run as ONE loop (`lanes`, capped): the stacked rows must fit one decode step (256 rows)
@@ -312,7 +322,7 @@ class Generator:
         that stream can be pre-drawn (`_host_noise_streams_ok`), else one batch per loop."""
         opt = self.opt
         if (getattr(opt, "sample", False) and getattr(self.transformer_model, "sample_noise", "host") != "device"
-                and not self._host_noise_streams_ok()):
+                and not self._host_noise_streams_ok(batch)):
             return 1
         if getattr(opt, "beam_size", None) is not None:
             return 1

@@ -146,7 +146,13 @@ class PipelinedRun:
         # token stages draw for themselves and must run one after the other, in batch order (one chain, one batch per group)
         self.host_noise = bool(getattr(opt, "sample", False)) and getattr(gen.transformer_model, "sample_noise", "host") != "device"
         self.noise_feed = None
-        if self.host_noise and not gen._host_noise_streams_ok():
+        self.it = iter(batches)
+        self.held = []            # a batch read ahead: the first one (its size decides below), or one that did not fit its group (ragged size)
+        first = next(self.it, None)
+        if first is not None:
+            self.held.append(first)
+        self.noise_streams = self.host_noise and gen._host_noise_streams_ok(first["vid"].shape[0] if first is not None else None)
+        if self.host_noise and not self.noise_streams:
             self.chains = 1
         # stream D and its twins: the encodes run on the first, the decode of batch i on stream i % n (two decodes side by side: the
         # small launches of one's coarse pyramid levels run under the other's large ones).  Default: two for frames of 128^2 and
@@ -171,8 +177,6 @@ class PipelinedRun:
         self.enc_spread = env("CCVS_PIPELINE_ENC_SPREAD", "0") == "1" and self.s_enc is self.dec_streams[0] and len(self.dec_streams) > 1
         self.chain_list = [gen._token_chain(k) for k in range(self.chains)]
         self.entry = torch.cuda.current_stream()
-        self.it = iter(batches)
-        self.held = []            # a batch read ahead that did not fit its group (ragged size): first of the next group
         self.index = first_iter
         self.n_groups = 0
         self.queues = [queue.Queue() for _ in range(self.chains)]
@@ -192,7 +196,7 @@ class PipelinedRun:
         for st in side:
             st.wait_stream(self.entry)
         self._warm_up()
-        if self.host_noise and gen._host_noise_streams_ok():
+        if self.noise_streams:
             self.noise_feed = NoiseFeed(gen.transformer_model.generator, self.dev)
         threads = [threading.Thread(target=self._token_worker, args=(k,), name=f"ccvs-token-chain-{k}", daemon=True) for k in range(self.chains)]
         for th in threads:
@@ -285,10 +289,9 @@ class PipelinedRun:
             packed.record()
         for st in set(self.dec_streams + [st_ for _, st_ in self.chain_list]):
             st.wait_event(packed)
-        first = next(self.it, None)
-        if first is None:
+        if not self.held:
             return
-        self.held.append(first)
+        first = self.held[-1]
         nb = first["vid"].shape[0]
         free, total = torch.cuda.mem_get_info(self.dev)
         foreign = max(0, total - free - torch.cuda.memory_reserved(self.dev))     # held by other processes on this device

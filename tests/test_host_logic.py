@@ -35,7 +35,7 @@ def test_token_group_size_rules(monkeypatch):
     token stream, no sliding window): each batch of the group then reads its own pre-drawn stream."""
     from ccvs_amd.helpers.generator import Generator
     g = Generator.__new__(Generator)
-    g.opt = types.SimpleNamespace(sample=True, beam_size=None, state=False, stft=False, vid_len=16, z_len=1024)
+    g.opt = types.SimpleNamespace(sample=True, beam_size=None, state=False, stft=False, vid_len=16, z_len=1024, cond_len=64, p2p=False, z_num=1024)
     g.qvid_opt = types.SimpleNamespace(z_shape=[8, 8])
     g.transformer_model = types.SimpleNamespace(sample_noise="device")
     monkeypatch.delenv("CCVS_PIPELINE_MAX_ROWS", raising=False)
@@ -55,6 +55,9 @@ def test_token_group_size_rules(monkeypatch):
     g.opt.stft, g.opt.use_graph = False, False        # eager steps draw for themselves
     assert g._token_group_size(16, 3) == 1
     g.opt.use_graph = True
+    g.opt.z_num, g.opt.cond_len = 16384, 320          # Kinetics: 704 x 64 x 16384 floats = 3 GB of noise per batch -- not held, drawn pick by pick
+    assert g._host_noise_streams_ok() and not g._host_noise_streams_ok(64) and g._token_group_size(64, 2) == 1 and g._host_noise_streams_ok(8)
+    g.opt.z_num, g.opt.cond_len = 1024, 64
     g.opt.sample = False
     assert g._token_group_size(16, 3) == 3            # greedy: nothing is drawn
     g.opt.beam_size = 4
