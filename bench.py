@@ -595,6 +595,32 @@ def main():
                 "note": "HIP events on each token stream around the whole loop of every token group of the timed region (prefill of the conditioning frame "
                         "included); bytes = weights counted ONCE per step + mean KV bytes of every batch in the group; `frac` is ONE loop's stream while "
                         "`concurrent_token_loops` loops and the decoder share the memory system (aggregate_frac = loops x frac)"}
+            if args.schedule == "pipelined" and args.config in ("bair", "bair-p2p", "kinetics"):
+                # the same token loop with the chip to itself (per step, alone against in-run): one whole loop over the
+                # stacked rows of a full token group, graph-replayed, in-kernel noise, outside the timed region
+                g_rows = max(1, int(round(mean_group))) * args.batch
+                n_g = g_rows // args.batch
+                import copy
+                code0 = torch.randint(0, xopt.z_num, (g_rows, xopt.cond_len), device=dev)
+                probe = copy.copy(net_t)          # the same parameters, its own engine state (KV cache, captured steps): the run's stay untouched
+                probe.drop_engine_state()
+                probe.noise_key, probe.row_offset, probe.noise_call = [(11 + g_, 7 + g_) for g_ in range(n_g)], [0] * n_g, 0
+                try:
+                    n_new = min(n_tok, xopt.z_len - xopt.cond_len)
+                    probe.generate(code0, 24, sample=True, top_k=xopt.top_k, temperature=xopt.temperature, noise="device")   # capture
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    probe.generate(code0, n_new, sample=True, top_k=xopt.top_k, temperature=xopt.temperature, noise="device")
+                    torch.cuda.synchronize()
+                    alone_ms = 1e3 * (time.perf_counter() - t0) / n_new
+                    line["roofline_token_loop"]["alone"] = {
+                        "ms_per_step": alone_ms, "rows": g_rows, "tokens": n_new, "in_run_over_alone": line["roofline_token_loop"]["ms_per_step"] / alone_ms,
+                        "frac": (w_bytes + n_g * kv_bytes) / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "note": f"one loop over {g_rows} stacked rows ({n_g} batches), prefill of the conditioning frame included, nothing beside it; "
+                                "in the timed region the same step shares the chip with the other token loop and two decodes"}
+                finally:
+                    probe.drop_engine_state()
+                    del probe
             # everything that runs in the timed region shares one memory system: the algorithmic bytes of the two big consumers
             conv_bytes_step = timer.total_bytes("conv2d_" + kind) / (1 if alone else args.steps)   # the convolutions of one batch
             line["pipeline_hbm"] = {"token_loop_GB_per_step": loop_bytes / args.steps / 1e9, "conv_GB_per_step": conv_bytes_step / 1e9,

@@ -66,59 +66,130 @@ class FrameFeed:
 
 
 class NoiseFeed:
-    """Host-drawn sampling noise, one request per batch, served strictly in request order by ONE thread: request i is the
-    `steps` blocks [rows, V] of Exp(1) values that `torch.multinomial` would draw for batch i's picks from the process
-    generator (transformer_model.py:395-409 -- `empty_like(probs).exponential_(1, gen)` per pick), so a run with many batches
-    in flight consumes the generator exactly like the reference's one-batch-at-a-time loop.  Each stream is drawn into pinned
-    memory and uploaded on a copy stream; `ticket["done"]` is set when the upload is enqueued, `ticket["event"]` is recorded
-    behind it."""
+    """Host-drawn sampling noise, one request per batch: request i is the `steps` blocks [rows, V] of Exp(1) values that
+    `torch.multinomial` would draw for batch i's picks from the process generator (transformer_model.py:395-409 --
+    `empty_like(probs).exponential_(1, gen)` per pick), so a run with many batches in flight consumes the generator exactly like the
+    reference's one-batch-at-a-time loop.  The generator is a serial stream (mt19937), but WHERE batch i's draws start is known as soon
+    as the draws before it have been counted off: one *skipper* thread walks a private copy of the generator from request to request
+    by drawing the same number of raw 64-bit values (`random_()` on int64: one `random64()` per element, like `exponential_`, at half
+    its cost -- checked against `exponential_` when the feed starts; if the states ever disagreed the feed falls back to drawing
+    every stream on the skipper itself) and hands the state at each boundary to a pool of *drawer* threads, which produce the
+    streams in parallel with torch's own `exponential_`, block by block, into pinned memory and upload them on a copy stream.
+    `ticket["done"]` is set when the upload is enqueued, `ticket["event"]` is recorded behind it.  The process generator itself is moved to
+    the end of everything requested in `drain()` / `close()`; nobody else may draw from it while requests are pending."""
 
-    def __init__(self, generator, device):
-        self.generator, self.device = generator, device
+    SKIP_CHUNK = 1 << 22   # raw values per skip call (32 MB of int64)
+
+    def __init__(self, generator, device, drawers=None):
+        self.real = generator if generator is not None else torch.default_generator
+        self.device = device
         self.copy_stream = torch.cuda.Stream(device=device)
-        self.jobs = queue.Queue()
+        self.cursor = torch.Generator()          # the skipper's copy: always at the start of the next request
+        self.cursor.set_state(self.real.get_state())
+        n = int(os.environ.get("CCVS_NOISE_DRAWERS", "4")) if drawers is None else int(drawers)
+        self.parallel = n > 0 and self._skip_matches_draw()
+        self.requests, self.work = queue.Queue(), queue.Queue()
         self.pending = 0
         self.idle = threading.Condition()
-        self.thread = threading.Thread(target=self._serve, name="ccvs-noise-feed", daemon=True)
-        self.thread.start()
+        self.threads = [threading.Thread(target=self._skipper, name="ccvs-noise-skipper", daemon=True)]
+        if self.parallel:
+            self.threads += [threading.Thread(target=self._drawer, name=f"ccvs-noise-drawer-{k}", daemon=True) for k in range(n)]
+        self.n_drawers = len(self.threads) - 1
+        for th in self.threads:
+            th.start()
+
+    def _skip_matches_draw(self):
+        """`random_()` on n int64 values leaves a generator where `exponential_` on n floats leaves it (ragged n included)."""
+        for n in (1, 17, 4099):
+            a, b = torch.Generator(), torch.Generator()
+            a.set_state(self.cursor.get_state())
+            b.set_state(self.cursor.get_state())
+            torch.empty(n, dtype=torch.float32).exponential_(1, generator=a)
+            torch.empty(n, dtype=torch.int64).random_(generator=b)
+            if not torch.equal(a.get_state(), b.get_state()):
+                return False
+        return True
 
     def request(self, rows, steps, width):
         ticket = {"rows": rows, "steps": steps, "width": width, "done": threading.Event(), "event": None, "noise": None, "error": None}
         with self.idle:
             self.pending += 1
-        self.jobs.put(ticket)
+        self.requests.put(ticket)
         return ticket
 
     def drain(self):
-        """Wait until every request so far has been drawn (another consumer of the generator is about to draw)."""
+        """Wait until every request so far has been drawn and move the process generator behind them (another consumer of the
+        generator is about to draw)."""
         with self.idle:
             self.idle.wait_for(lambda: self.pending == 0)
+            self.real.set_state(self.cursor.get_state())
+
+    def resync(self):
+        """After `drain()` and the other consumer's draws: the next request starts where the process generator now stands."""
+        with self.idle:
+            assert self.pending == 0
+            self.cursor.set_state(self.real.get_state())
 
     def close(self):
-        self.jobs.put(None)
-        self.thread.join(30.0)
+        self.requests.put(None)
+        self.threads[0].join(60.0)
+        for _ in range(self.n_drawers):
+            self.work.put(None)
+        for th in self.threads[1:]:
+            th.join(60.0)
+        self.real.set_state(self.cursor.get_state())
 
-    def _serve(self):
+    def _finish(self, t):
+        t["done"].set()
+        with self.idle:
+            self.pending -= 1
+            self.idle.notify_all()
+
+    def _draw(self, t, gen):
+        """One stream from `gen` (positioned at its first value): block after block, exactly the calls torch.multinomial makes."""
+        try:
+            buf = torch.empty(t["steps"], t["rows"], t["width"], dtype=torch.float32, pin_memory=True)
+            for i in range(t["steps"]):
+                buf[i].exponential_(1, generator=gen)
+            with torch.cuda.stream(self.copy_stream):
+                t["noise"] = buf.to(self.device, non_blocking=True)
+                t["event"] = torch.cuda.Event()
+                t["event"].record()
+        except BaseException as exc:
+            t["error"] = exc
+        finally:
+            self._finish(t)
+
+    def _skipper(self):
         torch.cuda.set_device(self.device)
         while True:
-            t = self.jobs.get()
+            t = self.requests.get()
             if t is None:
                 return
+            if not self.parallel:
+                self._draw(t, self.cursor)
+                continue
+            state = self.cursor.get_state()
+            self.work.put((t, state))
+            left = t["steps"] * t["rows"] * t["width"]
             try:
-                buf = torch.empty(t["steps"], t["rows"], t["width"], dtype=torch.float32, pin_memory=True)
-                for i in range(t["steps"]):
-                    buf[i].exponential_(1, generator=self.generator)
-                with torch.cuda.stream(self.copy_stream):
-                    t["noise"] = buf.to(self.device, non_blocking=True)
-                    t["event"] = torch.cuda.Event()
-                    t["event"].record()
-            except BaseException as exc:
+                while left > 0:           # count the stream's values off on the cursor: where the next request starts
+                    n = min(left, self.SKIP_CHUNK)
+                    torch.empty(n, dtype=torch.int64).random_(generator=self.cursor)
+                    left -= n
+            except BaseException as exc:   # (out of host memory ...): the tickets behind this one would start in the wrong place
                 t["error"] = exc
-            finally:
-                t["done"].set()
-                with self.idle:
-                    self.pending -= 1
-                    self.idle.notify_all()
+
+    def _drawer(self):
+        torch.cuda.set_device(self.device)
+        gen = torch.Generator()
+        while True:
+            item = self.work.get()
+            if item is None:
+                return
+            t, state = item
+            gen.set_state(state)
+            self._draw(t, gen)
 
 
 class PipelinedRun:
@@ -335,7 +406,8 @@ class PipelinedRun:
             elif data["vid"].shape[0] != members[0]["batch"]:
                 self.held.append(data)         # a ragged batch starts the next group
                 break
-            if self.noise_feed is not None and opt.cat and "vid_lbl" not in data:
+            other_draw = self.noise_feed is not None and opt.cat and "vid_lbl" not in data
+            if other_draw:
                 self.noise_feed.drain()        # `condition` draws the labels from the same generator: behind the previous batch's noise
             ev = {k: torch.cuda.Event(enable_timing=True) for k in ("e0", "e1", "d0", "d1")}
             s_enc = self.dec_streams[(self.index - self.first_iter + 1) % len(self.dec_streams)] if self.enc_spread else self.s_enc
@@ -343,6 +415,8 @@ class PipelinedRun:
                 ev["e0"].record()
                 ws = gen.condition(data)
                 ev["e1"].record()
+            if other_draw:
+                self.noise_feed.resync()       # ... and this batch's noise behind the labels
             for t in (ws["cropped"]["code"], ws["cropped"].get("cond_code"), ws["cropped"].get("state_code")):
                 if torch.is_tensor(t) and t.is_cuda:
                     t.record_stream(s_tok)

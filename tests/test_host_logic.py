@@ -223,3 +223,51 @@ def test_rank_cpu_sets():
     assert sets[2] == [8, 9, 10, 11, 12, 13, 14, 15] and sets[3] == [24, 25, 26, 27, 28, 29, 30, 31]
     assert A.rank_cpu_set(2, 4, list(range(32)), {0: 0, 1: 0}, node_cpus) == list(range(16, 24))   # incomplete map: contiguous blocks
     assert A.parse_showtoponuma("garbage") == {}
+
+
+def test_noise_feed_streams_follow_the_generator(monkeypatch):
+    """`NoiseFeed` (ccvs_amd/helpers/pipeline.py): requests served by parallel drawer threads behind a skipper that counts every
+    stream's values off on a copy of the generator == the same blocks drawn one after the other from the generator itself (what
+    torch.multinomial does, pick after pick, batch after batch); the process generator ends where the serial loop would leave it;
+    the single-thread fallback gives the same.  (The device pieces -- pinned memory, copy stream, events -- are stubbed: CPU test.)"""
+    import contextlib
+    import torch
+    from ccvs_amd.helpers import pipeline as P
+
+    class _Stub:
+        def __init__(self, *a, **k):
+            pass
+
+        def record(self):
+            pass
+
+    real_empty = torch.empty
+    monkeypatch.setattr(torch.cuda, "Stream", _Stub)
+    monkeypatch.setattr(torch.cuda, "Event", _Stub)
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **{kk: v for kk, v in k.items() if kk != "pin_memory"}))
+    ref = torch.Generator().manual_seed(7)
+    shapes = [(4, 30, 50), (4, 30, 50), (3, 7, 33), (4, 30, 50), (1, 1, 1), (5, 12, 64)]      # (rows, steps, width), ragged on purpose
+    want = [torch.stack([real_empty(r, w).exponential_(1, generator=ref) for _ in range(n)]) for r, n, w in shapes]
+    tail = real_empty(5).exponential_(1, generator=ref)
+    for drawers in (3, 0):
+        g = torch.Generator().manual_seed(7)
+        feed = P.NoiseFeed(g, "cpu", drawers=drawers)
+        assert feed.parallel == (drawers > 0)
+        tickets = [feed.request(r, n, w) for r, n, w in shapes[:4]]
+        feed.drain()                                   # another consumer draws here (class labels): the generator must stand behind request 3
+        mid = torch.Generator()
+        mid.set_state(g.get_state())
+        feed.resync()
+        tickets += [feed.request(r, n, w) for r, n, w in shapes[4:]]
+        for t in tickets:
+            assert t["done"].wait(60) and t["error"] is None
+        feed.close()
+        for t, w in zip(tickets, want):
+            assert torch.equal(t["noise"], w)
+        assert torch.equal(real_empty(5).exponential_(1, generator=g), tail)
+        chk = torch.Generator().manual_seed(7)
+        for r, n, w in shapes[:4]:
+            real_empty(n * r * w).exponential_(1, generator=chk)
+        assert torch.equal(mid.get_state(), chk.get_state())
