@@ -316,7 +316,9 @@ class PipelinedRun:
         cache = self.chain_list[c][0].net_t._caches.get(nb * g)
         live = cache is not None and cache.get("G") == g and len(cache.get("graphs", {})) > 0
         key = self._capture_key(c, nb * g, g)
-        if not live:
+        # ... and the live graphs must be THIS key's: a run with another sampler in between (bench.py's legs: host noise, device
+        # noise, host noise again) leaves graphs of its own behind a key that is still in the side set
+        if not live or cache.get("warm_key") != key:
             self.gen._warm_keys.discard(key)
         return key not in self.gen._warm_keys
 
@@ -336,7 +338,11 @@ class PipelinedRun:
                 tr.net_t.warm_only = False
                 tr.net_t.noise_key, tr.net_t.row_offset = None, 0
         s_tok.synchronize()
-        gen._warm_keys.add(self._capture_key(c, nb * g, g))
+        key = self._capture_key(c, nb * g, g)
+        gen._warm_keys.add(key)
+        cache = tr.net_t._caches.get(nb * g)
+        if cache is not None:
+            cache["warm_key"] = key
         self.s_enc.wait_stream(s_tok)
 
     def _warm_up(self):

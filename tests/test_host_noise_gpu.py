@@ -208,3 +208,37 @@ def test_run_entry_point_pipelined_equals_serial(tmp_path, monkeypatch):
         assert (np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b), key
     fakes = [v for (kind, _), v in outs["pipelined"][1].items() if kind == "fake"]
     assert isinstance(fakes[0], np.ndarray) and not np.array_equal(fakes[0], fakes[2])
+
+
+def test_sampler_switch_between_runs_recaptures_up_front(tiny, monkeypatch):
+    """bench.py's legs run the same Generator with host noise, device noise and host noise again.  The captured decode steps belong to
+    ONE sampler: after a run with the other one the up-front warm-up must see the chain as cold again (a capture left to a worker
+    thread would race with the other threads' launches), and the third run still equals the first."""
+    from ccvs_amd.helpers.generator import Generator
+    from ccvs_amd.helpers.pipeline import PipelinedRun
+    monkeypatch.setenv("CCVS_PIPELINE_DEC_STREAMS", "2")
+    xopt = tiny["xopt"]
+    xopt.sample, xopt.top_k, xopt.rec_pass = True, 10, False
+    old = (tiny["tr"].sample_noise, tiny["tr"].generator)
+    try:
+        gen = Generator(tiny["opt"])
+        gen.vid_model, gen.transformer_model = tiny["qv"], tiny["tr"]
+        batches = [gen.synthetic_batch(2, seed=30 + i)["vid"] for i in range(4)]
+        runs = []
+        for noise in ("host", "device", "host"):
+            for tr_ in [gen.transformer_model] + [t for t, _ in gen._chains]:
+                tr_.sample_noise, tr_.generator = noise, None
+            probe = PipelinedRun(gen, iter([{"vid": batches[0].clone()}]), lanes=2, chains=2)
+            if runs:
+                assert probe._is_cold(0, 2, 2), f"chain 0 still looks warm after the sampler changed to {noise}"
+            torch.manual_seed(5)
+            runs.append(gen.run_pipelined(({"vid": b.clone()} for b in batches), lanes=2, chains=2))
+            torch.cuda.synchronize()
+            assert not PipelinedRun(gen, iter([{"vid": batches[0].clone()}]), lanes=2, chains=2)._is_cold(0, 2, 2)
+        for a, b in zip(runs[0], runs[2]):
+            assert torch.equal(a["fake"]["code"], b["fake"]["code"]) and torch.equal(a["fake"]["vid"], b["fake"]["vid"])
+        assert not torch.equal(runs[0][0]["fake"]["code"], runs[1][0]["fake"]["code"])
+    finally:
+        xopt.sample, xopt.rec_pass = False, True
+        for tr_ in [tiny["tr"]] + [t for t, _ in gen._chains]:
+            tr_.sample_noise, tr_.generator = old
