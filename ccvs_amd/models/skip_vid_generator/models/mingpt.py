@@ -783,7 +783,13 @@ class GPT(nn.Module):
             def host_noise(nb, nv):
                 i = next(blocks)
                 return streams[0][i] if len(streams) == 1 else torch.cat([s_[i] for s_ in streams], dim=0)
-        # host-drawn noise inside the captured step: the call's whole noise stream is on the device before the first replay
+        # host-drawn noise inside the captured step: the call's whole noise stream is on the device before the first replay -- unless
+        # the caller did not pre-draw it and it would be too large to hold (Kinetics: 704 x 64 x 16384 floats = 3 GB; CCVS_NOISE_STREAM_MAX_MB):
+        # then every step draws and uploads its own block, eagerly, as in rounds 1-4
+        if host and not eager and self.noise_streams is None:
+            import os
+            if 4.0 * add_len * b * self.head.weight.shape[0] / 2 ** 20 > float(os.environ.get("CCVS_NOISE_STREAM_MAX_MB", "1024")):
+                eager = True
         sampler["stream"] = host and not eager
         max_len = n_pre + n_cond + t0 + add_len
         c = self.begin(b, max_len)

@@ -29,7 +29,7 @@ from ccvs_amd.helpers.generator import Generator  # noqa: E402
 
 batch = 16
 opt = Options().parse(load_qvid_generator=True, load_transformer=True,
-                      argv=list(BAIR_ARGV) + ["--batch_size_vid", str(batch), "--x_sample_noise", "device", "--rec_pass", "false"])
+                      argv=list(BAIR_ARGV) + ["--batch_size_vid", str(batch), "--x_sample_noise", os.environ.get("CCVS_SOAK_NOISE", "host"), "--rec_pass", "false"])   # host: the headline's sampler since round 5
 torch.manual_seed(0)
 engine = Engine()
 engine.distributed = True          # one rank, but the collective path
@@ -68,5 +68,6 @@ for r in range(runs):
     print(f"run {r + 1}/{runs}: {n_batches} batches in {dt:.1f} s = {15 * batch * n_batches / dt:.1f} frames/s; longest time between two finished "
           f"batches {max(gaps):.0f} ms (median {sorted(gaps)[len(gaps) // 2]:.0f} ms); load average {os.getloadavg()[0]:.1f}", flush=True)
 print(f"soak: {total_b} batches, {total_s:.0f} s, {15 * batch * total_b / total_s:.1f} frames/s, no stall, no time limit hit "
-      f"(lanes {gen.last_lanes}, chains {gen.last_chains}, decode streams {gen.last_dec_streams})", flush=True)
+      f"(lanes {gen.last_lanes}, chains {gen.last_chains}, decode streams {gen.last_dec_streams}, noise {os.environ.get('CCVS_SOAK_NOISE', 'host')}; "
+      f"host RSS {__import__('psutil').Process().memory_info().rss / 2 ** 30:.1f} GB)", flush=True)
 dist.destroy_process_group()
