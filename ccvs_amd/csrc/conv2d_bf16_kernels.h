@@ -359,9 +359,14 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
     const int ty = bx / p.tiles_x, tx = bx - ty * p.tiles_x;
     const int n0 = by * NT;
     int n = bz, cls = 0;
-    if (p.transposed) { cls = n & 3; n >>= 2; }
-    const AxisTaps ay = axis_taps(p.kh, p.stride, p.pad, p.transposed, cls >> 1, p.Hout);
-    const AxisTaps ax = axis_taps(p.kw, p.stride, p.pad, p.transposed, cls & 1, p.Wout);
+    if (!TAP3 && p.transposed) { cls = n & 3; n >>= 2; }
+    // GEO3 (the written-out 3 x 3 instantiations: stride 1, padding 1, not transposed -- the launcher sees to it): the tap table and
+    // with it the halo tile's geometry (IH, IW, row pitch, plane, item counts) are COMPILE-TIME constants.  The set-up in front of the
+    // first barrier was ~1900 instructions per wave, two dozen of them integer divisions by these launch-uniform values (25
+    // instructions each): 8.4 k cycles of a tile's 10.8 k-cycle prologue (profiles/r05_conv_ablate_cycles.txt) were this code, not latency.
+    constexpr bool GEO3 = TAP3;
+    const AxisTaps ay = GEO3 ? axis_taps_k3(p.Hout) : axis_taps(p.kh, p.stride, p.pad, p.transposed, cls >> 1, p.Hout);
+    const AxisTaps ax = GEO3 ? axis_taps_k3(p.Wout) : axis_taps(p.kw, p.stride, p.pad, p.transposed, cls & 1, p.Wout);
     if (ty * TH >= ay.V || tx * TW >= ax.V) return;
     if (ablate & 32768) return;   // timing experiments: the cost of dispatching the workgroups alone
     {   // Phase stagger (bits 18-23 of `ablate`, CCVS_CONV_STAGGER): the first workgroup of every CU starts ph x stg x ~3.8 us late,
@@ -390,7 +395,8 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
     // (75 % of the staging waves' LDS cycles, SQ_LDS_BANK_CONFLICT).
     const int IWS = VEC ? 4 * NQ + 1 : IW;
     const int plane = IH * IWS;
-    const int in_sz = 4 * plane, w_sz = ntx_max * 4 * NT;
+    const int ntxm_ = GEO3 ? 3 : ntx_max;
+    const int in_sz = 4 * plane, w_sz = ntxm_ * 4 * NT;
     uint4* in_buf = smem4;               // [2][half 2][part 2][plane]
     uint4* w_buf = smem4 + 2 * in_sz;    // [2][ntx][half 2][part 2][NT]
 
@@ -407,14 +413,22 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
     // so a load is `uniform base + 32-bit lane offset` with no vector address arithmetic.
     constexpr int NE = (VEC || P8IN) ? 1 : CB_MAX_E;
     int offs[NE];  // halo element -> plane offset; -2: no such element, -1: outside the image
+    {
+        // (row, column) of element rt by ONE division, then 256 elements further per round: an integer division by a run-time value
+        // is ~25 instructions, and this set-up code runs in front of every tile (see GEO3 above)
+        int er = 0, ec = 0;
+        const int dr_ = NP / IW, dc_ = NP - dr_ * IW;    // uniform
+        if (!VEC && !P8IN && producer) { er = rt / IW; ec = rt - er * IW; }
 #pragma unroll
-    for (int j = 0; j < NE; ++j) {
-        const int e = rt + NP * j;
-        offs[j] = -2;
-        if (!VEC && !P8IN && producer && e < plane) {
-            const int r = e / IW, c = e - r * IW;
-            const int gy = iy0 + r, gx = ix0 + c;
-            offs[j] = (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) ? gy * p.Win + gx : -1;
+        for (int j = 0; j < NE; ++j) {
+            const int e = rt + NP * j;
+            offs[j] = -2;
+            if (!VEC && !P8IN && producer && e < plane) {
+                const int gy = iy0 + er, gx = ix0 + ec;
+                offs[j] = (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) ? gy * p.Win + gx : -1;
+            }
+            er += dr_; ec += dc_;
+            if (ec >= IW) { ec -= IW; ++er; }
         }
     }
     auto pix_offset = [&](int j) -> int {  // register-array select without dynamic indexing
@@ -495,17 +509,30 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
     // P8 input: slot s = rt + 256 j of the 4-plane LDS image [half][hi|lo][pixel] <- one uint4 of the packed tensor
     constexpr int NJ = P8IN ? (PP == 4 ? 10 : 8) : 1;   // 16-byte slots of the 4-plane halo image per staging thread
     int p8off[NJ], p8q[NJ];
+    {
+        // (plane q, row, column) of slot rt by two divisions, then 256 slots further per round (no division per slot)
+        int sq = 0, sr = 0, sc = 0;
+        const int dr_ = 256 / IW, dc_ = 256 - dr_ * IW;   // uniform
+        if (P8IN && producer) {
+            sq = rt / plane;
+            const int e = rt - sq * plane;
+            sr = e / IW;
+            sc = e - sr * IW;
+        }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        p8off[j] = -2;  // no such slot
-        p8q[j] = 0;
-        const int s_ = rt + 256 * j;
-        if (P8IN && producer && s_ < 4 * plane) {
-            const int q = s_ / plane, e = s_ - q * plane;
-            const int r = e / IW, c = e - r * IW;
-            const int gy = iy0 + r, gx = ix0 + c;
-            p8off[j] = (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) ? gy * p.Win + gx : -1;
-            p8q[j] = q;
+        for (int j = 0; j < NJ; ++j) {
+            p8off[j] = -2;  // no such slot
+            p8q[j] = 0;
+            const int s_ = rt + 256 * j;
+            if (P8IN && producer && s_ < 4 * plane) {
+                const int gy = iy0 + sr, gx = ix0 + sc;
+                p8off[j] = (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) ? gy * p.Win + gx : -1;
+                p8q[j] = sq;
+            }
+            sr += dr_; sc += dc_;
+            if (sc >= IW) { sc -= IW; ++sr; }
+            if (sr >= IH) { sr -= IH; ++sq; }
+            if (sr >= IH) { sr -= IH; ++sq; }   // (a plane of fewer than 256 slots: two wraps per round at most -- planes hold >= 128)
         }
     }
     const int gin = (p.Cin + 7) >> 3;
@@ -955,7 +982,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
     // through LDS so that ALL 8 waves write 16-byte pieces along x (a lane then owns 4 consecutive
     // pixels of one channel) instead of 128 scalar stores per consumer lane: the store tail was
     // issue-bound.  32 couts x 256 pixels per pass, MB passes.
-    if (!p.transposed) {
+    if (GEO3 || !p.transposed) {
         float* stage = reinterpret_cast<float*>(smem4);
         constexpr int NIT = (8 * NPIX + 255 + NP) / (256 + NP);   // 16-byte pieces of a 32-channel pass per thread
         constexpr bool LEANK = MB == 1 || WPC == 2;   // kernels capped at 128 registers: the fast path below or the plain piece-by-piece one
@@ -1366,7 +1393,7 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
             static const int pp4p = getenv("CCVS_CONV_PP4") ? atoi(getenv("CCVS_CONV_PP4")) : 1;
             const int th4 = 16, halo_h4 = (th4 - 1) + k.kh, plane4 = halo_h4 * halo_w;
             const size_t smem_4 = (size_t)(2 * 4 * plane4 + 2 * ntx_max * 4 * NT) * 16;
-            if (pp4p && k.out_p8 && k.kh == 3 && k.kw == 3 && k.cu_limit <= 0 && k.Hout >= 2 * th4 && 4 * plane4 <= 10 * 256 && smem_4 <= 156 * 1024 &&
+            if (pp4p && k.out_p8 && k.kh == 3 && k.kw == 3 && k.pad == 1 && k.cu_limit <= 0 && k.Hout >= 2 * th4 && 4 * plane4 <= 10 * 256 && smem_4 <= 156 * 1024 &&
                 smem_4 >= (size_t)32 * 512 * 4) {
                 k.tiles_y = cdiv(k.Hout, th4);
                 const dim3 grid4(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
@@ -1385,7 +1412,7 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
         }
         bool done3 = false;
         if constexpr (MB != 4) {
-            if (k.kh == 3 && k.kw == 3) {
+            if (k.kh == 3 && k.kw == 3 && k.pad == 1) {
                 CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, -83>), 512, (smem_p > p8s2 ? smem_p : p8s2), (const uint4*)wsplit, CinG, ntx_max, ablate);
                 done3 = true;
             }
@@ -1398,7 +1425,7 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
     const int xsh = ((-k.pad % 4) + 4) % 4, nq = (xsh + halo_w + 3) / 4;
     const bool vec_ok = !k.transposed && k.stride == 1 && k.Win % 4 == 0 && k.in_sC % 4 == 0 && k.in_sN % 4 == 0 &&
                         (reinterpret_cast<uintptr_t>(k.x) & 15) == 0 && TW >= 16 && halo_h * ((nq + 1) / 2) * 4 <= 256 && ntx_max <= (MB == 1 ? 9 : 3) &&
-                        (k.kh == 1 || k.kh == 3) && !(ablate & 4);
+                        (k.kh == 1 || (k.kh == 3 && k.kw == 3 && k.pad == 1)) && !(ablate & 4);   // (3 x 3: the GEO3 instantiations assume padding 1)
     // packed K tail (ccvs_conv_desc.w_ktail): read by the vectorised 3 x 3 instantiations only
     static const int ktail_on = getenv("CCVS_CONV_KTAIL") ? atoi(getenv("CCVS_CONV_KTAIL")) : 1;
     const int ktail_r = k.Cin % CB_CC;

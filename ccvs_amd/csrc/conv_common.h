@@ -87,3 +87,10 @@ __device__ __forceinline__ AxisTaps axis_taps(int k, int stride, int pad, int tr
     return t;
 }
 
+// the tap table of a 3-tap axis with stride 1 and padding 1 (every field but the extent a constant)
+__device__ __forceinline__ AxisTaps axis_taps_k3(int out_extent) {
+    AxisTaps t;
+    t.nt = 3; t.d0 = -1; t.dd = 1; t.w0 = 0; t.dw = 1; t.s = 1; t.os = 1; t.oo = 0;
+    t.V = out_extent; t.lo = -1; t.ext = 2;
+    return t;
+}
