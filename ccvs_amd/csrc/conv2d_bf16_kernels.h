@@ -765,12 +765,25 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
     } else {
       int ci = -1, a = nt - 1;
       const int nloop = ktail ? nsteps - 1 : nsteps;
+#ifdef CB_STAMPS   // debug build: T0 loop top, T1 weight DMA issued, T2 the step's matrix instructions issued, T3 behind the step barrier
+      const bool stamp_on = p.dbg && tid == 0 && (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) == p.dbg_block;
+#define CB_STAMP(K)                                                                         \
+    if (stamp_on && s >= 0 && s < 24) {                                                     \
+        unsigned long long t_;                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+        p.dbg[4 * s + (K)] = (long long)t_;                                                 \
+    }
+#else
+#define CB_STAMP(K)
+#endif
       for (int s = -1; s < nloop; ++s) {
+        CB_STAMP(0)
         if (DMAW && !(ablate & (1 | 128)) && s + 1 < nsteps) {   // 128: activations still staged, no weight DMA  // weights of step s+1 by LDS-DMA; hipcc drains them (vmcnt 0) at the barrier
             int a1 = a + 1, c1 = ci;
             if (a1 == nt) { a1 = 0; ++c1; }
             dma_w(c1, a1, w_buf + ((s + 1) & 1) * w_sz);
         }
+        CB_STAMP(1)
         if (s >= 0 && !(ablate & 2)) {
             const uint4* it0 = in_buf + (ci & 1) * in_sz + (khalf * 2) * plane + (ay.d0 + a * ay.dd - ay.lo) * IWS;
             const uint4* wt0 = w_buf + (s & 1) * w_sz + (khalf * 2) * NT + (lane & 31);
@@ -923,9 +936,12 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
 #undef CB_TAP
             }
         }
+        CB_STAMP(2)
         __syncthreads();
+        CB_STAMP(3)
         if (++a == nt) { a = 0; ++ci; }
       }
+#undef CB_STAMP
       if constexpr (NTY == 3) {
         if (ktail) {
             // Packed K tail: the last chunk holds r = Cin % 16 <= 3 real channels.  Its nine taps x r channels are contracted
@@ -1341,6 +1357,10 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
     static const int conv_stagger = getenv("CCVS_CONV_STAGGER") ? atoi(getenv("CCVS_CONV_STAGGER")) : 0;   // experiments: phase stagger of the first workgroups (units of ~3.8 us)
     const int ablate = (ablate_env & 0xffff) | ((conv_prio & 3) << 16) | ((conv_stagger & 63) << 18);
     ConvK k = k_in;
+#ifdef CB_STAMPS
+    k.dbg = getenv("CCVS_CONV_DBG") ? (long long*)strtoull(getenv("CCVS_CONV_DBG"), nullptr, 0) : nullptr;
+    k.dbg_block = getenv("CCVS_CONV_DBG_BLOCK") ? atoi(getenv("CCVS_CONV_DBG_BLOCK")) : 0;
+#endif
     const dim3 grid3(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
     // cu_limit > 0: the tiles go out as consecutive 1-D chunks of cu_limit x (workgroups of this instantiation that fit one
     // CU) workgroups -- launches on one stream run one after the other, so the convolution never holds more than cu_limit

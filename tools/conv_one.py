@@ -11,7 +11,8 @@ from ccvs_amd import ops  # noqa: E402
 
 cin, cout, k, h, n = [int(v) for v in sys.argv[1:6]]
 p8 = "p8" in sys.argv[6:]
-if len(sys.argv) > 6 and sys.argv[6] != "p8":
+p8out = "p8out" in sys.argv[6:]      # fp32 input, packed output (the first convolution of a Matching / Subpixel stack)
+if len(sys.argv) > 6 and sys.argv[6] not in ("p8", "p8out"):
     ops.CONV_PRECISION = sys.argv[6]
 torch.manual_seed(0)
 x = torch.randn(n, cin, h, h, device="cuda")
@@ -21,13 +22,13 @@ wp = ops.pack_conv_weight(w)
 if p8:   # a packed input: the output of an identity 1x1 convolution
     eye = torch.eye(cin, device="cuda").view(cin, cin, 1, 1) * (cin ** 0.5)
     x = ops.conv2d(x, ops.pack_conv_weight(eye), None, cin, 1, out_p8=True)
-kw = dict(out_p8=True) if p8 else {}
+kw = dict(out_p8=True) if (p8 or p8out) else {}
 y = ops.conv2d(x, wp, b, cout, k, pad=k // 2, act=True, **kw)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(3):
-    ops.conv2d(x, wp, b, cout, k, pad=k // 2, act=True, **(kw if p8 else dict(out=y)))
+    ops.conv2d(x, wp, b, cout, k, pad=k // 2, act=True, **(kw if (p8 or p8out) else dict(out=y)))
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 3
