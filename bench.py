@@ -439,7 +439,7 @@ def main():
             gathered = [None] * world
             dist.all_gather_object(gathered, rank_stages[0])
             rank_stages = gathered
-        alone, self_check = None, None
+        alone, self_check, alone_passes = None, None, None
         if engine.is_main and args.schedule == "pipelined":
             # timed batch 0 once more, ALONE on the serial schedule (generate_vid: same inputs, same iteration index, the process
             # generator re-seeded as in front of the timed pass -- batch 0 is its first consumer in both), outside the timed region:
@@ -447,14 +447,27 @@ def main():
             #     in flight must be the serial clip, bit for bit (tokens and fp32 pixels);
             # (2) the same convolution launches with the chip to themselves: the kernel's roofline (in the pipelined schedule
             #     the launches are timed beside the token loops of other batches)
-            timer_alone = ops.KernelTimer()
-            ops.KERNEL_TIMER = timer_alone
-            torch.manual_seed(NOISE_SEED)
-            out_s = gen.generate_vid({k: v.clone() for k, v in batches[0].items()}, 0)
-            torch.cuda.synchronize()
-            ops.KERNEL_TIMER = None
-            n_a, f_a, ms_a = timer_alone.summary("conv2d_" + ops.CONV_PRECISION)
+            # The pass is run three times and the MEDIAN pass is the one reported (all of them listed in the line): right
+            # after the timed region single passes of one box came out between 183 and 266 TFLOP/s (the same pass in a process of
+            # its own: 266-267 every time, tools/r05/alone_var.py) -- the first pass runs into whatever the timed region left behind
+            # (clock state; worker threads winding down on the host side of the launch-bound small convolutions).
+            passes = []
+            for _ in range(3):       # ALONE_PASSES
+                timer_p = ops.KernelTimer()
+                ops.KERNEL_TIMER = timer_p
+                torch.manual_seed(NOISE_SEED)
+                out_p = gen.generate_vid({k: v.clone() for k, v in batches[0].items()}, 0)
+                torch.cuda.synchronize()
+                ops.KERNEL_TIMER = None
+                n_p, f_p, ms_p = timer_p.summary("conv2d_" + ops.CONV_PRECISION)
+                passes.append((f_p / (ms_p * 1e-3) / 1e12 if ms_p > 0 else 0.0, timer_p, (n_p, f_p, ms_p)))
+                if len(passes) == 1:
+                    out_s = out_p          # the self-check compares the FIRST pass
+                del out_p
+            alone_passes = [round(v[0], 1) for v in passes]
+            _, timer_alone, (n_a, f_a, ms_a) = sorted(passes, key=lambda v: v[0])[len(passes) // 2]
             alone = f_a / (ms_a * 1e-3) / 1e12 if ms_a > 0 else None
+            del passes
             if "fake" in kept:
                 same_tok = bool(torch.equal(kept["fake"]["code"], out_s["fake"]["code"]))
                 d = (kept["fake"]["vid"] - out_s["fake"]["vid"]).abs().max().item()
@@ -537,8 +550,9 @@ def main():
                                         if kind == "bf16x3" else "conv2d_mfma_kernel<TW,MB>"), "bound": "mfma",
                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                              "measured": ("HIP events around every convolution launch of one more batch run with nothing beside it, right after the timed "
-                                          "region (pipelined schedule: see in_timed_region)" if shared else
+                                          "region: the median of three such passes, `alone_passes` (pipelined schedule: see in_timed_region)" if shared else
                                           "HIP events around every convolution launch of the timed region"),
+                             "alone_passes": alone_passes if shared else None,
                              "in_timed_region": shared,
                              "cu_share": (f"launches capped to {gen.last_cu_limit} of {n_cu} CUs while a token loop is in flight: against that share of the "
                                           f"peak the fraction is {achieved / (peak * gen.last_cu_limit / n_cu):.4f}") if args.schedule == "pipelined" and gen.last_cu_limit else None,

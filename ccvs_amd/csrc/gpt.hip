@@ -121,9 +121,10 @@ struct Gemm16 {
     int kz;            // K slices across workgroups (gridDim.z); > 1 only with a workspace
     float* ws_slabs;   // [tile][kz][64 lanes][4] partial accumulators
     int* ws_count;     // [tile] arrival counters, zero between launches
+    int ablate;        // timing experiments (CCVS_GEMM_ABLATE; results are wrong): 1: every lane reads x row 0, 2: every lane reads W row 0
 };
 
-#define GEMM_U 4  // K steps (of 16) whose loads are issued together (4 float4 of W + 4 of x per lane: the 48-VGPR budget)
+#define GEMM_U 4  // one-block form: K steps (of 16) whose loads are issued together (4 float4 of W + 4 of x per lane: the 48-VGPR budget)
 #define GEMM_U_RB 8  // the same for the prefill form (512 threads, its own CU)
 #define GEMM_WS_TILES 1024  // 16 x 16 output tiles a workspace covers (64 column tiles x 16 row blocks: every split-K launch fits)
 #define GEMM_DECODE_MAX_M 256  // up to this many rows the weight-stream kernel below runs; beyond, the prefill form
@@ -156,7 +157,8 @@ __device__ __forceinline__ float gemm_epilogue(float v, bool ln, float rstd, flo
 // (the round-2 kernel) 16 us, 256 x 56 14 us, 256 x <= 48 VGPRs with <= 56 KB LDS 10 us (5.8 us alone).  Hence: 256 threads,
 // at most 48 VGPRs, a few KB of LDS -- bytes in flight per workgroup are what the registers allow (4 float4 of W and of x
 // per lane), and the launch gets its bandwidth from the NUMBER of workgroups.
-//   * workgroup = 16 rows x 16 columns, 4 waves = 4 K slices; each lane issues the float4 loads of a 64-deep K batch of W
+//   * workgroup = 16 rows x 16 columns (up to 16 rows in the launch; 2 x 2 such blocks beyond: see the template), 4 waves = 4 K
+//     slices; each lane issues the float4 loads of a 64-deep K batch of W
 //     (row n = lane&15, k = k0+4*(lane>>4)+t) and of x (same k map, row = lane&15, served by L2) before the MFMAs of the batch;
 //   * no LDS staging, no barrier in the main loop; the K slices are summed through LDS in a fixed order (wave 0 first;
 //     bitwise reproducible, no float atomics); deep K (>= 2048) also splits over `kz` workgroups (last-arriver reduction);
@@ -169,124 +171,182 @@ __device__ __forceinline__ float gemm_epilogue(float v, bool ln, float rstd, flo
 // -amdgpu-kernarg-preload-count they are delivered in SGPRs when the wave starts (gfx950 kernarg preload), so the weight
 // and activation loads of this latency-bound kernel go out without first waiting for a scalar load of the argument block.
 #define GEMM_WAVES 4
-template <int WNT>   // WNT = 2: weights with the non-temporal policy
+// RB x CB blocks of 16 x 16 outputs per workgroup (round 5).  With one block per workgroup the rows' activations are re-read by
+// every column tile and the weights by every row block: a 64-row step moved 8 x its unique bytes through the CUs' vector-memory
+// pipelines (33.5 MB per 1024 x 1024 layer for 4 MB of weights), and that pipeline -- ~12 bytes per clock and CU, L2 hits
+// included -- is what the token loops and the frame decoder beside them compete for: with those re-reads switched off
+// (CCVS_GEMM_ABLATE=3, wrong results) the bench line went from 213 to 237 frames/s (profiles/r05_gemm_tile_ab.txt).  A 2 x 2 block
+// tile halves both re-reads at 8 + 8 + 16 registers for the two operands and the four accumulators (one 16-deep K batch in
+// flight instead of four: U) -- 32 VGPRs + 16 AGPRs, the same 48; the blocks' arithmetic is the one-block kernel's, bit for bit
+// -- the same K slices per wave, the same MFMA order per block, the same slice order in the reduction -- so a row does not
+// depend on the tile it falls into.  Same box, 20 batches: 210.5 -> 227.8 frames/s, the token step beside the decoder 7.88 ->
+// 7.22 ms, the convolutions beside it 87 -> 95 TFLOP/s; alone the step costs the same (3.17 against 3.25 ms).  Larger tiles
+// (4 x 2, 2 x 4: 112 registers, a quarter of the workgroups) lose: 206-208 frames/s, 4.07 ms alone.
+template <int WNT, int RB, int CB, int U>   // WNT = 2: weights with the non-temporal policy
 __global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __restrict__ x_, const float* __restrict__ w_, long ldx_, int K_, int N_,
                                                                 int M_, int ks_, int kz_, Gemm16 p) {
-    __shared__ __attribute__((aligned(16))) float red[GEMM_WAVES * 64 * 4];
-    __shared__ float stat[GEMM_WAVES * 16 * 2];
-    __shared__ float fin[16 * 2];
+    constexpr int NB = RB * CB;
+    __shared__ __attribute__((aligned(16))) float red[GEMM_WAVES * NB * 64 * 4];
+    __shared__ float stat[GEMM_WAVES * RB * 16 * 2];
+    __shared__ float fin[RB * 16 * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.y * 16, ncol0 = blockIdx.x * 16;
-    const int nrow = min(ncol0 + li, N_ - 1), mrow = min(m0 + li, M_ - 1);  // tails: computed on a valid row, dropped at the store
+    const int m0 = blockIdx.y * 16 * RB, ncol0 = blockIdx.x * 16 * CB;
     const int kper = K_ / (ks_ * kz_);
     const int kbase = blockIdx.z * (K_ / kz_);
     const bool active = wave < ks_;
-    // Buffer loads: a wave-uniform 128-bit descriptor per tensor in SGPRs + ONE 32-bit byte offset per lane and stream (the
+    // Buffer loads: a wave-uniform 128-bit descriptor per tensor in SGPRs + ONE 32-bit byte offset per lane and block (the
     // K position goes into the scalar offset / the instruction's immediate) instead of 64-bit pointer pairs and their
     // adds -- the 48-VGPR budget.  The launcher checks that both tensors stay below 2^31 bytes.
     const unsigned koff = kbase + (active ? wave : 0) * kper + 4 * g;
-    const unsigned wofs = ((unsigned)nrow * (unsigned)K_ + koff) * 4u;
-    const unsigned xofs = ((unsigned)mrow * (unsigned)ldx_ + koff) * 4u;
+    unsigned wofs[CB], xofs[RB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {   // tails: computed on a valid row, dropped at the store
+        const int nrow = (p.ablate & 2) ? 0 : min(ncol0 + 16 * cb + li, N_ - 1);
+        wofs[cb] = ((unsigned)nrow * (unsigned)K_ + koff) * 4u;
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int mrow = (p.ablate & 1) ? 0 : min(m0 + 16 * rb + li, M_ - 1);
+        xofs[rb] = ((unsigned)mrow * (unsigned)ldx_ + koff) * 4u;
+    }
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w_), 0, N_ * K_ * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x_), 0, (int)(M_ * ldx_ * 4), 0x00020000);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float sx = 0.f, sxx = 0.f;
+    f32x4 acc[RB][CB];
+    float sx[RB], sxx[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        sx[rb] = 0.f; sxx[rb] = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = {0.f, 0.f, 0.f, 0.f};
+    }
     if (active) {
-        // full batches: GEMM_U unconditional 16-byte loads of W and of x in flight per lane, then the MFMAs (one accumulator
-        // chain: 16 dependent MFMAs per batch cost a few cycles each, a second chain would cost 4-8 registers)
+        // full batches: U unconditional 16-byte loads per block row of W and of x in flight per lane, then the MFMAs (one
+        // accumulator chain per block: the dependent MFMAs of a chain cost a few cycles each)
         int k0 = 0;
-        for (; k0 + 16 * GEMM_U <= kper; k0 += 16 * GEMM_U) {
-            f32x4 wv[GEMM_U], xv[GEMM_U];
+        for (; k0 + 16 * U <= kper; k0 += 16 * U) {
+            f32x4 wv[CB][U], xv[RB][U];
 #pragma unroll
-            for (int u = 0; u < GEMM_U; ++u) wv[u] = buf_load4<WNT>(wr, wofs, k0 * 4 + 64 * u);
+            for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int u = 0; u < GEMM_U; ++u) xv[u] = buf_load4(xr, xofs, k0 * 4 + 64 * u);
+                for (int u = 0; u < U; ++u) wv[cb][u] = buf_load4<WNT>(wr, wofs[cb], k0 * 4 + 64 * u);
 #pragma unroll
-            for (int u = 0; u < GEMM_U; ++u) {
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][t], wv[u][t], acc, 0, 0, 0);
-                if (p.ln_s) ln_accum(xv[u], sx, sxx);
+                for (int u = 0; u < U; ++u) xv[rb][u] = buf_load4(xr, xofs[rb], k0 * 4 + 64 * u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[rb][u][t], wv[cb][u][t], acc[rb][cb], 0, 0, 0);
+                    if (p.ln_s) ln_accum(xv[rb][u], sx[rb], sxx[rb]);
+                }
             }
         }
         for (; k0 < kper; k0 += 16) {  // remainder (small K only)
-            const f32x4 w1 = buf_load4<WNT>(wr, wofs, k0 * 4);
-            const f32x4 x1 = buf_load4(xr, xofs, k0 * 4);
+            f32x4 w1[CB], x1[RB];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[t], w1[t], acc, 0, 0, 0);
-            if (p.ln_s) ln_accum(x1, sx, sxx);
+            for (int cb = 0; cb < CB; ++cb) w1[cb] = buf_load4<WNT>(wr, wofs[cb], k0 * 4);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) x1[rb] = buf_load4(xr, xofs[rb], k0 * 4);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[rb][t], w1[cb][t], acc[rb][cb], 0, 0, 0);
+                if (p.ln_s) ln_accum(x1[rb], sx[rb], sxx[rb]);
+            }
         }
     }
     if (p.ln_s) {  // lanes li, li+16, li+32, li+48 hold the four k-groups of row li
-        sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
-        sxx += __shfl_xor(sxx, 16, 64); sxx += __shfl_xor(sxx, 32, 64);
-        if (g == 0) { stat[(wave * 16 + li) * 2] = sx; stat[(wave * 16 + li) * 2 + 1] = sxx; }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            float a = sx[rb], b = sxx[rb];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (g == 0) { stat[((wave * RB + rb) * 16 + li) * 2] = a; stat[((wave * RB + rb) * 16 + li) * 2 + 1] = b; }
+        }
     }
-    *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = acc;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<f32x4*>(red + ((wave * NB + rb * CB + cb) * 64 + lane) * 4) = acc[rb][cb];
     __syncthreads();
-    if (p.ln_s && tid < 16) {
+    if (p.ln_s && tid < 16 * RB) {
+        const int rb = tid >> 4, r = tid & 15;
         float a = 0.f, b = 0.f;
-        for (int w = 0; w < GEMM_WAVES; ++w) { a += stat[(w * 16 + tid) * 2]; b += stat[(w * 16 + tid) * 2 + 1]; }
+        for (int w = 0; w < GEMM_WAVES; ++w) { a += stat[((w * RB + rb) * 16 + r) * 2]; b += stat[((w * RB + rb) * 16 + r) * 2 + 1]; }
         float mean, rstd;
         ln_finish(a, b, p.K, p.ln_eps, mean, rstd);
         fin[tid * 2] = mean;
         fin[tid * 2 + 1] = rstd;
     }
     __syncthreads();
-    if (wave > 0) return;  // wave 0 finishes the tile
+    // wave w finishes the blocks w, w + 4, ... (one block per workgroup: wave 0, as before)
+#pragma unroll 1
+    for (int blk = wave; blk < NB; blk += GEMM_WAVES) {
+        const int rb = blk / CB, cb = blk - rb * CB;
+        f32x4 a4 = *reinterpret_cast<const f32x4*>(red + (blk * 64 + lane) * 4);
 #pragma unroll
-    for (int s = 1; s < GEMM_WAVES; ++s) acc += *reinterpret_cast<const f32x4*>(red + (s * 64 + lane) * 4);
+        for (int s = 1; s < GEMM_WAVES; ++s) a4 += *reinterpret_cast<const f32x4*>(red + ((s * NB + blk) * 64 + lane) * 4);
+        const int mb0 = m0 + 16 * rb, nb0 = ncol0 + 16 * cb;
+        if (mb0 >= p.M || nb0 >= p.N) continue;   // a block wholly outside the matrix (ragged row / column counts)
 
-    bool finisher = true;
-    if (p.kz > 1) {
-        // K is also split over gridDim.z workgroups (few output columns: keeps all 256 CUs streaming W).
-        // Each publishes its 16x16 partial, the LAST arriver sums the slabs in slice order (bitwise
-        // reproducible) and runs the epilogue.  The slabs are written and read with agent-scope (sc1)
-        // accesses, which go through to memory and bypass the per-XCD L2s: no release / acquire fence is
-        // needed -- on this chip a fence is an L2 write-back + invalidate costing several us, and all the
-        // hand-off needs is slab stores acknowledged (vmcnt 0) before the ticket, and slab loads after it.
-        const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-        float* slabs = p.ws_slabs + (long)tile * p.kz * 256;
-        float* mine = slabs + (blockIdx.z * 64 + lane) * 4;
+        bool finisher = true;
+        if (p.kz > 1) {
+            // K is also split over gridDim.z workgroups (few output columns: keeps all 256 CUs streaming W).
+            // Each publishes its 16x16 partial, the LAST arriver sums the slabs in slice order (bitwise
+            // reproducible) and runs the epilogue.  The slabs are written and read with agent-scope (sc1)
+            // accesses, which go through to memory and bypass the per-XCD L2s: no release / acquire fence is
+            // needed -- on this chip a fence is an L2 write-back + invalidate costing several us, and all the
+            // hand-off needs is slab stores acknowledged (vmcnt 0) before the ticket, and slab loads after it.
+            const int tile = (mb0 >> 4) * ((p.N + 15) >> 4) + (nb0 >> 4);   // the 16 x 16 block's own slabs and counter
+            float* slabs = p.ws_slabs + (long)tile * p.kz * 256;
+            float* mine = slabs + (blockIdx.z * 64 + lane) * 4;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) __hip_atomic_store(mine + c, acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        int ticket = 0;
-        if (lane == 0) ticket = __hip_atomic_fetch_add(p.ws_count + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ticket = __builtin_amdgcn_readfirstlane(ticket);
-        finisher = ticket == p.kz - 1;
-        if (finisher) {
+            for (int c = 0; c < 4; ++c) __hip_atomic_store(mine + c, a4[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int ticket = 0;
+            if (lane == 0) ticket = __hip_atomic_fetch_add(p.ws_count + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            finisher = ticket == p.kz - 1;
+            if (finisher) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = __hip_atomic_load(slabs + lane * 4 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int z = 1; z < p.kz; ++z) {
+                for (int c = 0; c < 4; ++c) a4[c] = __hip_atomic_load(slabs + lane * 4 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int z = 1; z < p.kz; ++z) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] += __hip_atomic_load(slabs + (z * 64 + lane) * 4 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int c = 0; c < 4; ++c) a4[c] += __hip_atomic_load(slabs + (z * 64 + lane) * 4 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (lane == 0) __hip_atomic_store(p.ws_count + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (lane == 0) __hip_atomic_store(p.ws_count + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-    }
 
-    // D[row = 4*g + r][col = li]
-    const int col = ncol0 + li;
-    if (finisher && col < p.N) {
-        const float bv = p.bias ? p.bias[col] : 0.f;
-        const float sn = p.ln_s ? p.ln_s[col] : 0.f;
+        // D[row = 4*g + r][col = li]
+        const int col = nb0 + li;
+        if (finisher && col < p.N) {
+            const float bv = p.bias ? p.bias[col] : 0.f;
+            const float sn = p.ln_s ? p.ln_s[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + 4 * g + r;
-            if (row >= p.M) continue;
-            const float rv = p.epi == 2 ? p.res[(long)row * p.ldy + col] : 0.f;
-            const float v = gemm_epilogue(acc[r], p.ln_s != nullptr, fin[(4 * g + r) * 2 + 1], fin[(4 * g + r) * 2], sn, bv, p.epi, rv);
-            if (p.kcache && col >= p.C) {
-                const int cc = col - p.C;
-                float* cache = cc >= p.C ? p.vcache : p.kcache;
-                const int c2 = cc >= p.C ? cc - p.C : cc;
-                const int h = c2 / p.D, d = c2 - h * p.D;
-                const int b = row / p.Tq, t = row - b * p.Tq;
-                const int pos = p.pos0 + (p.pos_dev ? p.pos_dev[p.grp_rows > 0 ? b / p.grp_rows : 0] : 0);
-                if (pos + t < p.Tmax) cache[(((long)b * p.H + h) * p.Tmax + pos + t) * p.D + d] = v;
-            } else {
-                p.y[(long)row * p.ldy + col] = v;
+            for (int r = 0; r < 4; ++r) {
+                const int row = mb0 + 4 * g + r;
+                if (row >= p.M) continue;
+                const float rv = p.epi == 2 ? p.res[(long)row * p.ldy + col] : 0.f;
+                const float v = gemm_epilogue(a4[r], p.ln_s != nullptr, fin[(rb * 16 + 4 * g + r) * 2 + 1], fin[(rb * 16 + 4 * g + r) * 2], sn, bv, p.epi, rv);
+                if (p.kcache && col >= p.C) {
+                    const int cc = col - p.C;
+                    float* cache = cc >= p.C ? p.vcache : p.kcache;
+                    const int c2 = cc >= p.C ? cc - p.C : cc;
+                    const int h = c2 / p.D, d = c2 - h * p.D;
+                    const int b = row / p.Tq, t = row - b * p.Tq;
+                    const int pos = p.pos0 + (p.pos_dev ? p.pos_dev[p.grp_rows > 0 ? b / p.grp_rows : 0] : 0);
+                    if (pos + t < p.Tmax) cache[(((long)b * p.H + h) * p.Tmax + pos + t) * p.D + d] = v;
+                } else {
+                    p.y[(long)row * p.ldy + col] = v;
+                }
             }
         }
     }
@@ -594,6 +654,8 @@ static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
         return CCVS_ERR_ARG;
     }
     if (!decode_form && g.grp_rows > 0) { ccvs_set_error("%s: row groups need M <= %d", name, GEMM_DECODE_MAX_M); return CCVS_ERR_ARG; }
+    static const int gemm_ablate = getenv_int("CCVS_GEMM_ABLATE", 0);
+    g.ablate = gemm_ablate;
     g.kz = decode_form ? gemm_kz(g) : 1;
     if (g.kz > 1 && cdiv(g.N, 16) * cdiv(g.M, 16) > GEMM_WS_TILES) g.kz = 1;   // cannot happen for M <= 256 (kz > 1 needs <= 64 column tiles)
     g.ks = decode_form ? GEMM_WAVES : 8;
@@ -604,12 +666,17 @@ static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
         hipLaunchKernelGGL(gemm_seq_kernel, dim3(rt * ct), dim3(256), 0, st, g, rt, ct);
     } else if (!decode_form)
         hipLaunchKernelGGL((gemm16_rb_kernel<4>), dim3(cdiv(g.N, 16), cdiv(g.M, 64), 1), dim3(512), 0, st, g);
-    else if (decode_nt() & 2)
-        hipLaunchKernelGGL(gemm16_kernel<2>, dim3(cdiv(g.N, 16), cdiv(g.M, 16), g.kz), dim3(64 * GEMM_WAVES), 0, st, g.x, g.w, g.ldx, g.K, g.N, g.M, g.ks,
-                           g.kz, g);
-    else
-        hipLaunchKernelGGL(gemm16_kernel<0>, dim3(cdiv(g.N, 16), cdiv(g.M, 16), g.kz), dim3(64 * GEMM_WAVES), 0, st, g.x, g.w, g.ldx, g.K, g.N, g.M, g.ks,
-                           g.kz, g);
+    else {
+        // 2 x 2 blocks of 16 x 16 per workgroup once there are two row blocks (stacked batches) -- the blocks' bits do not depend on the tile
+        static const int tile2 = getenv_int("CCVS_GEMM_TILE2", 1);   // 0: one block per workgroup (rounds 3-4)
+        const bool t2 = tile2 && g.M > 16 && g.N >= 32;
+#define GEMM16_LAUNCH(WNTv, RBv, CBv, Uv)                                                                                                         \
+    hipLaunchKernelGGL((gemm16_kernel<WNTv, RBv, CBv, Uv>), dim3(cdiv(g.N, 16 * CBv), cdiv(g.M, 16 * RBv), g.kz), dim3(64 * GEMM_WAVES), 0, st, g.x, \
+                       g.w, g.ldx, g.K, g.N, g.M, g.ks, g.kz, g)
+        if (decode_nt() & 2) { if (t2) GEMM16_LAUNCH(2, 2, 2, 1); else GEMM16_LAUNCH(2, 1, 1, GEMM_U); }
+        else { if (t2) GEMM16_LAUNCH(0, 2, 2, 1); else GEMM16_LAUNCH(0, 1, 1, GEMM_U); }
+#undef GEMM16_LAUNCH
+    }
     CCVS_CHECK_LAUNCH(name);
     return CCVS_OK;
 }
