@@ -630,10 +630,11 @@ static int decode_nt() {
 static int gemm_kz(const Gemm16& g) {
     static int kz_max = -1;
     if (kz_max < 0) { const char* e = getenv("CCVS_GEMM_KZ_MAX"); kz_max = e ? atoi(e) : 4; }
+    static const int kz_min_k = getenv_int("CCVS_GEMM_KZ_MINK", 2048);   // the shallowest K that is split over workgroups
     const int tiles = cdiv(g.N, 16);
     int kz = 1;
     if (g.ws_slabs && !g.ln_s)
-        while (g.K >= 2048 && kz < kz_max && tiles * kz * 2 <= 256 && g.K % (16 * GEMM_WAVES * kz * 2) == 0) kz *= 2;
+        while (g.K >= kz_min_k && kz < kz_max && tiles * kz * 2 <= 256 && g.K % (16 * GEMM_WAVES * kz * 2) == 0) kz *= 2;
     return kz;
 }
 
