@@ -623,12 +623,16 @@ def main():
                     n_new = min(n_tok, xopt.z_len - xopt.cond_len)
                     probe.generate(code0, 24, sample=True, top_k=xopt.top_k, temperature=xopt.temperature, noise="device")   # capture
                     torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    probe.generate(code0, n_new, sample=True, top_k=xopt.top_k, temperature=xopt.temperature, noise="device")
-                    torch.cuda.synchronize()
-                    alone_ms = 1e3 * (time.perf_counter() - t0) / n_new
+                    loops_ms = []
+                    for _ in range(2):     # two loops, the faster one reported: one in four single loops came out at 9.4 instead of 3.2 ms per step
+                        t0 = time.perf_counter()
+                        probe.generate(code0, n_new, sample=True, top_k=xopt.top_k, temperature=xopt.temperature, noise="device")
+                        torch.cuda.synchronize()
+                        loops_ms.append(1e3 * (time.perf_counter() - t0) / n_new)
+                    alone_ms = min(loops_ms)
                     line["roofline_token_loop"]["alone"] = {
-                        "ms_per_step": alone_ms, "rows": g_rows, "tokens": n_new, "in_run_over_alone": line["roofline_token_loop"]["ms_per_step"] / alone_ms,
+                        "ms_per_step": alone_ms, "loops_ms_per_step": [round(v, 3) for v in loops_ms],
+                        "rows": g_rows, "tokens": n_new, "in_run_over_alone": line["roofline_token_loop"]["ms_per_step"] / alone_ms,
                         "frac": (w_bytes + n_g * kv_bytes) / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                         "note": f"one loop over {g_rows} stacked rows ({n_g} batches), prefill of the conditioning frame included, nothing beside it; "
                                 "in the timed region the same step shares the chip with the other token loop and two decodes"}

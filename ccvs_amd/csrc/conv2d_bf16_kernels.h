@@ -21,6 +21,17 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// The 16-byte stores of the epilogues.  -DCB_STORE_WT (an experiment, tools/r05/store_wt_ab.sh): write-through (`sc1`) -- the output
+// tile leaves no dirty lines in the XCD's L2, so the write-back at the END of every other kernel on the chip (the release at a
+// kernel boundary: 123 per token step beside these convolutions) finds nothing of ours to flush.
+#ifdef CB_STORE_WT
+__device__ __forceinline__ void cb_store16(void* dst, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+}
+#else
+__device__ __forceinline__ void cb_store16(void* dst, f32x4 v) { *reinterpret_cast<f32x4*>(dst) = v; }
+#endif
+__device__ __forceinline__ void cb_store16(void* dst, uint4 v) { cb_store16(dst, f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)}); }
 
 #define CB_CC 16      // input channels per chunk = one MFMA K step
 #define CB_MAX_E 5
@@ -1070,8 +1081,8 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
             uint4 hi, lo;                                                                      \
             split8(v, hi, lo);                                                                 \
             uint4* dst = y4 + ((long)n * gout + (co0_ >> 3)) * 2 * hw_out + opix_;             \
-            dst[0] = hi;                                                                       \
-            dst[hw_out] = lo;                                                                  \
+            cb_store16(dst, hi);                                                               \
+            cb_store16(dst + hw_out, lo);                                                      \
         }                                                                                      \
     }
                 if (p.pre) {
@@ -1139,7 +1150,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
             t = (t + (ADD2)) * p.out_scale;                                                          \
             v[j] = t + (ADD3);                                                                       \
         }                                                                                            \
-        *reinterpret_cast<float4*>(ybase + (long)co_ * p.out_sC + opix_) = make_float4(v[0], v[1], v[2], v[3]); \
+        cb_store16(ybase + (long)co_ * p.out_sC + opix_, f32x4{v[0], v[1], v[2], v[3]});           \
     }
                 if (add_kind == 0) {
                     CB_EPI_FINISH(0.f, 0.f, 0.f)
@@ -1175,7 +1186,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
                         v[j] = (t + 0.f) * p.out_scale + 0.f;
                     }
                     if (nv == 4 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
-                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        cb_store16(dst, f32x4{v[0], v[1], v[2], v[3]});
                     } else {
                         _Pragma("unroll") for (int j = 0; j < 4; ++j) if (j < nv) dst[j] = v[j];
                     }
@@ -1217,7 +1228,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
                         v[j] = t + (add_kind == 3 ? ad[i][j] : 0.f);
                     }
                     if (nv == 4 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
-                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        cb_store16(dst, f32x4{v[0], v[1], v[2], v[3]});
                     } else {
                         _Pragma("unroll") for (int j = 0; j < 4; ++j) if (j < nv) dst[j] = v[j];
                     }
@@ -1262,7 +1273,7 @@ __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) vo
                         v[j] = t + ov[j];
                     }
                     if (vec) {
-                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        cb_store16(dst, f32x4{v[0], v[1], v[2], v[3]});
                     } else {
                         _Pragma("unroll") for (int j = 0; j < 4; ++j) if (j < nv) dst[j] = v[j];
                     }
