@@ -17,15 +17,21 @@ timeout 600 python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-strict-
 timeout 300 python3 tools/mem_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_mem_bench.txt
 python3 tools/conv_shape_census.py 2>&1 | grep -v Loading > $OUT/${TAG}_conv_shape_census.txt
 timeout 300 python3 tools/token_step_probe.py 480 16 32 48 64 2>&1 | grep rows > $OUT/${TAG}_token_step_probe.txt
+QUICK=${2:-}
 cd /tmp && export TMPDIR=/tmp
 export CCVS_BENCH_SUPERVISE=0   # (bench.py also recognises the profiler's preload by itself)
 for SCHED in pipelined serial; do
   rm -rf /tmp/prof_$SCHED
+  for TRY in 1 2 3; do   # (rocprofv3 itself segfaults at start-up every other time on this image: the bench never ran then)
+  rm -rf /tmp/prof_$SCHED
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$SCHED -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strict-f32 --no-encode-cond-leg --schedule $SCHED > /tmp/prof_$SCHED.log 2>&1
+  ls /tmp/prof_$SCHED/*/*kernel_stats.csv > /dev/null 2>&1 && break
+  done
   cp $(ls /tmp/prof_$SCHED/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_${SCHED}_kernel_stats.csv
   grep "^{" /tmp/prof_$SCHED.log | tail -1 > $OUT/${TAG}_bench_${SCHED}_under_rocprof.json
 done
 unset CCVS_BENCH_SUPERVISE
+if [ "$QUICK" = "quick" ]; then ls -la $OUT | tail -20; exit 0; fi   # the PMC passes below: only when their kernels changed
 SHAPE="195 128 3 256 240" timeout 900 bash $ROOT/tools/pmc_conv_counters.sh > $OUT/${TAG}_pmc_conv_counters.txt 2>&1
 SHAPE="128 64 3 256 240" timeout 900 bash $ROOT/tools/pmc_conv_counters.sh > $OUT/${TAG}_pmc_conv_counters_128to64.txt 2>&1
 SHAPE="128 64 3 256 240 p8" timeout 900 bash $ROOT/tools/pmc_conv_counters.sh > $OUT/${TAG}_pmc_conv_counters_128to64_packed.txt 2>&1
