@@ -121,7 +121,6 @@ struct Gemm16 {
     int kz;            // K slices across workgroups (gridDim.z); > 1 only with a workspace
     float* ws_slabs;   // [tile][kz][64 lanes][4] partial accumulators
     int* ws_count;     // [tile] arrival counters, zero between launches
-    int ablate;        // timing experiments (CCVS_GEMM_ABLATE; results are wrong): 1: every lane reads x row 0, 2: every lane reads W row 0
 };
 
 #define GEMM_U 4  // one-block form: K steps (of 16) whose loads are issued together (4 float4 of W + 4 of x per lane: the 48-VGPR budget)
@@ -175,7 +174,7 @@ __device__ __forceinline__ float gemm_epilogue(float v, bool ln, float rstd, flo
 // every column tile and the weights by every row block: a 64-row step moved 8 x its unique bytes through the CUs' vector-memory
 // pipelines (33.5 MB per 1024 x 1024 layer for 4 MB of weights), and that pipeline -- ~12 bytes per clock and CU, L2 hits
 // included -- is what the token loops and the frame decoder beside them compete for: with those re-reads switched off
-// (CCVS_GEMM_ABLATE=3, wrong results) the bench line went from 213 to 237 frames/s (profiles/r05_gemm_tile_ab.txt).  A 2 x 2 block
+// (every lane reading row 0 of x and of W -- wrong results; an experiment switch of the round, removed again: reading it cost the one-block form 0.5 us in front of its first load) the bench line went from 213 to 237 frames/s (profiles/r05_gemm_tile_ab.txt).  A 2 x 2 block
 // tile halves both re-reads at 8 + 8 + 16 registers for the two operands and the four accumulators (one 16-deep K batch in
 // flight instead of four: U) -- 32 VGPRs + 16 AGPRs, the same 48; the blocks' arithmetic is the one-block kernel's, bit for bit
 // -- the same K slices per wave, the same MFMA order per block, the same slice order in the reduction -- so a row does not
@@ -202,12 +201,12 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __
     unsigned wofs[CB], xofs[RB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {   // tails: computed on a valid row, dropped at the store
-        const int nrow = (p.ablate & 2) ? 0 : min(ncol0 + 16 * cb + li, N_ - 1);
+        const int nrow = min(ncol0 + 16 * cb + li, N_ - 1);
         wofs[cb] = ((unsigned)nrow * (unsigned)K_ + koff) * 4u;
     }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-        const int mrow = (p.ablate & 1) ? 0 : min(m0 + 16 * rb + li, M_ - 1);
+        const int mrow = min(m0 + 16 * rb + li, M_ - 1);
         xofs[rb] = ((unsigned)mrow * (unsigned)ldx_ + koff) * 4u;
     }
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w_), 0, N_ * K_ * 4, 0x00020000);
@@ -234,6 +233,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int u = 0; u < U; ++u) xv[rb][u] = buf_load4(xr, xofs[rb], k0 * 4 + 64 * u);
+            __builtin_amdgcn_sched_barrier(0);   // every load of the batch goes out before its first MFMA (hipcc otherwise sinks half of them between the MFMAs)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -655,8 +655,6 @@ static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
         return CCVS_ERR_ARG;
     }
     if (!decode_form && g.grp_rows > 0) { ccvs_set_error("%s: row groups need M <= %d", name, GEMM_DECODE_MAX_M); return CCVS_ERR_ARG; }
-    static const int gemm_ablate = getenv_int("CCVS_GEMM_ABLATE", 0);
-    g.ablate = gemm_ablate;
     g.kz = decode_form ? gemm_kz(g) : 1;
     if (g.kz > 1 && cdiv(g.N, 16) * cdiv(g.M, 16) > GEMM_WS_TILES) g.kz = 1;   // cannot happen for M <= 256 (kz > 1 needs <= 64 column tiles)
     g.ks = decode_form ? GEMM_WAVES : 8;
@@ -670,7 +668,7 @@ static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
     else {
         // 2 x 2 blocks of 16 x 16 per workgroup once there are two row blocks (stacked batches) -- the blocks' bits do not depend on the tile
         static const int tile2 = getenv_int("CCVS_GEMM_TILE2", 1);   // 0: one block per workgroup (rounds 3-4)
-        const bool t2 = tile2 && g.M > 16 && g.N >= 32;
+        const bool t2 = tile2 && g.M > 32 && g.N >= 32;   // from three row blocks on: with two, N / 32 workgroups are too few alone (2.03 against 1.53 ms per step)
 #define GEMM16_LAUNCH(WNTv, RBv, CBv, Uv)                                                                                                         \
     hipLaunchKernelGGL((gemm16_kernel<WNTv, RBv, CBv, Uv>), dim3(cdiv(g.N, 16 * CBv), cdiv(g.M, 16 * RBv), g.kz), dim3(64 * GEMM_WAVES), 0, st, g.x, \
                        g.w, g.ldx, g.K, g.N, g.M, g.ks, g.kz, g)
