@@ -287,10 +287,13 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __
     }
     __syncthreads();
     // wave w finishes the blocks w, w + 4, ... (one block per workgroup: wave 0, as before)
+    if (NB == 1 && wave > 0) return;
 #pragma unroll 1
     for (int blk = wave; blk < NB; blk += GEMM_WAVES) {
         const int rb = blk / CB, cb = blk - rb * CB;
-        f32x4 a4 = *reinterpret_cast<const f32x4*>(red + (blk * 64 + lane) * 4);
+        f32x4 a4;
+        if constexpr (NB == 1) a4 = acc[0][0];   // (wave 0: its own slice is still in registers)
+        else a4 = *reinterpret_cast<const f32x4*>(red + (blk * 64 + lane) * 4);
 #pragma unroll
         for (int s = 1; s < GEMM_WAVES; ++s) a4 += *reinterpret_cast<const f32x4*>(red + ((s * NB + blk) * 64 + lane) * 4);
         const int mb0 = m0 + 16 * rb, nb0 = ncol0 + 16 * cb;
