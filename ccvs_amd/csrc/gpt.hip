@@ -10,10 +10,18 @@
 // (mingpt.py:234-236,242-244; the factored s_emb/t_emb (+delta_length) or flat pos_emb rows
 // are pre-summed by the host into pos_table once per call).
 // ---------------------------------------------------------------------------------------
+// -DCCVS_TOKEN_PRIO=n (an experiment, tools/r05/token_prio_ab.sh): the kernels of a decode step raise their waves' issue priority --
+// they are few, short and mostly waiting on memory, beside convolution waves that issue MFMAs back to back.
+#ifdef CCVS_TOKEN_PRIO
+#define TOKEN_PRIO() __builtin_amdgcn_s_setprio(CCVS_TOKEN_PRIO)
+#else
+#define TOKEN_PRIO() ((void)0)
+#endif
 __global__ __launch_bounds__(256) void gpt_embed_kernel(const int64_t* __restrict__ idx, long idx_sB, const int32_t* __restrict__ pos_off,
                                                         int pos0, const int32_t* __restrict__ pos_dev, int grp_rows, int Tq,
                                                         const float* __restrict__ tok, const float* __restrict__ pos,
                                                         float* __restrict__ x, long total, int C, int vocab) {
+    TOKEN_PRIO();
     // device-resident position: lets a captured hipGraph replay at advancing positions; with row groups (grp_rows > 0)
     // batch row b reads the word of its group, pos_dev[b / grp_rows]
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -184,6 +192,7 @@ __device__ __forceinline__ float gemm_epilogue(float v, bool ln, float rstd, flo
 template <int WNT, int RB, int CB, int U>   // WNT = 2: weights with the non-temporal policy
 __global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __restrict__ x_, const float* __restrict__ w_, long ldx_, int K_, int N_,
                                                                 int M_, int ks_, int kz_, Gemm16 p) {
+    TOKEN_PRIO();
     constexpr int NB = RB * CB;
     __shared__ __attribute__((aligned(16))) float red[GEMM_WAVES * NB * 64 * 4];
     __shared__ float stat[GEMM_WAVES * RB * 16 * 2];
@@ -949,6 +958,7 @@ template <int D, bool NT>
 __global__ __launch_bounds__(256) void attention_decode_kernel(const float* __restrict__ q, long q_sB, const float* __restrict__ kc,
                                                                const float* __restrict__ vc, float* __restrict__ out, int H, int pos0,
                                                                const int32_t* __restrict__ pos_dev, int grp_rows, int Tmax, float scale) {
+    TOKEN_PRIO();
     constexpr int LPK = D / 4;     // lanes per key row
     constexpr int KPI = 64 / LPK;  // key rows per wave-instruction
     constexpr int NW = 4;
@@ -1142,6 +1152,7 @@ __device__ __forceinline__ unsigned kth_largest_key(const float* xs, int V, int 
 __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restrict__ logits, long ld, const float* __restrict__ noise,
                                                           int64_t* __restrict__ out, long out_stride, int V, int top_k, float temperature,
                                                           Advance adv) {
+    TOKEN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                  // [V]
     float* redf = smem + V;            // [4]

@@ -36,6 +36,18 @@ for q, rr in sorted(byq.items(), key=lambda kv: -len(kv[1])):
         st = stat[n]
         st[0] += 1; st[1] += e - s; st[2] += max(gap, 0); st[3].append(gap)
     print(f"queue {q}: {len(rr)} dispatches, span {span / 1e6:.1f} ms, kernels {100.0 * busy / span:.1f} % of it")
+    edges = [0, 5e3, 20e3, 100e3, 1e6, 10e6, 1e12]
+    hist = [[0, 0] for _ in edges[:-1]]
+    for i in range(1, len(rr)):
+        gap = rr[i][0] - rr[i - 1][1]
+        if gap <= 0:
+            continue
+        for b in range(len(hist)):
+            if edges[b] <= gap < edges[b + 1]:
+                hist[b][0] += 1; hist[b][1] += gap
+                break
+    print("    gaps between consecutive kernels (<5 us, 5-20, 20-100, 100 us-1 ms, 1-10 ms, >10 ms): "
+          + "   ".join(f"{c} x = {100.0 * t / span:.1f} %" for c, t in hist))
     for n, (c, d, g, gl) in sorted(stat.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))[:8]:
         gl.sort()
         print(f"    {n:48s} {c:7d} x  kernel {d / c / 1e3:8.1f} us   gap before it: mean {g / c / 1e3:7.1f} us, median {gl[len(gl) // 2] / 1e3:6.1f}, p90 {gl[int(0.9 * len(gl))] / 1e3:6.1f}")
