@@ -4,10 +4,30 @@
 #include "common.h"
 #include "conv_common.h"
 #include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
 
 #define CB_DECL(TWv, MBv) int ccvs_conv_bf16_launch_##TWv##_##MBv(const ConvK& k, const void* wsplit, const void* wktail, int CinG, int halo_h, int halo_w, int ntx_max, int gz, hipStream_t st, int wpc2);
 CB_DECL(32, 4) CB_DECL(32, 2) CB_DECL(32, 1) CB_DECL(16, 4) CB_DECL(16, 2) CB_DECL(16, 1) CB_DECL(8, 4) CB_DECL(8, 2) CB_DECL(8, 1)
 #undef CB_DECL
+
+// How many bytes per lane the ACTIVATION fetches of a convolution kernel of this library read at a time, by the kernel's name as
+// rocprofv3 prints it (`conv2d_bf16x3_pc_kernel<32, 2, -83, 4, 1>`): 16 (aligned dwordx4 rows / LDS-DMA), 4 (dword by dword: the
+// scalar staging modes, the synchronous split-bf16 kernel and the fp32-MFMA kernel), -1 for a name this library does not know --
+// the caller must then stop instead of guessing.  Pure host code (no GPU call): tools/pmc_widths.py and its CPU test use it to
+// apply gfx950's FETCH_SIZE correction (a 16-byte-per-lane stream is tallied at half its bytes) per instantiation.
+extern "C" int ccvs_conv_fetch_bytes_per_lane(const char* kernel_name) {
+    if (!kernel_name) return -1;
+    const char* pc = strstr(kernel_name, "conv2d_bf16x3_pc_kernel<");
+    if (pc) {
+        int tw = 0, mb = 0, nty = 0;
+        if (sscanf(pc + strlen("conv2d_bf16x3_pc_kernel<"), " %d , %d , %d", &tw, &mb, &nty) != 3) return -1;
+        const int b = conv_nty_fetch_bytes(nty);
+        return b ? b : -1;
+    }
+    if (strstr(kernel_name, "conv2d_bf16x3_kernel<") || strstr(kernel_name, "conv2d_mfma_kernel")) return 4;
+    return -1;
+}
 
 extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const float* bias, const float* residual, float* y,
                                   const ccvs_conv_desc* d, void* stream) {

@@ -324,11 +324,12 @@ template <int TW, int MB, int NTY, int PP = 2, int WPC = 1>
 __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
     static_assert(WPC == 1 || (WPC == 2 && MB == 2 && PP == 2 && NTY == 3), "two workgroups per CU: the 64-channel 3 x 3 form only");
     static_assert(PP == 2 || (PP == 4 && (NTY > 0 || NTY == -83) && MB == 2), "the 512-pixel tile exists for the VEC / packed staging modes and 64 output channels");
-    constexpr bool VEC = NTY > 0;
+    static_assert(conv_nty_fetch_bytes(NTY) != 0, "unknown staging mode: classify it in conv_common.h (conv_nty_*)");
+    constexpr bool VEC = conv_nty_vec(NTY);
     // NTY == -8: the input is a packed split-bf16 activation (P8: [N][C/8][hi|lo][H][W] x 8 bf16, written by the epilogue of
     // the producing convolution): its halo tile is already in the LDS image's format, so the staging waves only issue
     // LDS-DMA (global_load_lds_dwordx4, zero source outside the image) -- no registers, no conversion.
-    constexpr bool P8IN = NTY == -8 || NTY == -83;   // -83: packed input AND three tap rows known at compile time (3 x 3 layers)
+    constexpr bool P8IN = conv_nty_p8(NTY);   // -83: packed input AND three tap rows known at compile time (3 x 3 layers)
     constexpr bool TAP3 = NTY == 3 || NTY == -83;    // the tap loop of the MFMA waves written out
     constexpr bool DMAW = VEC || P8IN;   // weights by LDS-DMA from the MFMA waves
     constexpr int CB_XQ = (NTY == -2) ? 2 : 1;  // scalar staging: halo-tile pixel passes per thread and step (passes <= CB_XQ * nt)

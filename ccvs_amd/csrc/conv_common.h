@@ -34,6 +34,16 @@ struct ConvK {
 #endif
 };
 
+// Staging mode of a producer / consumer instantiation (template parameter NTY of conv2d_bf16x3_pc_kernel, described at the kernel):
+// which modes fetch their activations 16 bytes per lane (aligned global_load_dwordx4 or LDS-DMA) and which dword by dword.  One
+// definition for the kernel and for ccvs_conv_fetch_bytes_per_lane (the HBM-counter scripts under tools/ ask the LIBRARY how an
+// instantiation reads instead of keeping a list of their own: on gfx950 FETCH_SIZE tallies a 16-byte-per-lane stream at half its
+// bytes, MI355X_MICROARCH.md "HBM").
+constexpr bool conv_nty_vec(int nty) { return nty == 1 || nty == 3; }        // fp32 rows by dwordx4, weights by LDS-DMA
+constexpr bool conv_nty_p8(int nty) { return nty == -8 || nty == -83; }      // packed split-bf16 input: everything by LDS-DMA
+constexpr bool conv_nty_scalar(int nty) { return nty == 0 || nty == -2; }    // halo elements dword by dword
+constexpr int conv_nty_fetch_bytes(int nty) { return (conv_nty_vec(nty) || conv_nty_p8(nty)) ? 16 : (conv_nty_scalar(nty) ? 4 : 0); }
+
 // Tile coordinates of a workgroup.  Workgroups are handed to the 8 XCDs round-robin in dispatch order (linear id % 8), and
 // each XCD has its own L2: with the identity mapping the 8 neighbours of a tile -- whose halo rows and columns it shares --
 // are all fetched through OTHER L2s.  The linear id is therefore re-mapped so that XCD j walks the j-th contiguous eighth

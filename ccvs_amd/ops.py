@@ -24,16 +24,16 @@ class KernelTimer:
         self.records = []  # (name, algorithmic flops, start event, end event)
         self._open = None
 
-    def begin(self, name, flops=0.0, nbytes=0.0):
+    def begin(self, name, flops=0.0, nbytes=0.0, side=0.0, tag=None):
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        self._open = (name, flops, e0, nbytes)
+        self._open = (name, flops, e0, nbytes, side, tag)
 
     def end(self):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        name, flops, e0, nbytes = self._open
-        self.records.append((name, flops, e0, e1, nbytes))
+        name, flops, e0, nbytes, side, tag = self._open
+        self.records.append((name, flops, e0, e1, nbytes, side, tag))
 
     def summary(self, name):
         """(launches, total algorithmic flops, total milliseconds) -- call after a device sync."""
@@ -43,6 +43,11 @@ class KernelTimer:
     def total_bytes(self, name):
         """Algorithmic bytes (inputs read once + outputs written once) of the launches called `name`."""
         return sum(r[4] for r in self.records if r[0] == name)
+
+    def total_side_bytes(self, name):
+        """The other operands of the same launches, each counted once: weights (split-bf16: 4 bytes per element), the residual,
+        the pre-activation addend (`pre`: one image per `pre_div` outputs) and the old output of an accumulating launch."""
+        return sum(r[5] for r in self.records if r[0] == name)
 
 
 KERNEL_TIMER = None  # set to a KernelTimer() to time conv launches
@@ -219,7 +224,11 @@ def conv2d(x, w_packed, bias, cout, k, stride=1, pad=0, transposed=False, act=Fa
     prof = KERNEL_TIMER
     if prof is not None:
         macs = n * cout * cin * k * kw * (h * w if transposed else ho * wo)
-        prof.begin("conv2d_" + w_packed.kind, flops=2.0 * macs, nbytes=4.0 * (n * cin * h * w + n * cout * ho * wo))
+        side = 4.0 * (cin * cout * k * kw + n * cout * ho * wo * ((residual is not None) + bool(accumulate))
+                      + (n // pre_div * cout * ho * wo if pre is not None else 0))
+        prof.begin("conv2d_" + w_packed.kind, flops=2.0 * macs, nbytes=4.0 * (n * cin * h * w + n * cout * ho * wo), side=side,
+                   tag=(n, cin, h, w, cout, k, kw, stride, int(bool(transposed)), int(in_p8), int(bool(out_p8)), int(pre is not None),
+                        int(residual is not None), int(bool(accumulate))))
     fn = L.ccvs_conv2d if w_packed.kind == "f32" else L.ccvs_conv2d_bf16x3
     _lib.check(fn(_p(x.data if in_p8 else x), _p(w_packed.data), _p(bias), _p(residual), _p(out), C.byref(d), _stream()),
                "ccvs_conv2d[" + w_packed.kind + "]")

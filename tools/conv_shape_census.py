@@ -22,9 +22,9 @@ data = {"vid": gen.synthetic_batch(batch, seed=1)["vid"].cuda()}
 
 
 class Census(ops.KernelTimer):
-    def begin(self, name, flops=0.0, nbytes=0.0):
-        super().begin(name, flops, nbytes)
-        self._open = (self._key, flops, self._open[2], nbytes)
+    def begin(self, name, flops=0.0, nbytes=0.0, side=0.0, tag=None):
+        super().begin(name, flops, nbytes, side, tag)
+        self._open = (self._key, flops, self._open[2], nbytes, side, tag)
 
 
 census = Census()
@@ -50,7 +50,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
     ops.KERNEL_TIMER = None
 agg = defaultdict(lambda: [0, 0.0, 0.0, 0.0, 0])
-for key, flops, e0, e1, nbytes in census.records:
+for key, flops, e0, e1, nbytes, _side, _tag in census.records:
     a = agg[(key[0][1:],) + key[1:]]          # launches that differ only in the number of images are folded together
     a[0] += 1
     a[1] += e0.elapsed_time(e1)
