@@ -10,7 +10,7 @@
 // (mingpt.py:234-236,242-244; the factored s_emb/t_emb (+delta_length) or flat pos_emb rows
 // are pre-summed by the host into pos_table once per call).
 // ---------------------------------------------------------------------------------------
-// -DCCVS_TOKEN_PRIO=n (an experiment, tools/r05/token_prio_ab.sh): the kernels of a decode step raise their waves' issue priority --
+// -DCCVS_TOKEN_PRIO=n (an experiment, tools/r05/prio_ab.sh): the kernels of a decode step raise their waves' issue priority --
 // they are few, short and mostly waiting on memory, beside convolution waves that issue MFMAs back to back.
 #ifdef CCVS_TOKEN_PRIO
 #define TOKEN_PRIO() __builtin_amdgcn_s_setprio(CCVS_TOKEN_PRIO)

@@ -330,14 +330,18 @@ class Generator:
         return max(1, min(int(lanes), min(max_rows, 256) // max(batch, 1)))
 
     @staticmethod
-    def _lanes_that_fit(lanes, chains, batch, height, width, total_bytes, frac=0.7, bytes_per_clip_pixel=10.0e3, taken=0, dec_streams=2):
+    def _lanes_that_fit(lanes, chains, batch, height, width, total_bytes, frac=0.7, bytes_per_clip_pixel=10.0e3, taken=0, dec_streams=2,
+                        noise_bytes_per_batch=0.0):
         """Lanes per token group such that the batches in flight -- up to lanes x (chains + 2): two groups in the token loops, one
         encoded behind them, one being decoded -- fit `frac` of the device memory minus what OTHER processes hold on the device
         (`taken`).  A batch in flight holds its context rings, skip features, token caches and the decoder's intermediates: ~10 KB
         per clip and pixel measured with two decode streams (BAIR: 174 GB at 16 batches of 16 x 256^2 in flight, weights and
         captured steps included); every decode stream beyond two keeps one more batch's decoder intermediates alive (~1/4 of a
-        batch each).  BAIR at batch 16 keeps 4 lanes on 288 GB; batch 32 gets 2."""
-        per_batch = float(batch) * height * width * bytes_per_clip_pixel
+        batch each).  BAIR at batch 16 keeps 4 lanes on 288 GB; batch 32 gets 2.
+        `noise_bytes_per_batch`: the pre-drawn host noise stream of a batch (steps x B x V x 4 bytes, up to CCVS_NOISE_STREAM_MAX_MB),
+        resident on the device (and pinned on the host) for every batch in flight -- 63 MB for BAIR, but 1 GB per batch just under the
+        cap: 16 GB unaccounted at 16 batches in flight before round 6."""
+        per_batch = float(batch) * height * width * bytes_per_clip_pixel + float(noise_bytes_per_batch)
         extra = 0.25 * max(0, dec_streams - 2) * per_batch
         while lanes > 1 and lanes * (chains + 2) * per_batch + extra > frac * total_bytes - taken:
             lanes -= 1

@@ -89,7 +89,10 @@ class NoiseFeed:
         n = int(os.environ.get("CCVS_NOISE_DRAWERS", "4")) if drawers is None else int(drawers)
         self.parallel = n > 0 and self._skip_matches_draw()
         self.requests, self.work = queue.Queue(), queue.Queue()
-        self.pending = 0
+        self.pending = 0          # requests not yet drawn (uploaded): decremented by whoever drew them
+        self.unskipped = 0        # requests whose values the skipper has not yet counted off on `cursor`
+        self.failed = None        # sticky: the exception that left `cursor` in an unknown place
+        self.timeout = float(os.environ.get("CCVS_PIPELINE_TIMEOUT", "600"))
         self.idle = threading.Condition()
         self.threads = [threading.Thread(target=self._skipper, name="ccvs-noise-skipper", daemon=True)]
         if self.parallel:
@@ -113,21 +116,34 @@ class NoiseFeed:
     def request(self, rows, steps, width):
         ticket = {"rows": rows, "steps": steps, "width": width, "done": threading.Event(), "event": None, "noise": None, "error": None}
         with self.idle:
+            if self.failed is not None:    # the cursor stands in the wrong place since a skip failed: serve nothing from it
+                raise RuntimeError("NoiseFeed: an earlier request failed while its values were counted off; the noise stream is lost") from self.failed
             self.pending += 1
+            self.unskipped += 1
         self.requests.put(ticket)
         return ticket
 
+    def _settled(self):
+        """Every request so far has been DRAWN (`pending`: the drawers) and COUNTED OFF on the cursor (`unskipped`: the skipper).  The two
+        finish in either order -- a drawer runs `exponential_`, the skipper the cheaper `random_`, but with pinned cores, launch threads
+        and torch's pool competing nothing says the skipper wins -- and the cursor is only at the start of the next request once the
+        skipper is through (`pending == 0` alone let drain() publish a mid-stream cursor)."""
+        return self.pending == 0 and self.unskipped == 0
+
     def drain(self):
-        """Wait until every request so far has been drawn and move the process generator behind them (another consumer of the
-        generator is about to draw)."""
+        """Wait until every request so far has been drawn and counted off, and move the process generator behind them (another
+        consumer of the generator is about to draw)."""
         with self.idle:
-            self.idle.wait_for(lambda: self.pending == 0)
+            if not self.idle.wait_for(lambda: self._settled() or self.failed is not None, timeout=self.timeout):
+                raise RuntimeError(f"NoiseFeed.drain: requests still pending after {self.timeout:.0f} s")
+            if self.failed is not None:
+                raise RuntimeError("NoiseFeed: a request failed while its values were counted off; the generator's position is unknown") from self.failed
             self.real.set_state(self.cursor.get_state())
 
     def resync(self):
         """After `drain()` and the other consumer's draws: the next request starts where the process generator now stands."""
         with self.idle:
-            assert self.pending == 0
+            assert self._settled()
             self.cursor.set_state(self.real.get_state())
 
     def close(self):
@@ -137,12 +153,21 @@ class NoiseFeed:
             self.work.put(None)
         for th in self.threads[1:]:
             th.join(60.0)
+        if self.failed is not None:
+            raise RuntimeError("NoiseFeed: a request failed while its values were counted off; the generator was left where the run found it") from self.failed
+        if self.threads[0].is_alive():     # still counting: its cursor is mid-stream
+            raise RuntimeError("NoiseFeed.close: the skipper thread did not finish within 60 s; the generator was left where the run found it")
         self.real.set_state(self.cursor.get_state())
 
     def _finish(self, t):
         t["done"].set()
         with self.idle:
             self.pending -= 1
+            self.idle.notify_all()
+
+    def _skipped(self):
+        with self.idle:
+            self.unskipped -= 1
             self.idle.notify_all()
 
     def _draw(self, t, gen):
@@ -166,19 +191,32 @@ class NoiseFeed:
             t = self.requests.get()
             if t is None:
                 return
+            if self.failed is not None:       # sticky: every later ticket carries the error instead of noise from a misplaced cursor
+                t["error"] = self.failed
+                self._finish(t)
+                self._skipped()
+                continue
             if not self.parallel:
                 self._draw(t, self.cursor)
+                if t["error"] is not None:
+                    self.failed = t["error"]
+                self._skipped()
                 continue
             state = self.cursor.get_state()
-            self.work.put((t, state))
             left = t["steps"] * t["rows"] * t["width"]
             try:
+                self.work.put((t, state))
                 while left > 0:           # count the stream's values off on the cursor: where the next request starts
                     n = min(left, self.SKIP_CHUNK)
-                    torch.empty(n, dtype=torch.int64).random_(generator=self.cursor)
+                    self._skip(n)
                     left -= n
             except BaseException as exc:   # (out of host memory ...): the tickets behind this one would start in the wrong place
-                t["error"] = exc
+                self.failed = exc
+            finally:
+                self._skipped()
+
+    def _skip(self, n):
+        torch.empty(n, dtype=torch.int64).random_(generator=self.cursor)
 
     def _drawer(self):
         torch.cuda.set_device(self.device)
@@ -372,8 +410,14 @@ class PipelinedRun:
         nb = first["vid"].shape[0]
         free, total = torch.cuda.mem_get_info(self.dev)
         foreign = max(0, total - free - torch.cuda.memory_reserved(self.dev))     # held by other processes on this device
+        noise_bytes = 0.0
+        if self.noise_streams:      # every batch in flight holds its pre-drawn stream [steps, B, V] on the device
+            size = self.frame_tokens
+            steps = self.opt.vid_len * size - int(self.opt.cond_len) - (size if self.opt.p2p else 0)
+            noise_bytes = 4.0 * max(steps, 0) * nb * gen.transformer_model.net_t.head.weight.shape[0]
         fit = gen._lanes_that_fit(self.lanes, self.chains, nb, first["vid"].shape[-2], first["vid"].shape[-1], total,
-                                  frac=float(os.environ.get("CCVS_PIPELINE_MEM_FRAC", "0.7")), taken=foreign, dec_streams=len(self.dec_streams))
+                                  frac=float(os.environ.get("CCVS_PIPELINE_MEM_FRAC", "0.7")), taken=foreign, dec_streams=len(self.dec_streams),
+                                  noise_bytes_per_batch=noise_bytes)
         if fit < self.lanes:
             print(f"[pipeline] {self.lanes} -> {fit} batches per token group: {self.lanes * (self.chains + 2)} batches of {nb} clips in flight would not fit "
                   "the device memory (CCVS_PIPELINE_MEM_FRAC)", file=sys.stderr, flush=True)

@@ -77,6 +77,9 @@ def test_lanes_that_fit_the_device_memory():
     assert Generator._lanes_that_fit(4, 2, 16, 256, 256, total, taken=60 * 2 ** 30) == 3   # another process holds 60 GB of the device
     assert Generator._lanes_that_fit(4, 2, 16, 256, 256, total, dec_streams=4) == 4 and Generator._lanes_that_fit(4, 2, 16, 256, 256, 235 * 2 ** 30, dec_streams=6) == 3
     assert Generator._lanes_that_fit(4, 2, 16, 256, 256, 235 * 2 ** 30, dec_streams=2) == 4
+    # the pre-drawn host noise stream of every batch in flight: BAIR's 63 MB changes nothing, 1 GB per batch does
+    assert Generator._lanes_that_fit(4, 2, 16, 256, 256, total, noise_bytes_per_batch=960 * 16 * 1024 * 4.0) == 4
+    assert Generator._lanes_that_fit(4, 2, 16, 256, 256, 235 * 2 ** 30, noise_bytes_per_batch=2.0 ** 30) == 3
 
 
 def test_frames_the_encoder_has_to_see():
@@ -271,3 +274,97 @@ def test_noise_feed_streams_follow_the_generator(monkeypatch):
         for r, n, w in shapes[:4]:
             real_empty(n * r * w).exponential_(1, generator=chk)
         assert torch.equal(mid.get_state(), chk.get_state())
+
+
+def _stub_device_pieces(monkeypatch):
+    import contextlib
+    import torch
+
+    class _Stub:
+        def __init__(self, *a, **k):
+            pass
+
+        def record(self):
+            pass
+
+    real_empty = torch.empty
+    monkeypatch.setattr(torch.cuda, "Stream", _Stub)
+    monkeypatch.setattr(torch.cuda, "Event", _Stub)
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **{kk: v for kk, v in k.items() if kk != "pin_memory"}))
+    return real_empty
+
+
+def test_noise_feed_drain_waits_for_a_slow_skipper(monkeypatch):
+    """`pending == 0` said "every stream is drawn", not "the skipper has counted the last one off": with the
+    drawers faster than the skipper drain() published a mid-stream cursor and the class labels that `condition()` draws next came
+    from the wrong place.  Here the skipper is slowed down until every drawer has finished first, and the schedule of a
+    class-conditional run without given labels -- labels(i), noise(i), labels(i+1), ... -- must reproduce the serial order."""
+    import time
+    import torch
+    from ccvs_amd.helpers import pipeline as P
+    real_empty = _stub_device_pieces(monkeypatch)
+    orig_skip = P.NoiseFeed._skip
+
+    def slow_skip(self, n):
+        time.sleep(0.15)                 # the drawers (tiny streams) are done long before
+        orig_skip(self, n)
+
+    monkeypatch.setattr(P.NoiseFeed, "_skip", slow_skip)
+    shape = (4, 9, 31)                   # rows, steps, width
+    ref = torch.Generator().manual_seed(11)
+    want = []
+    for _ in range(3):                   # the serial loop: labels of batch i (generator.py:124), then its picks' noise
+        lbl = torch.randint(0, 101, (shape[0],), generator=ref)
+        noise = torch.stack([real_empty(shape[0], shape[2]).exponential_(1, generator=ref) for _ in range(shape[1])])
+        want.append((lbl, noise))
+    g = torch.Generator().manual_seed(11)
+    feed = P.NoiseFeed(g, "cpu", drawers=3)
+    assert feed.parallel
+    got = []
+    for i in range(3):
+        feed.drain()                     # `_submit_group`: behind the previous batch's noise ...
+        lbl = torch.randint(0, 101, (shape[0],), generator=g)
+        feed.resync()                    # ... and this batch's noise behind the labels
+        got.append((lbl, feed.request(*shape)))
+    for (lbl, t), (wl, wn) in zip(got, want):
+        assert t["done"].wait(60) and t["error"] is None
+        assert torch.equal(lbl, wl)
+        assert torch.equal(t["noise"], wn)
+    feed.close()
+    assert torch.equal(torch.randint(0, 101, (7,), generator=g), torch.randint(0, 101, (7,), generator=ref))
+
+
+def test_noise_feed_failure_is_sticky(monkeypatch):
+    """a skip that fails leaves the cursor in an unknown place -- every later request must carry the error (not
+    noise from a misplaced stream), and drain() / close() must raise instead of publishing the cursor."""
+    import pytest as _pytest
+    import torch
+    from ccvs_amd.helpers import pipeline as P
+    _stub_device_pieces(monkeypatch)
+    calls = {"n": 0}
+    orig_skip = P.NoiseFeed._skip
+
+    def failing_skip(self, n):
+        calls["n"] += 1
+        if calls["n"] == 2:
+            raise MemoryError("host memory exhausted (test)")
+        orig_skip(self, n)
+
+    monkeypatch.setattr(P.NoiseFeed, "_skip", failing_skip)
+    g = torch.Generator().manual_seed(5)
+    before = g.get_state().clone()
+    feed = P.NoiseFeed(g, "cpu", drawers=2)
+    t1, t2, t3 = feed.request(2, 3, 8), feed.request(2, 3, 8), feed.request(2, 3, 8)
+    for t in (t1, t2, t3):
+        assert t["done"].wait(60)
+    assert t1["error"] is None
+    assert isinstance(t3["error"], MemoryError)          # served behind the failure: refused
+    with _pytest.raises(RuntimeError):
+        feed.drain()
+    with _pytest.raises(RuntimeError):
+        feed.request(2, 3, 8)
+    with _pytest.raises(RuntimeError):
+        feed.close()
+    assert torch.equal(g.get_state(), before)            # the process generator was not moved to a wrong position

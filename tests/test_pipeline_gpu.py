@@ -1,5 +1,7 @@
 """-m gpu: Generator.run_pipelined (several batches in flight: the decoder of one batch on one stream, ONE token loop over the
 stacked rows of the next `lanes` batches on a high-priority stream) must give exactly what the serial schedule gives."""
+import os
+
 import pytest
 import torch
 
@@ -158,6 +160,25 @@ def test_decode_gemm_rows_do_not_depend_on_the_launch():
                 assert torch.equal(a[lo:hi], b), (m, lo)
         want = torch.nn.functional.gelu(torch.nn.functional.layer_norm(xs, (C,), gamma, beta) @ w_fc.t() + b_fc)
         assert (whole[2] - want).abs().max().item() < 2e-4
+
+
+def test_gemm_block_tile_switch_is_bit_identical(tmp_path):
+    """the 2 x 2 block tile (`gemm16_kernel<.., 2, 2, 1>`, rows > 32) against the one-block form on the SAME M, by flipping
+    CCVS_GEMM_TILE2 (read once per process, hence two worker processes): M = 48 / 64 / 37, N not a multiple of 32 (the ragged-block
+    `continue` and the per-block slab indexing), K = 4096 (K also split over workgroups), with and without the LayerNorm prologue."""
+    import subprocess
+    import sys
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = []
+    for flag in ("0", "1"):
+        path = str(tmp_path / f"tile{flag}.npz")
+        env = dict(os.environ, CCVS_GEMM_TILE2=flag)
+        subprocess.run([sys.executable, os.path.join(here, "gemm_tile_worker.py"), path], env=env, check=True, timeout=600)
+        outs.append(np.load(path))
+    assert sorted(outs[0].files) == sorted(outs[1].files) and len(outs[0].files) == 27
+    for key in outs[0].files:
+        assert np.array_equal(outs[0][key], outs[1][key]), key
 
 
 def test_sequence_gemm_rows_do_not_depend_on_the_launch():
