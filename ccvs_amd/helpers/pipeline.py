@@ -83,7 +83,10 @@ class NoiseFeed:
     def __init__(self, generator, device, drawers=None):
         self.real = generator if generator is not None else torch.default_generator
         self.device = device
-        self.copy_stream = torch.cuda.Stream(device=device)
+        # (device "cpu": the host half only -- draw into ordinary memory, no upload; tools/host_stress.py measures N ranks' host work
+        # side by side that way, without a GPU)
+        self.on_gpu = torch.device(device).type == "cuda"
+        self.copy_stream = torch.cuda.Stream(device=device) if self.on_gpu else None
         self.cursor = torch.Generator()          # the skipper's copy: always at the start of the next request
         self.cursor.set_state(self.real.get_state())
         n = int(os.environ.get("CCVS_NOISE_DRAWERS", "4")) if drawers is None else int(drawers)
@@ -173,20 +176,24 @@ class NoiseFeed:
     def _draw(self, t, gen):
         """One stream from `gen` (positioned at its first value): block after block, exactly the calls torch.multinomial makes."""
         try:
-            buf = torch.empty(t["steps"], t["rows"], t["width"], dtype=torch.float32, pin_memory=True)
+            buf = torch.empty(t["steps"], t["rows"], t["width"], dtype=torch.float32, pin_memory=self.on_gpu)
             for i in range(t["steps"]):
                 buf[i].exponential_(1, generator=gen)
-            with torch.cuda.stream(self.copy_stream):
-                t["noise"] = buf.to(self.device, non_blocking=True)
-                t["event"] = torch.cuda.Event()
-                t["event"].record()
+            if not self.on_gpu:
+                t["noise"] = buf
+            else:
+                with torch.cuda.stream(self.copy_stream):
+                    t["noise"] = buf.to(self.device, non_blocking=True)
+                    t["event"] = torch.cuda.Event()
+                    t["event"].record()
         except BaseException as exc:
             t["error"] = exc
         finally:
             self._finish(t)
 
     def _skipper(self):
-        torch.cuda.set_device(self.device)
+        if self.on_gpu:
+            torch.cuda.set_device(self.device)
         while True:
             t = self.requests.get()
             if t is None:
@@ -219,7 +226,8 @@ class NoiseFeed:
         torch.empty(n, dtype=torch.int64).random_(generator=self.cursor)
 
     def _drawer(self):
-        torch.cuda.set_device(self.device)
+        if self.on_gpu:
+            torch.cuda.set_device(self.device)
         gen = torch.Generator()
         while True:
             item = self.work.get()

@@ -55,6 +55,18 @@ def main():
         solo = Generator(Options().parse(True, True, argv=TINY_ARGV))          # the same job on one rank
         assert solo.noise_key(5) == gen.noise_key(5) and solo.noise_key(6) != gen.noise_key(5)
         assert torch.equal(torch.cat(allrows), solo.first_clip(4) + torch.arange(4)), "global clip rows differ from the 1-rank job"
+        # host-drawn noise (the default sampler): bench.py seeds rank r's process generator with NOISE_SEED + r, so the first Exp(1)
+        # block torch.multinomial would consume (transformer_model.py:395-409) differs between the ranks (round <= 5: every rank
+        # NOISE_SEED itself -> rank 1's clips sampled with rank 0's noise); rank 0 keeps the single-GPU stream
+        import bench
+        assert bench.noise_seed_of_rank(0) == bench.NOISE_SEED and bench.noise_seed_of_rank(eng.rank) == bench.NOISE_SEED + eng.rank
+        torch.manual_seed(bench.noise_seed_of_rank(eng.rank))
+        block = torch.empty(2, 64).exponential_(1)
+        blocks = [torch.zeros_like(block) for _ in range(2)]
+        dist.all_gather(blocks, block)
+        assert not torch.equal(blocks[0], blocks[1]), "the two ranks draw the same host noise"
+        torch.manual_seed(bench.NOISE_SEED)
+        assert torch.equal(blocks[0], torch.empty(2, 64).exponential_(1)), "rank 0 no longer draws the single-GPU stream"
         h = eng.all_gather_clips_async(clips)          # the side-stream form degrades to the blocking call on gloo
         assert torch.equal(h.wait(), want)
         t = eng.all_reduce_max(1.0 + eng.rank)
