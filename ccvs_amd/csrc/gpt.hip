@@ -118,6 +118,49 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
     return __builtin_bit_cast(f32x4, v);
 }
 
+// ---------------------------------------------------------------------------------------
+// Agent-scope ("sc1") accesses for data that one workgroup hands to another INSIDE a launch (the persistent decode step below; the
+// split-K slabs since round 2).  Per-XCD L2s are not coherent and a CU's L1 is never refreshed by another CU's stores
+// (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): the producer stores sc1 (write-through)
+// and drains (s_waitcnt vmcnt(0)) before its workgroup signals; EVERY consumer load of those bytes is an sc1 load (it bypasses
+// L1) issued after the consumer's poll has matched and its workgroup has passed a barrier.  COH = false: the plain access (a
+// kernel boundary orders it), so that one body serves the launch chain and the persistent kernel with identical arithmetic.
+// ---------------------------------------------------------------------------------------
+template <bool COH>
+__device__ __forceinline__ float ld_act(const float* p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void st_act(float* p, float v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+// threadIdx.x, opaque to the optimiser when OPAQUE: inside the persistent step's phase loop every lane-derived constant of every
+// phase body (LDS offsets, row / column maps, masks -- dozens of registers) is loop-invariant and gets hoisted in front of the loop,
+// where it stays live across all the other phases (with a 64-register cap: 19 spills, all of them such values); behind an asm
+// statement the optimiser cannot move, each body recomputes its handful of shifts and masks where it runs.
+template <bool OPAQUE>
+__device__ __forceinline__ int thread_id() {
+    int t = threadIdx.x;
+    if constexpr (OPAQUE) asm volatile("" : "+v"(t));
+    return t;
+}
+// a pointer read from the persistent step's phase table (constant memory) is a GENERIC pointer to the compiler: the cast through
+// address_space(1) makes its accesses global_* instead of flat_* (COH = false: the kernel's own argument, already global)
+template <bool COH, typename T>
+__device__ __forceinline__ T* gp_(T* p) {
+    if constexpr (COH) return (T*)(__attribute__((address_space(1))) T*)p;
+    else return p;
+}
+// 16 bytes, sc1 (global_load_dwordx4 ... sc1 through a one-off buffer descriptor: aux bit 4)
+__device__ __forceinline__ f32x4 ld_act4_sc1(const float* p) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 16, 0x00020000);
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+    const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 16);
+    return __builtin_bit_cast(f32x4, v);
+}
+
 struct Gemm16 {
     const float* x; long ldx;
     const float* w; const float* bias; const float* res; float* y; long ldy;
@@ -189,19 +232,29 @@ __device__ __forceinline__ float gemm_epilogue(float v, bool ln, float rstd, flo
 // depend on the tile it falls into.  Same box, 20 batches: 210.5 -> 227.8 frames/s, the token step beside the decoder 7.88 ->
 // 7.22 ms, the convolutions beside it 87 -> 95 TFLOP/s; alone the step costs the same (3.17 against 3.25 ms).  Larger tiles
 // (4 x 2, 2 x 4: 112 registers, a quarter of the workgroups) lose: 206-208 frames/s, 4.07 ms alone.
-template <int WNT, int RB, int CB, int U>   // WNT = 2: weights with the non-temporal policy
-__global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __restrict__ x_, const float* __restrict__ w_, long ldx_, int K_, int N_,
-                                                                int M_, int ks_, int kz_, Gemm16 p) {
-    TOKEN_PRIO();
+// LDS of one tile: the K slices' partial blocks, their LayerNorm sums, the rows' (mean, rstd)
+#define GEMM16_RED_WORDS(NB) (GEMM_WAVES * (NB) * 64 * 4)
+#define GEMM16_STAT_WORDS(RB) (GEMM_WAVES * (RB) * 16 * 2)
+#define GEMM16_FIN_WORDS(RB) ((RB) * 16 * 2)
+// One tile (block (bx, by, bz) of the launch's grid) of the weight-stream GEMM: the body of gemm16_kernel, and of the GEMM phases of
+// the persistent decode step (gpt_step_kernel: COH = true -- the activations x / res / y / the new cache rows are handed over
+// between workgroups of ONE launch, so they are read and written with sc1 accesses; the arithmetic is the same instruction for
+// instruction, so a row's bits do not depend on which of the two forms computed it).
+// PT: `Gemm16` (the kernel's own argument block) or `__attribute__((address_space(4))) Gemm16` (an entry of the persistent step's phase
+// table in constant memory: every `p.field` is then a scalar load at its point of use -- the epilogue's operands are not held
+// in registers across the K loop -- and the pointers read from it are generic, hence GP() = the cast through the global address space).
+template <int WNT, int RB, int CB, int U, bool COH, typename PT>   // WNT = 2: weights with the non-temporal policy
+__device__ __forceinline__ void gemm16_tile(const float* __restrict__ x_, const float* __restrict__ w_, long ldx_, int K_, int N_, int M_, int ks_,
+                                            int kz_, const PT& p, int bx_, int by_, int bz_, float* __restrict__ red, float* __restrict__ stat,
+                                            float* __restrict__ fin) {
+#define GP(ptr) gp_<COH>(ptr)
     constexpr int NB = RB * CB;
-    __shared__ __attribute__((aligned(16))) float red[GEMM_WAVES * NB * 64 * 4];
-    __shared__ float stat[GEMM_WAVES * RB * 16 * 2];
-    __shared__ float fin[RB * 16 * 2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int XAUX = COH ? 16 : 0;   // sc1 on the activation loads
+    const int tid = thread_id<COH>(), lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.y * 16 * RB, ncol0 = blockIdx.x * 16 * CB;
+    const int m0 = by_ * 16 * RB, ncol0 = bx_ * 16 * CB;
     const int kper = K_ / (ks_ * kz_);
-    const int kbase = blockIdx.z * (K_ / kz_);
+    const int kbase = bz_ * (K_ / kz_);
     const bool active = wave < ks_;
     // Buffer loads: a wave-uniform 128-bit descriptor per tensor in SGPRs + ONE 32-bit byte offset per lane and block (the
     // K position goes into the scalar offset / the instruction's immediate) instead of 64-bit pointer pairs and their
@@ -241,7 +294,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int u = 0; u < U; ++u) xv[rb][u] = buf_load4(xr, xofs[rb], k0 * 4 + 64 * u);
+                for (int u = 0; u < U; ++u) xv[rb][u] = buf_load4<XAUX>(xr, xofs[rb], k0 * 4 + 64 * u);
             __builtin_amdgcn_sched_barrier(0);   // every load of the batch goes out before its first MFMA (hipcc otherwise sinks half of them between the MFMAs)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -260,7 +313,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) w1[cb] = buf_load4<WNT>(wr, wofs[cb], k0 * 4);
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) x1[rb] = buf_load4(xr, xofs[rb], k0 * 4);
+            for (int rb = 0; rb < RB; ++rb) x1[rb] = buf_load4<XAUX>(xr, xofs[rb], k0 * 4);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
@@ -296,7 +349,6 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __
     }
     __syncthreads();
     // wave w finishes the blocks w, w + 4, ... (one block per workgroup: wave 0, as before)
-    if (NB == 1 && wave > 0) return;
 #pragma unroll 1
     for (int blk = wave; blk < NB; blk += GEMM_WAVES) {
         const int rb = blk / CB, cb = blk - rb * CB;
@@ -317,13 +369,13 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __
             // needed -- on this chip a fence is an L2 write-back + invalidate costing several us, and all the
             // hand-off needs is slab stores acknowledged (vmcnt 0) before the ticket, and slab loads after it.
             const int tile = (mb0 >> 4) * ((p.N + 15) >> 4) + (nb0 >> 4);   // the 16 x 16 block's own slabs and counter
-            float* slabs = p.ws_slabs + (long)tile * p.kz * 256;
-            float* mine = slabs + (blockIdx.z * 64 + lane) * 4;
+            float* slabs = GP(p.ws_slabs) + (long)tile * p.kz * 256;
+            float* mine = slabs + (bz_ * 64 + lane) * 4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) __hip_atomic_store(mine + c, a4[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             int ticket = 0;
-            if (lane == 0) ticket = __hip_atomic_fetch_add(p.ws_count + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) ticket = __hip_atomic_fetch_add(GP(p.ws_count) + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ticket = __builtin_amdgcn_readfirstlane(ticket);
             finisher = ticket == p.kz - 1;
             if (finisher) {
@@ -333,35 +385,46 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __
 #pragma unroll
                     for (int c = 0; c < 4; ++c) a4[c] += __hip_atomic_load(slabs + (z * 64 + lane) * 4 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (lane == 0) __hip_atomic_store(p.ws_count + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(GP(p.ws_count) + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
 
         // D[row = 4*g + r][col = li]
         const int col = nb0 + li;
         if (finisher && col < p.N) {
-            const float bv = p.bias ? p.bias[col] : 0.f;
-            const float sn = p.ln_s ? p.ln_s[col] : 0.f;
+            const float bv = p.bias ? GP(p.bias)[col] : 0.f;
+            const float sn = p.ln_s ? GP(p.ln_s)[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = mb0 + 4 * g + r;
                 if (row >= p.M) continue;
-                const float rv = p.epi == 2 ? p.res[(long)row * p.ldy + col] : 0.f;
+                const float rv = p.epi == 2 ? ld_act<COH>(GP(p.res) + (long)row * p.ldy + col) : 0.f;
                 const float v = gemm_epilogue(a4[r], p.ln_s != nullptr, fin[(rb * 16 + 4 * g + r) * 2 + 1], fin[(rb * 16 + 4 * g + r) * 2], sn, bv, p.epi, rv);
                 if (p.kcache && col >= p.C) {
                     const int cc = col - p.C;
-                    float* cache = cc >= p.C ? p.vcache : p.kcache;
+                    float* cache = cc >= p.C ? GP(p.vcache) : GP(p.kcache);
                     const int c2 = cc >= p.C ? cc - p.C : cc;
                     const int h = c2 / p.D, d = c2 - h * p.D;
                     const int b = row / p.Tq, t = row - b * p.Tq;
-                    const int pos = p.pos0 + (p.pos_dev ? p.pos_dev[p.grp_rows > 0 ? b / p.grp_rows : 0] : 0);
-                    if (pos + t < p.Tmax) cache[(((long)b * p.H + h) * p.Tmax + pos + t) * p.D + d] = v;
+                    const int pos = p.pos0 + (p.pos_dev ? GP(p.pos_dev)[p.grp_rows > 0 ? b / p.grp_rows : 0] : 0);
+                    if (pos + t < p.Tmax) st_act<COH>(cache + (((long)b * p.H + h) * p.Tmax + pos + t) * p.D + d, v);
                 } else {
-                    p.y[(long)row * p.ldy + col] = v;
+                    st_act<COH>(GP(p.y) + (long)row * p.ldy + col, v);
                 }
             }
         }
     }
+#undef GP
+}
+
+template <int WNT, int RB, int CB, int U>
+__global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __restrict__ x_, const float* __restrict__ w_, long ldx_, int K_, int N_,
+                                                                int M_, int ks_, int kz_, Gemm16 p) {
+    TOKEN_PRIO();
+    __shared__ __attribute__((aligned(16))) float red[GEMM16_RED_WORDS(RB * CB)];
+    __shared__ float stat[GEMM16_STAT_WORDS(RB)];
+    __shared__ float fin[GEMM16_FIN_WORDS(RB)];
+    gemm16_tile<WNT, RB, CB, U, false>(x_, w_, ldx_, K_, N_, M_, ks_, kz_, p, blockIdx.x, blockIdx.y, blockIdx.z, red, stat, fin);
 }
 
 // Prefill form (M > GEMM_DECODE_MAX_M rows): one workgroup computes RB row blocks of 16 against the SAME 16 output columns,
@@ -692,7 +755,12 @@ static int launch_gemm16(Gemm16& g, hipStream_t st, const char* name) {
     return CCVS_OK;
 }
 
-extern "C" int64_t ccvs_gemm_workspace_bytes(void) { return (int64_t)GEMM_WS_TILES * (4 * 256 * sizeof(float) + sizeof(int)); }
+// Workspace layout: [GEMM_WS_TILES x kz<=4 x 256 floats of split-K slabs][GEMM_WS_TILES arrival counters][StepBar: the grid barrier of
+// the persistent decode step, below] -- zeroed once by the caller, left consistent by every launch.
+#define GEMM_WS_SLAB_BYTES ((size_t)GEMM_WS_TILES * 4 * 256 * sizeof(float))
+#define GEMM_WS_BAR_OFFSET (GEMM_WS_SLAB_BYTES + (size_t)GEMM_WS_TILES * sizeof(int))   // 4 MB + 4 KB: 128-byte aligned
+#define GEMM_WS_BAR_BYTES 2048
+extern "C" int64_t ccvs_gemm_workspace_bytes(void) { return (int64_t)(GEMM_WS_BAR_OFFSET + GEMM_WS_BAR_BYTES); }
 
 extern "C" int ccvs_gemm_nt(const float* x, int64_t ldx, const float* w, const float* bias, const float* res, float* y, int64_t ldy,
                             int32_t M, int32_t N, int32_t K, int32_t epilogue, void* workspace, void* stream) {
@@ -701,7 +769,7 @@ extern "C" int ccvs_gemm_nt(const float* x, int64_t ldx, const float* w, const f
     g.epi = epilogue & 0xff; g.seq = (epilogue & CCVS_GEMM_SEQ) ? 1 : 0;
     if (workspace) {
         g.ws_slabs = (float*)workspace;
-        g.ws_count = (int*)((char*)workspace + (size_t)GEMM_WS_TILES * 4 * 256 * sizeof(float));
+        g.ws_count = (int*)((char*)workspace + GEMM_WS_SLAB_BYTES);
     }
     return launch_gemm16(g, (hipStream_t)stream, "ccvs_gemm_nt");
 }
@@ -954,24 +1022,31 @@ __device__ __forceinline__ f32x4 ld_f4(const float* p) {
 // convolution workgroup of the frame decoder instead of waiting for one to retire; a stream of this shape keeps 3.5 TB/s
 // beside the decoder (5.5 alone; tools/chain_probe.py).  Four key rows per lane are requested together (16 KB in flight
 // per workgroup); the first V batch is requested before the softmax reduction starts.
-template <int D, bool NT>
-__global__ __launch_bounds__(256) void attention_decode_kernel(const float* __restrict__ q, long q_sB, const float* __restrict__ kc,
-                                                               const float* __restrict__ vc, float* __restrict__ out, int H, int pos0,
-                                                               const int32_t* __restrict__ pos_dev, int grp_rows, int Tmax, float scale) {
-    TOKEN_PRIO();
+// (bh = the (batch row, head) pair; smem = 16 + 1024 + Tmax floats.  COH: the persistent decode step -- q, the cache row of the
+//  CURRENT position (written by the QKV phase of the same launch) and the output are handed between workgroups of one launch:
+//  sc1 accesses; the older cache rows were written by earlier launches and stay on the plain / non-temporal stream.)
+template <int D, bool NT, bool COH>
+__device__ __forceinline__ void attention_decode_item(const float* __restrict__ q, long q_sB, const float* __restrict__ kc,
+                                                      const float* __restrict__ vc, float* __restrict__ out, int H, int pos0,
+                                                      const int32_t* __restrict__ pos_dev, int grp_rows, int Tmax, float scale, int bh,
+                                                      float* smem) {
     constexpr int LPK = D / 4;     // lanes per key row
     constexpr int KPI = 64 / LPK;  // key rows per wave-instruction
     constexpr int NW = 4;
     constexpr int AU = 4;          // key rows per lane whose loads are issued together
     constexpr int BATCH = NW * KPI * AU;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* red = smem;                    // [16]
     float* pv = smem + 16;                // [NW][64][4]
     float* ps = smem + 16 + NW * 256;     // [Tmax]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bh = blockIdx.x;
+    const int tid = thread_id<COH>(), lane = tid & 63, wave = tid >> 6;
     const int b = bh / H, h = bh - b * H;
-    if (pos_dev) pos0 += pos_dev[grp_rows > 0 ? b / grp_rows : 0];   // row groups of a decode step: one cache length per group
+    if (pos_dev) {   // row groups of a decode step: one cache length per group
+        // (COH: the length words are constant for the whole launch until the pick's last row moves them on, after every other reader:
+        //  a SCALAR load through the constant address space -- as a vector load of a uniform address the value, and with it the
+        //  loop bounds and row addresses, is per-lane data to the compiler)
+        if constexpr (COH) pos0 += ((const __attribute__((address_space(4))) int32_t*)pos_dev)[grp_rows > 0 ? b / grp_rows : 0];
+        else pos0 += pos_dev[grp_rows > 0 ? b / grp_rows : 0];
+    }
     const int L = min(pos0 + 1, Tmax);
     const int kk = lane / LPK, d4 = lane - kk * LPK;
     const float* kbase = kc + (long)bh * Tmax * D + 4 * d4;
@@ -980,15 +1055,31 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const float* __re
     const int nbatch = (L + BATCH - 1) / BATCH;
 
     // unconditional loads from clamped rows (predicated loads would serialise)
-#define ATT_LOAD(dst, base, bi)                                                                                          \
-    _Pragma("unroll") for (int u = 0; u < AU; ++u)                                                                       \
-        dst[u] = ld_f4<NT>(base + (long)min((bi) * BATCH + jw + u * NW * KPI, L - 1) * D)
+    // COH: rows >= L - 1 (the position this step appends, and the clamped tail of the last batch) take the row fetched by ONE sc1
+    // load instead of whatever the streaming load of that address returned -- same values, same arithmetic, no stale line
+    f32x4 k_new = {0.f, 0.f, 0.f, 0.f}, v_new = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (COH) {
+        k_new = ld_act4_sc1(kbase + (long)(L - 1) * D);
+        v_new = ld_act4_sc1(vbase + (long)(L - 1) * D);
+    }
+#define ATT_LOAD(dst, base, bi, fresh)                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < AU; ++u) {                                                                     \
+        dst[u] = ld_f4<NT>(base + (long)min((bi) * BATCH + jw + u * NW * KPI, L - 1) * D);                                \
+        if constexpr (COH) { if ((bi) * BATCH + jw + u * NW * KPI >= L - 1) dst[u] = fresh; }                            \
+    }
 
-    const float4 qv = *reinterpret_cast<const float4*>(q + (long)b * q_sB + h * D + 4 * d4);
+    float4 qv;
+    if constexpr (COH) {
+        const f32x4 q4 = ld_act4_sc1(q + (long)b * q_sB + h * D + 4 * d4);
+        qv = make_float4(q4[0], q4[1], q4[2], q4[3]);
+    } else {
+        qv = *reinterpret_cast<const float4*>(q + (long)b * q_sB + h * D + 4 * d4);
+    }
     float lmax = -INFINITY;
+#pragma unroll 1   // (one batch of AU rows in flight per lane: the 48-register budget; hipcc unrolls this loop by two once the body is an inlined function)
     for (int bi = 0; bi < nbatch; ++bi) {
         f32x4 kv[AU];
-        ATT_LOAD(kv, kbase, bi);
+        ATT_LOAD(kv, kbase, bi, k_new);
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
             const int j = bi * BATCH + jw + u * NW * KPI;
@@ -1003,7 +1094,7 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const float* __re
         }
     }
     f32x4 vv[AU];
-    ATT_LOAD(vv, vbase, 0);  // in flight during the softmax reductions
+    ATT_LOAD(vv, vbase, 0, v_new);  // in flight during the softmax reductions
 
     lmax = wave_max(lmax);
     if (lane == 0) red[wave] = lmax;
@@ -1026,8 +1117,9 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const float* __re
     for (int w = 1; w < NW; ++w) tot += red[w];
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
     for (int bi = 0; bi < nbatch; ++bi) {
-        if (bi > 0) ATT_LOAD(vv, vbase, bi);
+        if (bi > 0) ATT_LOAD(vv, vbase, bi, v_new);
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
             const int j = bi * BATCH + jw + u * NW * KPI;
@@ -1043,8 +1135,17 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const float* __re
         float o = 0.f;
         for (int w = 0; w < NW; ++w)
             for (int s2 = 0; s2 < KPI; ++s2) o += pv[(w * 64 + s2 * LPK + dd4) * 4 + comp];
-        out[(long)b * (H * D) + h * D + tid] = o / tot;
+        st_act<COH>(out + (long)b * (H * D) + h * D + tid, o / tot);
     }
+}
+
+template <int D, bool NT>
+__global__ __launch_bounds__(256) void attention_decode_kernel(const float* __restrict__ q, long q_sB, const float* __restrict__ kc,
+                                                               const float* __restrict__ vc, float* __restrict__ out, int H, int pos0,
+                                                               const int32_t* __restrict__ pos_dev, int grp_rows, int Tmax, float scale) {
+    TOKEN_PRIO();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    attention_decode_item<D, NT, false>(q, q_sB, kc, vc, out, H, pos0, pos_dev, grp_rows, Tmax, scale, blockIdx.x, smem);
 }
 
 #define ATT_DECODE_LAUNCH(Dv, grid_, smem_, ...)                                                                       \
@@ -1149,28 +1250,28 @@ __device__ __forceinline__ unsigned kth_largest_key(const float* xs, int V, int 
     return prefix;
 }
 
-__global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restrict__ logits, long ld, const float* __restrict__ noise,
-                                                          int64_t* __restrict__ out, long out_stride, int V, int top_k, float temperature,
-                                                          Advance adv) {
-    TOKEN_PRIO();
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// (b = the row, B_all = the rows of the launch; smem = PICK_SMEM_WORDS(V) floats.  COH: the logits were written by the head GEMM phase
+//  of the same launch -- sc1 loads.)
+template <bool COH>
+__device__ __forceinline__ void sample_topk_row(const float* __restrict__ logits, long ld, const float* __restrict__ noise,
+                                                int64_t* __restrict__ out, long out_stride, int V, int top_k, float temperature,
+                                                Advance adv, int b, int B_all, float* smem) {
     float* xs = smem;                  // [V]
     float* redf = smem + V;            // [4]
     int* redj = (int*)(smem + V + 4);  // [4]
     int* wtot = (int*)(smem + V + 8);  // [4]
     int* sel = (int*)(smem + V + 12);  // [2]
     int* hist = (int*)(smem + V + 16); // [256]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
+    const int tid = thread_id<COH>(), lane = tid & 63, wave = tid >> 6;
     // row group of this row: its own counters / Philox words; `brow` = the row's index inside the group
     const int grp = adv.grp_rows > 0 ? b / adv.grp_rows : 0;
     const int brow = b - grp * (adv.grp_rows > 0 ? adv.grp_rows : 0);
-    const int nrows = adv.grp_rows > 0 ? min(adv.grp_rows, (int)gridDim.x - grp * adv.grp_rows) : (int)gridDim.x;
+    const int nrows = adv.grp_rows > 0 ? min(adv.grp_rows, B_all - grp * adv.grp_rows) : B_all;
     if (adv.grp_rows > 0) { adv.state += 8 * grp; adv.widx += grp; adv.len += grp; }
     const float* lr = logits + (long)b * ld;
     float lmax = -INFINITY;
     for (int j = tid; j < V; j += 256) {
-        const float v = lr[j] / temperature;
+        const float v = ld_act<COH>(lr + j) / temperature;
         xs[j] = v;
         lmax = fmaxf(lmax, v);
     }
@@ -1244,6 +1345,14 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restrict__ logits, long ld, const float* __restrict__ noise,
+                                                          int64_t* __restrict__ out, long out_stride, int V, int top_k, float temperature,
+                                                          Advance adv) {
+    TOKEN_PRIO();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    sample_topk_row<false>(logits, ld, noise, out, out_stride, V, top_k, temperature, adv, blockIdx.x, gridDim.x, smem);
 }
 
 #define PICK_SMEM_WORDS(V) ((V) + 16 + 256)
@@ -1380,6 +1489,349 @@ extern "C" int ccvs_sample_topn(const float* logits, int64_t ld, const float* no
 }
 
 // ---------------------------------------------------------------------------------------
+// The decode step as ONE launch (ccvs_gpt_decode.persistent): 256-thread workgroups that stay resident for
+// the whole step -- one per CU -- and walk its phases themselves,
+//     embed | per layer: ln1+QKV+cache scatter | attention | proj+res | ln2+fc+GELU | fc2+res | ln_f+head | pick,
+// instead of 5 n_layer + 3 dependent launches.  A phase is the launch it replaces, tile for tile: workgroup w takes the tiles
+// w, w + G, ... of the phase's grid and runs the SAME tile body (gemm16_tile / attention_decode_item / sample_topk_row), so a row's
+// arithmetic -- K slices per wave, MFMA order, slab order, reduction order -- is the launch chain's instruction for instruction and
+// the tokens are bit-identical (tests/test_persistent_step_gpu.py).  What changes is how a phase's output reaches the next phase's
+// readers on OTHER CUs (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": per-XCD L2s are not
+// coherent, a CU's L1 is never refreshed by another CU's stores):
+//   * every buffer handed over inside the launch -- x, q, the cache row of the current position, att, h, logits, the split-K slabs --
+//     is written with sc1 (write-through) stores and read with sc1 loads (L1 bypassed): COH = true in the tile bodies; weights, the
+//     older cache rows, the embedding tables and the device-resident counters were written by EARLIER launches and stay plain;
+//   * the grid barrier between two phases: every wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets (s_barrier), ONE
+//     lane adds 1 to the workgroup's shard of a monotonic arrival counter (8 shards on lines of their own: 32 agent-scope adds per
+//     word instead of 256), wave 0 polls the 8 shards with sc1 loads + s_sleep until their sum reaches base + phases passed x G,
+//     the workgroup meets again and goes on -- no fence instruction anywhere (the "Valid forms" table, first row: one lane of each
+//     storing workgroup signals for all of that workgroup's stores after every storing wave's vmcnt(0) and the workgroup's barrier;
+//     the poller loads after its poll has matched, the other waves after a barrier it then joins; sc1 stores of 4 / 16 bytes, sc1
+//     loads of 4 / 16 bytes).  `base` = the arrivals counted before this launch, kept in a word of its own that workgroup 0 moves
+//     forward once per launch (read by the NEXT launch only: a kernel boundary apart), so nothing is zeroed between launches and a
+//     captured step replays unchanged; comparisons are on the wrapped difference.  A poll that sees nothing for 5 s gives up, sets
+//     StepBar.err and lets the workgroup run on -- the results of that launch are garbage and ccvs_gpt_decode_status reports it.
+// Residency: G = the number of CUs; a workgroup (256 threads, <= 48 registers, <= 18 KB of LDS at BAIR size) fits beside a
+// convolution workgroup of the frame decoder like the launch chain's kernels do, but it HOLDS that slot for the whole step: two
+// token chains' persistent steps cannot both be resident beside the decoder on one CU, and partially resident grids that wait
+// for each other's slots stall until convolution workgroups retire -- a schedule with ONE token chain is what this form is for
+// (DESIGN.md 4.2).
+// ---------------------------------------------------------------------------------------
+#define STEP_SPIN_TICKS 500000000ULL   // 5 s of the 100 MHz s_memrealtime counter
+struct StepBar {
+    unsigned shard[8][32];   // arrivals, monotonic; one 128-byte line per shard
+    unsigned base[32];       // arrivals counted when the current launch started
+    unsigned err[32];        // != 0: a barrier of some launch gave up (phase index + 1)
+};
+static_assert(sizeof(StepBar) <= GEMM_WS_BAR_BYTES, "StepBar outgrew its slot in the workspace");
+
+// One phase of the step, built once per descriptor by the host (ccvs_gpt_decode_prepare) into a caller-provided device buffer: the
+// kernel reads phase ph's operands by scalar loads when it gets there.  (Operands selected inside the kernel from a by-value argument
+// block -- 24 layers x 12 pointers -- are loop-invariant to the compiler: it kept them ALL live across the phase loop, ran out of
+// scalar registers (106) and parked uniform values in vector registers: 96 + 16 registers per lane instead of the tile bodies' 48.)
+#define STEP_GEMM 0
+#define STEP_ATTENTION 1
+struct StepPhase {
+    int kind, pad_;
+    Gemm16 g;   // STEP_GEMM: the launch this phase replaces; STEP_ATTENTION: x = q, y = att, kcache / vcache, H, Tmax, M = rows
+};
+
+struct StepArgs {
+    int B, C, V, vocab, grp_rows, pos_off, n_phases, H;
+    const float *tok_emb, *pos_table;
+    const int64_t* tok;
+    const int32_t* len;
+    float *x, *logits;
+    StepBar* bar;
+    const StepPhase* prog;
+    float scale;
+    const float* noise;
+    int top_k;
+    float temperature;
+    Advance adv;
+};
+
+__device__ __forceinline__ void step_barrier(StepBar* bar, unsigned target, int phase) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY wave: its sc1 stores of this phase have left
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&bar->shard[blockIdx.x & 7][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned* sp = &bar->shard[threadIdx.x & 7][0];
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            unsigned v = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            if ((int)(v - target) >= 0) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > STEP_SPIN_TICKS) {
+                if (threadIdx.x == 0) __hip_atomic_store(&bar->err[0], (unsigned)(phase + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int RB, int CB, int U>
+__device__ __forceinline__ void step_gemm(const __attribute__((address_space(4))) Gemm16& g, float* smem) {
+    float* red = smem;
+    float* stat = red + GEMM16_RED_WORDS(RB * CB);
+    float* fin = stat + GEMM16_STAT_WORDS(RB);
+    const int N = g.N, M = g.M, K = g.K, ks = g.ks, kz = g.kz;
+    const long ldx = g.ldx;
+    const float* x = gp_<true>(g.x);
+    const float* w = gp_<true>(g.w);
+    const int gx = (N + 16 * CB - 1) / (16 * CB), gy = (M + 16 * RB - 1) / (16 * RB);
+    const int total = gx * gy * kz;
+    // tile order = the launch's dispatch order (x fastest): the row blocks of a column tile are 96 / 32 / 128 tiles apart, a multiple
+    // of 8, so with workgroups dealt to the XCDs round-robin they meet in one L2, as in the launch chain
+    for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
+        const int bx = vb % gx, r = vb / gx;
+        gemm16_tile<0, RB, CB, U, true>(x, w, ldx, K, N, M, ks, kz, g, bx, r % gy, r / gy, red, stat, fin);
+        __syncthreads();   // the tile's LDS is the next tile's
+    }
+}
+
+#define STEP_GEMM_WORDS(RB, CB) (GEMM16_RED_WORDS((RB) * (CB)) + GEMM16_STAT_WORDS(RB) + GEMM16_FIN_WORDS(RB))
+
+// The argument block and the phase table live in device memory (d->program) and are read through CONSTANT-address-space pointers:
+//   * as by-value kernel arguments the whole block -- the pick's sampler words included -- was loaded at the entry and stayed live in
+//     scalar registers across all 122 phases (106 SGPRs, uniform values parked in vector registers);
+//   * through an ordinary pointer the compiler must assume the kernel's own stores may alias the table: it then reads the (uniform)
+//     operands with FLAT vector loads into vector registers and every pointer among them is a generic pointer -- flat loads and stores
+//     for the tensors too, which s_waitcnt vmcnt does not even cover alone.  address_space(4) says "constant for this launch" (scalar
+//     loads), and every pointer read from the table is cast through address_space(1) so that the accesses are global_* / buffer_*.
+#define STEP_CONST __attribute__((address_space(4)))
+#define STEP_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ T* as_global(T* p) {
+    return (T*)(STEP_GLOBAL T*)p;
+}
+// amdgpu_waves_per_eu(8, 8): at most 64 registers per lane (no finer cap exists: amdgpu_num_vgpr is not honoured here).  Left alone,
+// hipcc allocates 73 + 16 for this body although no phase needs more than the launch chain's 48: with 256 threads per workgroup it
+// sees no reason to be frugal.  64 fit beside two convolution waves of up to 216 registers per SIMD (the 3 x 3 forms that carry
+// the decoder's time: 208 / 214), not beside the 1 x 1 forms' 225 -- there the step's workgroup waits for one to retire, once per step.
+template <int D, bool T2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void gpt_step_kernel(const StepArgs* __restrict__ ap_) {
+    TOKEN_PRIO();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int RB = T2 ? 2 : 1, CB = T2 ? 2 : 1, U = T2 ? 1 : GEMM_U;
+    const unsigned G = gridDim.x;
+    const STEP_CONST StepArgs* ap = (const STEP_CONST StepArgs*)ap_;
+    StepBar* bar = as_global(ap->bar);
+    const STEP_CONST StepPhase* prog = (const STEP_CONST StepPhase*)ap->prog;
+    const int n_phases = ap->n_phases;
+    const float att_scale = ap->scale;
+    unsigned target = __hip_atomic_load(&bar->base[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {   // embedding of the last picked token at row pos_off + *len (gpt_embed_kernel)
+        const int B = ap->B, C = ap->C, vocab = ap->vocab, grp_rows = ap->grp_rows, pos_off = ap->pos_off;
+        const int64_t* tok = as_global(ap->tok);
+        const int32_t* len = as_global(ap->len);
+        const float* tok_emb = as_global(ap->tok_emb);
+        const float* pos_table = as_global(ap->pos_table);
+        float* x = as_global(ap->x);
+        const long total = (long)B * C;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)G * 256) {
+            const long b = i / C;
+            const int c = (int)(i - b * C);
+            long t = tok[b];
+            t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+            const long prow = pos_off + len[grp_rows > 0 ? b / grp_rows : 0];
+            st_act<true>(x + i, tok_emb[t * C + c] + pos_table[prow * C + c]);
+        }
+    }
+    target += G; step_barrier(bar, target, 0);
+    // ONE call site per tile body, operands from the phase table (per layer: ln1+QKV | attention | proj | ln2+fc | fc2; then ln_f+head)
+#pragma unroll 1
+    for (int ph = 0; ph < n_phases; ++ph) {
+        const STEP_CONST StepPhase* P = prog + ph;
+        if (P->kind == STEP_ATTENTION) {
+            const STEP_CONST Gemm16& g = P->g;
+            const int n_bh = g.M * g.H, H = g.H, Tmax = g.Tmax, grp_rows = g.grp_rows;
+            const long q_sB = g.ldx;
+            const float* q = as_global(g.x);
+            const float* kc = as_global(g.kcache);
+            const float* vc = as_global(g.vcache);
+            float* att = as_global(g.y);
+            const int32_t* len = as_global(g.pos_dev);
+            for (int bh = blockIdx.x; bh < n_bh; bh += G) {   // attention over the cache
+                attention_decode_item<D, true, true>(q, q_sB, kc, vc, att, H, 0, len, grp_rows, Tmax, att_scale, bh, smem);
+                __syncthreads();
+            }
+        } else {
+            step_gemm<RB, CB, U>(P->g, smem);
+        }
+        target += G; step_barrier(bar, target, ph + 1);
+    }
+    // (workgroup 0, past the last barrier: the arrivals counted so far are the next launch's base -- no workgroup of THIS launch reads it again)
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&bar->base[0], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {   // pick + bookkeeping
+        const int B = ap->B, V = ap->V;
+        Advance adv;
+        adv.codes = as_global(ap->adv.codes); adv.codes_sB = ap->adv.codes_sB; adv.widx = as_global(ap->adv.widx); adv.len = as_global(ap->adv.len);
+        adv.rng = ap->adv.rng;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) adv.imm[i] = 0u;
+        adv.state = as_global(ap->adv.state); adv.grp_rows = ap->adv.grp_rows; adv.noise_stream = as_global(ap->adv.noise_stream);
+        for (int b = blockIdx.x; b < B; b += G) {
+            sample_topk_row<true>(as_global(ap->logits), (long)V, as_global(ap->noise), const_cast<int64_t*>(as_global(ap->tok)), 1L, V, ap->top_k,
+                                  ap->temperature, adv, b, B, smem);
+            __syncthreads();
+        }
+    }
+}
+
+// 0 when the persistent steps launched with this workspace so far all completed their barriers (the stream is synchronised first)
+extern "C" int ccvs_gpt_decode_status(const void* workspace, void* stream) {
+    CCVS_REQUIRE(workspace, "ccvs_gpt_decode_status: null pointer");
+    unsigned err = 0;
+    const StepBar* bar = (const StepBar*)((const char*)workspace + GEMM_WS_BAR_OFFSET);
+    hipError_t e = hipMemcpyAsync(&err, &bar->err[0], sizeof(err), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) { ccvs_set_error("ccvs_gpt_decode_status: %s", hipGetErrorString(e)); return CCVS_ERR_LAUNCH; }
+    if (err) {
+        ccvs_set_error("ccvs_gpt_decode_status: a grid barrier of the persistent decode step gave up (phase %u): the tokens of that step are invalid", err - 1);
+        return CCVS_ERR_LAUNCH;
+    }
+    return CCVS_OK;
+}
+
+// d->program = [StepArgs, padded to STEP_HEAD_BYTES][5 n_layer + 1 phases]
+#define STEP_HEAD_BYTES 512
+static_assert(sizeof(StepArgs) <= STEP_HEAD_BYTES, "StepArgs outgrew the head of the program buffer");
+extern "C" int64_t ccvs_gpt_program_bytes(int32_t n_layer) { return (int64_t)STEP_HEAD_BYTES + (int64_t)(5 * (n_layer > 0 ? n_layer : 0) + 1) * sizeof(StepPhase); }
+
+static int step_check(const ccvs_gpt_decode* d, const char* who) {
+    // what the persistent step covers -- what the pipelined generation uses -- and says so otherwise: no silent fall-back
+    if (!(d->workspace && d->program)) { ccvs_set_error("%s: the persistent step needs `workspace` (ccvs_gemm_workspace_bytes, zeroed once) and `program` (ccvs_gpt_program_bytes)", who); return CCVS_ERR_ARG; }
+    if (d->B > GEMM_DECODE_MAX_M) { ccvs_set_error("%s: the persistent step takes at most %d rows", who, GEMM_DECODE_MAX_M); return CCVS_ERR_ARG; }
+    if (!(decode_nt() == 1 && getenv_int("CCVS_GEMM_TILE2", 1) == 1)) { ccvs_set_error("%s: the persistent step is built for the default cache policies and tile (CCVS_DECODE_NT=1, CCVS_GEMM_TILE2=1)", who); return CCVS_ERR_ARG; }
+    if (!(d->C >= 32 && d->F >= 32 && d->V >= 32 && d->C % 16 == 0 && d->F % 16 == 0)) { ccvs_set_error("%s: the persistent step needs >= 32 output columns per GEMM and K %% 16 == 0", who); return CCVS_ERR_ARG; }
+    if (!((long)d->V * d->C * 4 < (1L << 31) && (long)d->F * d->C * 4 < (1L << 31) && (long)d->B * d->F * 4 < (1L << 31))) { ccvs_set_error("%s: operand beyond 2^31 bytes (32-bit buffer offsets)", who); return CCVS_ERR_ARG; }
+    return CCVS_OK;
+}
+
+// The phase table of d's persistent step, written to d->program (device memory): the Gemm16 of every launch of the chain, K slicing
+// exactly as launch_gemm16 decides it.  A synchronous copy on `stream`: once per descriptor, outside graph capture.
+extern "C" int ccvs_gpt_decode_prepare(const ccvs_gpt_decode* d, void* stream) {
+    CCVS_REQUIRE(d && d->layers && d->n_layer > 0 && d->C > 0 && d->H > 0 && d->C % d->H == 0, "ccvs_gpt_decode_prepare: bad descriptor");
+    int rc = step_check(d, "ccvs_gpt_decode_prepare");
+    if (rc != CCVS_OK) return rc;
+    const int D = d->C / d->H;
+    const int grp_rows = d->groups > 1 ? d->B / d->groups : 0;
+    float* ws_slabs = (float*)d->workspace;
+    int* ws_count = (int*)((char*)d->workspace + GEMM_WS_SLAB_BYTES);
+    const int n_ph = 5 * d->n_layer + 1;
+    const size_t bytes = (size_t)ccvs_gpt_program_bytes(d->n_layer);
+    char* host = (char*)calloc(1, bytes);
+    CCVS_REQUIRE(host, "ccvs_gpt_decode_prepare: out of host memory");
+    StepPhase* prog = (StepPhase*)(host + STEP_HEAD_BYTES);
+    {
+        StepArgs& a = *(StepArgs*)host;
+        a.B = d->B; a.C = d->C; a.V = d->V; a.vocab = d->vocab; a.grp_rows = grp_rows; a.pos_off = d->pos_off; a.n_phases = n_ph; a.H = d->H;
+        a.tok_emb = d->tok_emb; a.pos_table = d->pos_table; a.tok = d->tok; a.len = d->len; a.x = d->x; a.logits = d->logits;
+        a.bar = (StepBar*)((char*)d->workspace + GEMM_WS_BAR_OFFSET);
+        a.prog = (const StepPhase*)((const char*)d->program + STEP_HEAD_BYTES);
+        a.scale = 1.0f / sqrtf((float)D);
+        a.noise = d->noise; a.top_k = d->top_k; a.temperature = d->temperature;
+        a.adv.codes = d->codes; a.adv.codes_sB = (long)d->codes_sB; a.adv.widx = d->widx; a.adv.len = d->len;
+        a.adv.rng = (d->rng && !d->noise && !d->noise_stream) ? 1 : 0; a.adv.state = d->state; a.adv.grp_rows = grp_rows;
+        a.adv.noise_stream = d->noise ? nullptr : d->noise_stream;
+    }
+    auto slice = [&](Gemm16& g) {
+        g.kz = gemm_kz(g);
+        if (g.kz > 1 && cdiv(g.N, 16) * cdiv(g.M, 16) > GEMM_WS_TILES) g.kz = 1;
+        g.ks = GEMM_WAVES;
+        while (g.ks > 1 && g.K % (16 * g.ks * g.kz) != 0) g.ks >>= 1;
+    };
+    int n = 0;
+    for (int l = 0; l < d->n_layer; ++l) {
+        const ccvs_gpt_layer& L = d->layers[l];
+        if (!(L.qkv_w && L.qkv_b && L.qkv_s && L.proj_w && L.proj_b && L.fc_w && L.fc_b && L.fc_s && L.fc2_w && L.fc2_b && L.kcache && L.vcache)) {
+            free(host);
+            ccvs_set_error("ccvs_gpt_decode_prepare: null pointer in layer %d", l);
+            return CCVS_ERR_ARG;
+        }
+        {   // ln1 + QKV + cache scatter
+            Gemm16& g = prog[n].g; prog[n++].kind = STEP_GEMM;
+            g.x = d->x; g.ldx = d->C; g.w = L.qkv_w; g.bias = L.qkv_b; g.y = d->q; g.ldy = d->C; g.M = d->B; g.N = 3 * d->C; g.K = d->C;
+            g.ln_s = L.qkv_s; g.ln_eps = d->ln_eps;
+            g.kcache = L.kcache; g.vcache = L.vcache; g.C = d->C; g.H = d->H; g.D = D; g.Tq = 1; g.Tmax = d->Tmax; g.pos0 = 0; g.pos_dev = d->len;
+            g.grp_rows = grp_rows;
+            slice(g);
+        }
+        {   // attention over the cache
+            Gemm16& g = prog[n].g; prog[n++].kind = STEP_ATTENTION;
+            g.x = d->q; g.ldx = d->C; g.y = d->att; g.kcache = L.kcache; g.vcache = L.vcache; g.H = d->H; g.M = d->B; g.Tmax = d->Tmax;
+            g.pos_dev = d->len; g.grp_rows = grp_rows;
+        }
+        {   // proj + residual (in place on x)
+            Gemm16& g = prog[n].g; prog[n++].kind = STEP_GEMM;
+            g.x = d->att; g.ldx = d->C; g.w = L.proj_w; g.bias = L.proj_b; g.res = d->x; g.y = d->x; g.ldy = d->C; g.M = d->B; g.N = d->C; g.K = d->C; g.epi = 2;
+            g.ws_slabs = ws_slabs; g.ws_count = ws_count;
+            slice(g);
+        }
+        {   // ln2 + fc + GELU
+            Gemm16& g = prog[n].g; prog[n++].kind = STEP_GEMM;
+            g.x = d->x; g.ldx = d->C; g.w = L.fc_w; g.bias = L.fc_b; g.y = d->h; g.ldy = d->F; g.M = d->B; g.N = d->F; g.K = d->C; g.epi = 1;
+            g.ln_s = L.fc_s; g.ln_eps = d->ln_eps;
+            slice(g);
+        }
+        {   // fc2 + residual (in place on x)
+            Gemm16& g = prog[n].g; prog[n++].kind = STEP_GEMM;
+            g.x = d->h; g.ldx = d->F; g.w = L.fc2_w; g.bias = L.fc2_b; g.res = d->x; g.y = d->x; g.ldy = d->C; g.M = d->B; g.N = d->C; g.K = d->F; g.epi = 2;
+            g.ws_slabs = ws_slabs; g.ws_count = ws_count;
+            slice(g);
+        }
+    }
+    {   // ln_f + head
+        Gemm16& g = prog[n].g; prog[n++].kind = STEP_GEMM;
+        g.x = d->x; g.ldx = d->C; g.w = d->head_w; g.bias = d->head_b; g.y = d->logits; g.ldy = d->V; g.M = d->B; g.N = d->V; g.K = d->C;
+        g.ln_s = d->head_s; g.ln_eps = d->ln_eps;
+        slice(g);
+    }
+    hipError_t e = hipMemcpyAsync(d->program, host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    free(host);
+    if (e != hipSuccess) { ccvs_set_error("ccvs_gpt_decode_prepare: %s", hipGetErrorString(e)); return CCVS_ERR_LAUNCH; }
+    return CCVS_OK;
+}
+
+static int launch_step_persistent(const ccvs_gpt_decode* d, int D, hipStream_t st) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { ccvs_set_error("ccvs_gpt_decode_step: no device properties"); return CCVS_ERR_LAUNCH; }
+        n_cu = prop.multiProcessorCount;
+    }
+    const StepArgs* a = (const StepArgs*)d->program;   // written by ccvs_gpt_decode_prepare
+    const bool t2 = d->B > 32;
+    size_t words = t2 ? STEP_GEMM_WORDS(2, 2) : STEP_GEMM_WORDS(1, 1);
+    const size_t w_att = 16 + 4 * 256 + (size_t)d->Tmax, w_pick = PICK_SMEM_WORDS(d->V);
+    if (w_att > words) words = w_att;
+    if (w_pick > words) words = w_pick;
+    const size_t smem = words * sizeof(float);
+#define STEP_LAUNCH(Dv, T2v)                                                                                                          \
+    do {                                                                                                                              \
+        static bool attr_set = false;                                                                                                 \
+        if (!attr_set) {                                                                                                              \
+            (void)hipFuncSetAttribute((const void*)gpt_step_kernel<Dv, T2v>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                                          \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((gpt_step_kernel<Dv, T2v>), dim3(n_cu), dim3(256), smem, st, a);                                           \
+    } while (0)
+    if (D == 64) { if (t2) STEP_LAUNCH(64, true); else STEP_LAUNCH(64, false); }
+    else if (D == 32) { if (t2) STEP_LAUNCH(32, true); else STEP_LAUNCH(32, false); }
+    else { if (t2) STEP_LAUNCH(16, true); else STEP_LAUNCH(16, false); }
+#undef STEP_LAUNCH
+    CCVS_CHECK_LAUNCH("ccvs_gpt_decode_step(persistent)");
+    return CCVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // One decode step: the launch sequence of ccvs_gpt_embed / ccvs_gemm_ln_qkv / ccvs_attention /
 // ccvs_gemm_nt / ccvs_gemm_ln / ccvs_sample_topk for a single new position, 5 * n_layer + 3 launches
 // on one stream, every per-step quantity device-resident (hipGraph-capturable).
@@ -1402,6 +1854,11 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream) {
     CCVS_REQUIRE(smem_att <= 64 * 1024, "ccvs_gpt_decode_step: sequence too long for the LDS score buffer");
     CCVS_REQUIRE(smem_pick <= 160 * 1024, "ccvs_gpt_decode_step: vocabulary %d too large", d->V);
     hipStream_t st = (hipStream_t)stream;
+    if (d->persistent) {   // ONE launch (gpt_step_kernel) over the phase table ccvs_gpt_decode_prepare wrote to d->program
+        int rc_ = step_check(d, "ccvs_gpt_decode_step");
+        if (rc_ != CCVS_OK) return rc_;
+        return launch_step_persistent(d, D, st);
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)sample_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1415,7 +1872,7 @@ extern "C" int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream) {
         CCVS_CHECK_LAUNCH("ccvs_gpt_decode_step(embed)");
     }
     float* ws_slabs = (float*)d->workspace;
-    int* ws_count = d->workspace ? (int*)((char*)d->workspace + (size_t)GEMM_WS_TILES * 4 * 256 * sizeof(float)) : nullptr;
+    int* ws_count = d->workspace ? (int*)((char*)d->workspace + GEMM_WS_SLAB_BYTES) : nullptr;
     const float scale = 1.0f / sqrtf((float)D);
     int rc;
     for (int l = 0; l < d->n_layer; ++l) {

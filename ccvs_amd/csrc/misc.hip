@@ -13,7 +13,7 @@ void ccvs_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ccvs_last_error(void) { return g_err; }
-extern "C" int ccvs_abi_version(void) { return 5; }
+extern "C" int ccvs_abi_version(void) { return 6; }
 
 // Per-stream CU budgets: a handful of (stream, limit) pairs.  Written by the thread that drives the decode stream, read by
 // every launching thread (the token worker reads its own stream's entry): one mutex around the table.  A budget of 0

@@ -16,7 +16,7 @@ EXPORTS = [
     "ccvs_last_error", "ccvs_abi_version", "ccvs_conv2d", "ccvs_conv2d_bf16x3", "ccvs_conv_fetch_bytes_per_lane", "ccvs_upfirdn2d", "ccvs_dwconvT4x4s2",
     "ccvs_correlation7x7", "ccvs_backwarp", "ccvs_backwarp_ctx", "ccvs_backwarp_p8_ctx", "ccvs_backwarp_proj_ctx", "ccvs_warp_fuse_blend", "ccvs_warp_fuse_blend_ctx", "ccvs_tap_shift_add", "ccvs_vq_argmin", "ccvs_embed_gather",
     "ccvs_gpt_embed", "ccvs_layernorm", "ccvs_gemm_workspace_bytes", "ccvs_gemm_nt", "ccvs_gemm_ln", "ccvs_gemm_ln_qkv", "ccvs_attention", "ccvs_kv_append", "ccvs_sample_topk", "ccvs_sample_topk_philox", "ccvs_sample_topn",
-    "ccvs_gpt_decode_step", "ccvs_pack_u8", "ccvs_pack_u8_norm", "ccvs_stream_cu_limit", "ccvs_psnr", "ccvs_ssim_workspace_bytes", "ccvs_ssim", "ccvs_resize_bilinear",
+    "ccvs_gpt_decode_step", "ccvs_gpt_decode_status", "ccvs_gpt_program_bytes", "ccvs_gpt_decode_prepare", "ccvs_pack_u8", "ccvs_pack_u8_norm", "ccvs_stream_cu_limit", "ccvs_psnr", "ccvs_ssim_workspace_bytes", "ccvs_ssim", "ccvs_resize_bilinear",
 ]
 
 
@@ -63,6 +63,7 @@ class GptDecode(C.Structure):
         ("noise", C.c_void_p), ("rng", C.c_int32), ("top_k", C.c_int32), ("temperature", C.c_float),
         ("workspace", C.c_void_p), ("state", C.c_void_p), ("groups", C.c_int32),
         ("noise_stream", C.c_void_p),
+        ("persistent", C.c_int32), ("program", C.c_void_p),
     ]
 
 
@@ -90,6 +91,8 @@ def load():
     lib.ccvs_gemm_workspace_bytes.argtypes = []
     lib.ccvs_ssim_workspace_bytes.restype = C.c_int64
     lib.ccvs_ssim_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+    lib.ccvs_gpt_program_bytes.restype = C.c_int64
+    lib.ccvs_gpt_program_bytes.argtypes = [C.c_int32]
     lib.ccvs_conv_fetch_bytes_per_lane.restype = C.c_int
     lib.ccvs_conv_fetch_bytes_per_lane.argtypes = [C.c_char_p]
     sigs = {
@@ -118,6 +121,8 @@ def load():
         "ccvs_sample_topk_philox": [vp, i64, vp, i64, i32, i32, i32, f32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp],
         "ccvs_sample_topn": [vp, i64, vp, vp, vp, i32, i32, i32, f32, i32, vp],
         "ccvs_gpt_decode_step": [C.POINTER(GptDecode), vp],
+        "ccvs_gpt_decode_status": [vp, vp],
+        "ccvs_gpt_decode_prepare": [C.POINTER(GptDecode), vp],
         "ccvs_pack_u8": [vp, vp, i64, i32, i32, f32, f32, vp],
         "ccvs_pack_u8_norm": [vp, vp, i64, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp],
         "ccvs_stream_cu_limit": [vp, i32],

@@ -166,6 +166,12 @@ class GPT(nn.Module):
         # group, block i = the [rows, V] Exp(1) draw of pick i in the order of the reference's generator (`Generator.run_pipelined`
         # draws them on a noise thread, batch after batch).  None: generate() draws its own through `host_noise` (one group only).
         self.noise_streams = None
+        # persistent_step: the decode step as ONE launch of resident workgroups with in-launch grid barriers (gpt.hip:
+        # gpt_step_kernel; `ccvs_gpt_decode.persistent`) instead of 5 n_layer + 3 dependent launches -- bit-identical tokens
+        # (tests/test_persistent_step_gpu.py).  A step then holds its CU slots for its whole duration: for schedules with ONE
+        # token loop in flight (`Generator.run_pipelined` with chains = 1).  CCVS_DECODE_PERSISTENT=1 turns it on.
+        import os
+        self.persistent_step = os.environ.get("CCVS_DECODE_PERSISTENT", "0") == "1"
 
     @property
     def _graphs(self):
@@ -508,7 +514,7 @@ class GPT(nn.Module):
         device_rng = sampler["sample"] and sampler["noise"] == "device"
         host_stream = bool(sampler["sample"] and not device_rng and sampler.get("stream"))   # host noise read from a pre-drawn stream
         key = (tuple(blk._folded[0] for blk in self.blocks), head_key, sampler["sample"], sampler["top_k"],
-               sampler["temperature"], device_rng, host_stream, c["frame_pos0"])
+               sampler["temperature"], device_rng, host_stream, c["frame_pos0"], bool(self.persistent_step))
         if c["desc"] is None or c["desc"][0] != key:
             layers = []
             for i, blk in enumerate(self.blocks):
@@ -523,10 +529,19 @@ class GPT(nn.Module):
                 x=c["x"], q=c["q"], att=c["att"], h=c["h"], logits=c["logits"],
                 noise=c["noise"] if (sampler["sample"] and not device_rng and not host_stream) else None, rng=device_rng,
                 noise_stream=c["noise_ptrs"] if host_stream else None,
-                top_k=sampler["top_k"], temperature=sampler["temperature"], state=c["state"])
+                top_k=sampler["top_k"], temperature=sampler["temperature"], state=c["state"], persistent=self.persistent_step)
             c["desc"] = (key, desc)
             c["graphs"] = {}   # captured graphs replay the OLD descriptor's pointers (packed weights are freed with it)
         return c["desc"][1]
+
+    def check_steps(self):
+        """Persistent decode steps: wait for the current stream and raise if a grid barrier of a step enqueued so far gave up (its
+        tokens would be garbage).  No-op for the launch chain.  generate() calls it in front of every sequence -- i.e. behind the
+        previous one on this stream --, callers that read the last sequence's tokens call it themselves (tests, bench.py)."""
+        for c in self._caches.values():
+            if c.get("desc") is not None and c["desc"][1].persistent:
+                c["desc"][1].status()
+                return      # one workspace per stream: one check covers every cache of this engine
 
     def _emit(self, logits, sampler, noise, col, words=None, step=None):
         """Pick the next token from `logits` into c['tok'] and store it in column `col` of c['codes'] (`words`, `step`: in-kernel
@@ -792,6 +807,8 @@ class GPT(nn.Module):
                 eager = True
         sampler["stream"] = host and not eager
         max_len = n_pre + n_cond + t0 + add_len
+        if self.persistent_step and not self.warm_only:
+            self.check_steps()   # the previous sequence's steps on this stream all passed their barriers
         c = self.begin(b, max_len)
 
         device_rng = sample and noise == "device"

@@ -617,7 +617,7 @@ class GptDecodeStep:
     `launch()` enqueues one whole decode step on the current stream."""
 
     def __init__(self, layers, B, C, H, Tmax, ln_eps, tok_emb, pos_table, pos_off, head, tok, codes, widx, length,
-                 x, q, att, h, logits, noise, top_k, temperature, state, rng=False, groups=1, noise_stream=None):
+                 x, q, att, h, logits, noise, top_k, temperature, state, rng=False, groups=1, noise_stream=None, persistent=False):
         hw, hb, hs = head
         keep = [tok_emb, pos_table, hw, hb, hs, tok, codes, widx, length, x, q, att, h, logits, noise, state, noise_stream]
         for t in keep:
@@ -658,10 +658,25 @@ class GptDecodeStep:
         d.workspace, d.state = _p(self.ws), _p(state)
         d.groups = groups
         self.desc, self._arr, self._keep = d, arr, keep
+        self.persistent = bool(persistent)
+        if self.persistent:
+            # ONE launch per step (gpt.hip: gpt_step_kernel): its phase table lives in a device buffer of ours, written once, here
+            # (a synchronous copy on the current stream: descriptors are built outside graph capture)
+            L = _lib.load()
+            self.program = torch.empty(int(L.ccvs_gpt_program_bytes(len(layers))), dtype=torch.uint8, device=x.device)
+            d.persistent, d.program = 1, _p(self.program)
+            _lib.check(L.ccvs_gpt_decode_prepare(C.byref(d), _stream()), "ccvs_gpt_decode_prepare")
 
     def launch(self):
         L = _lib.load()
         _lib.check(L.ccvs_gpt_decode_step(C.byref(self.desc), _stream()), "ccvs_gpt_decode_step")
+
+    def status(self):
+        """Persistent step: synchronise the current stream and raise if a grid barrier of any step launched with this workspace gave
+        up (a workgroup that never became resident): the tokens of that step are invalid."""
+        if self.persistent:
+            L = _lib.load()
+            _lib.check(L.ccvs_gpt_decode_status(_p(self.ws), _stream()), "ccvs_gpt_decode_status")
 
 
 def stream_cu_limit(stream, cu_limit):

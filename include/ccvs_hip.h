@@ -331,8 +331,23 @@ typedef struct ccvs_gpt_decode {
      * the host only rewrites the pointer table (stream-ordered) when a new sequence starts: reference-seed sampling inside
      * hipGraph replays and inside row groups. */
     const float* const* noise_stream;
+    /* ABI 6.  0: the step is 5 * n_layer + 3 dependent launches (above).  1: ONE launch of resident workgroups (one per CU) that walk the
+     * same phases with in-launch grid barriers (gpt.hip, gpt_step_kernel): the same tile bodies in the same order, so the tokens are
+     * bit-identical to the launch chain's; needs `workspace` and `program`, B <= 256.  A step holds its CU slots for its whole
+     * duration: meant for schedules with ONE token loop in flight per GPU (two persistent steps beside the frame decoder wait
+     * for each other's slots).  Check ccvs_gpt_decode_status(workspace, stream) when a sequence is done. */
+    int32_t persistent;
+    void* program;                      /* persistent = 1: device buffer of ccvs_gpt_program_bytes(n_layer) bytes, filled by ccvs_gpt_decode_prepare */
 } ccvs_gpt_decode;
 int ccvs_gpt_decode_step(const ccvs_gpt_decode* d, void* stream);
+/* Synchronises `stream` and returns 0 unless a grid barrier of a persistent decode step launched with this workspace gave up (a
+ * workgroup that never became resident within 5 s): the tokens of that step are then invalid and the call says which phase. */
+int ccvs_gpt_decode_status(const void* workspace, void* stream);
+/* The phase table of the persistent step: one entry per launch of the chain it replaces (operands, K slicing as the chain's launcher
+ * decides it), written into d->program by a synchronous copy on `stream` -- once per descriptor (and again when a pointer or shape
+ * in it changes), outside graph capture. */
+int64_t ccvs_gpt_program_bytes(int32_t n_layer);
+int ccvs_gpt_decode_prepare(const ccvs_gpt_decode* d, void* stream);
 
 /* ---- sharing the chip between two streams ------------------------------------------
  * ccvs_stream_cu_limit(stream, n): work submitted to `stream` from now on occupies at most n compute units (0 lifts the

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert sorted(built_lib.EXPORTS) == declared, "ccvs_amd/lib.py EXPORTS out of sync with the header"
     built_lib.load()
     handle.ccvs_abi_version.restype = ctypes.c_int
-    assert handle.ccvs_abi_version() == 5
+    assert handle.ccvs_abi_version() == 6
 
 
 def test_conv_desc_layout_matches_c(built_lib, tmp_path):
