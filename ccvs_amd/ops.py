@@ -665,7 +665,8 @@ class GptDecodeStep:
             L = _lib.load()
             self.program = torch.empty(int(L.ccvs_gpt_program_bytes(len(layers))), dtype=torch.uint8, device=x.device)
             d.persistent, d.program = 1, _p(self.program)
-            _lib.check(L.ccvs_gpt_decode_prepare(C.byref(d), _stream()), "ccvs_gpt_decode_prepare")
+            import ctypes   # (`C` is the embedding width in this scope)
+            _lib.check(L.ccvs_gpt_decode_prepare(ctypes.byref(d), _stream()), "ccvs_gpt_decode_prepare")
 
     def launch(self):
         L = _lib.load()

@@ -29,4 +29,4 @@ for f in sorted(glob.glob("gpurun_out/r06b/bench_*.json")):
           "stage", {k: round(v) for k, v in r["stage_ms_per_step"].items()}, "conv alone %.1f in-run %.1f" % (r["roofline"]["achieved"], (r["roofline"]["in_timed_region"] or {}).get("achieved", 0)),
           "self_check", (r.get("self_check") or {}).get("pipelined_equals_serial"), "hbm_gb %.0f" % r.get("hbm_peak_allocated_gb", 0))
 PY
-tail -3 $O/*.err | grep -v '^$' | tail -30
+for f in $O/*.err; do echo "== $f"; tail -n 3 $f; done | tail -n 40
