@@ -417,8 +417,15 @@ __device__ __forceinline__ void gemm16_tile(const float* __restrict__ x_, const 
 #undef GP
 }
 
+// -DCCVS_GEMM16_NUM_VGPR=48 (an experiment, tools/r06/run3.sh): hipcc then allocates the one-block form 46 registers and no AGPRs
+// instead of 50 + 4 (56 allocated: it does not fit beside two 232-register convolution waves), the 2 x 2 form 48 + 0 instead of 32 + 16.
+#ifdef CCVS_GEMM16_NUM_VGPR
+#define GEMM16_ATTR __attribute__((amdgpu_num_vgpr(CCVS_GEMM16_NUM_VGPR)))
+#else
+#define GEMM16_ATTR
+#endif
 template <int WNT, int RB, int CB, int U>
-__global__ __launch_bounds__(64 * GEMM_WAVES) void gemm16_kernel(const float* __restrict__ x_, const float* __restrict__ w_, long ldx_, int K_, int N_,
+__global__ __launch_bounds__(64 * GEMM_WAVES) GEMM16_ATTR void gemm16_kernel(const float* __restrict__ x_, const float* __restrict__ w_, long ldx_, int K_, int N_,
                                                                 int M_, int ks_, int kz_, Gemm16 p) {
     TOKEN_PRIO();
     __shared__ __attribute__((aligned(16))) float red[GEMM16_RED_WORDS(RB * CB)];
