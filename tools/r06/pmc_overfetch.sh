@@ -4,8 +4,9 @@
 # 40 x 10 pixels per 32 x 8 output pixels = 1.5625 x the input if no neighbour's fetch is ever an L2 hit.  Per shape: FETCH_SIZE
 # (x2: 16 bytes per lane), L2 hits / misses, L2 read requests -- with the XCD-aware tile order and with the plain one.
 cd /tmp && export TMPDIR=/tmp
-for SHAPE in "195 128 3 256 48" "128 64 3 256 48 p8"; do
-  for XCD in 1 0; do
+IFS=';' read -ra SHAPE_LIST <<< "${SHAPES:-195 128 3 256 48;128 64 3 256 48 p8}"     # SHAPES="Cin Cout k H N [p8] [pre=K];..."
+for SHAPE in "${SHAPE_LIST[@]}"; do
+  for XCD in ${XCDS:-1 0}; do
     echo "== shape (Cin Cout k H N) $SHAPE   CCVS_CONV_XCD=$XCD"
     for c in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
       rm -rf /tmp/pmc; CCVS_CONV_XCD=$XCD timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/conv_one.py $SHAPE > /tmp/pmc.log 2>&1
