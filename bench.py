@@ -63,8 +63,10 @@ def parse_args():
                          "(~10 s of one CPU thread, what the reference's CPU path spends too); Drums' ancillary picks are not one plain stream")
     ap.add_argument("--no-other-noise-leg", action="store_true", help="skip the second timed pass (same K batches) with the other noise source")
     ap.add_argument("--conv-precision", type=str, default=None, choices=["bf16x3", "f32"])
-    ap.add_argument("--schedule", type=str, default=os.environ.get("CCVS_BENCH_SCHEDULE", "pipelined"), choices=["serial", "pipelined"],
-                    help="serial: batches one after the other; pipelined: token loop of batch i+1 beside the decoder of batch i")
+    ap.add_argument("--schedule", type=str, default=os.environ.get("CCVS_BENCH_SCHEDULE", "pipelined"), choices=["serial", "stream", "pipelined"],
+                    help="serial: batches one after the other, token loop then decode (the single-call drop-in, Generator.generate_vid); stream: batches one "
+                         "after the other, the decoder of a batch following ITS OWN token loop frame by frame (generate_vid(schedule='stream')); pipelined: "
+                         "several batches in flight (token loops of batches i+1.. beside the decoder of batch i)")
     ap.add_argument("--cu-limit", type=int, default=None, help="pipelined: CUs the decoder stream may occupy while token loops are in flight")
     ap.add_argument("--lanes", type=int, default=None, help="pipelined: batches whose token loops run as ONE loop over their stacked rows (a token group)")
     ap.add_argument("--chains", type=int, default=None, help="pipelined: token groups that run beside each other (one stream each)")
@@ -467,7 +469,7 @@ def main():
                 ops.CONV_CU_LIMIT = args.cu_limit or 0     # (experiments: the cost of capping the convolutions, in isolation)
                 handles, stages = [], {"encode": 0.0, "transformer": 0.0, "decode": 0.0}
                 for i, data in enumerate(batches):
-                    out = gen.generate_vid(data, first + i)
+                    out = gen.generate_vid(data, first + i, schedule="stream" if args.schedule == "stream" else "serial")
                     handles.append(finish(first + i, out["fake"]))
                     for k, v in gen.stage_ms().items():
                         stages[k] += v
@@ -517,7 +519,7 @@ def main():
                 timer_p = ops.KernelTimer()
                 ops.KERNEL_TIMER = timer_p
                 torch.manual_seed(rank_seed)
-                out_p = gen.generate_vid({k: v.clone() for k, v in batches[0].items()}, 0)
+                out_p = gen.generate_vid({k: v.clone() for k, v in batches[0].items()}, 0, schedule="serial")
                 torch.cuda.synchronize()
                 ops.KERNEL_TIMER = None
                 n_p, f_p, ms_p = timer_p.summary("conv2d_" + ops.CONV_PRECISION)
@@ -601,7 +603,8 @@ def main():
                                         + (f", whose kernels are capped to {gen.last_cu_limit} of {n_cu} CUs" if gen.last_cu_limit else "")
                                         + f"; every generate call is one batch of {args.batch} clips; "
                                         "K batches timed from resident inputs to gathered clips, fill and drain included") if args.schedule == "pipelined"
-                                       else "serial: one batch at a time",
+                                       else ("serial: one batch at a time" if args.schedule == "serial" else
+                                             "stream: one batch at a time, its decoder following its own token loop frame by frame (generate_vid(schedule='stream'))"),
                            "parallelism": f"dp{world} (batch sharded, one RCCL all-gather of uint8 clips on a side stream)",
                            "conv_intermediates": ("packed split-bf16 (hi + lo, 4 bytes per element like fp32; bit-identical results) between the convolutions of "
                                                   "Matching / Subpixel" if (ops.CONV_P8 and kind == "bf16x3") else "fp32")},
@@ -810,7 +813,7 @@ def main():
                 # one B = 16 comparison of the two arithmetics: timed batch 0 decoded by both (GPU vs GPU, teacher-forced on the
                 # headline's tokens so that a VQ near-tie flipped by the encoder's arithmetic cannot hide the pixel difference)
                 torch.manual_seed(rank_seed)
-                ref_out = gen.generate_vid({k: v.clone() for k, v in batches[0].items()}, 0)          # split-bf16, batch 0 (= the self-check's clip)
+                ref_out = gen.generate_vid({k: v.clone() for k, v in batches[0].items()}, 0, schedule="serial")          # split-bf16, batch 0 (= the self-check's clip)
                 ops.CONV_PRECISION = "f32"
                 try:
                     t32 = ops.KernelTimer()
@@ -840,7 +843,7 @@ def main():
                         torch.manual_seed(rank_seed)
                         t0 = time.perf_counter()
                         for i in range(2):
-                            gen.generate_vid({k: v.clone() for k, v in batches[i % len(batches)].items()}, i)
+                            gen.generate_vid({k: v.clone() for k, v in batches[i % len(batches)].items()}, i, schedule="serial")
                         torch.cuda.synchronize()
                         dt = time.perf_counter() - t0
                         n_b, sched, stage32 = 2, "serial, 2 batches", None

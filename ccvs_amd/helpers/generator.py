@@ -249,8 +249,29 @@ class Generator:
         return rec_data
 
     @torch.no_grad()
-    def generate_vid(self, data, global_iter=0, save=False):
+    def generate_vid(self, data, global_iter=0, save=False, schedule=None):
+        """One batch through the synthesis path (reference helpers/generator.py:57-230).  `schedule`:
+          "serial"  the reference's order -- encode, the whole token loop, then the decode;
+          "stream"  the same work with the DECODER FOLLOWING THE TOKEN LOOP frame by frame (it needs the tokens of frame t only to decode
+                    frame t, quantized_video_model.py:868-903): the one-batch case of `run_pipelined` (its token stream + one decode stream,
+                    the call's host noise pre-drawn by the noise threads instead of inline) -- same clips, bit for bit, the call returns when
+                    everything is enqueued on the caller's stream as before;
+        None = `CCVS_GENERATE_VID_SCHEDULE` (default "serial").  step_by_step / rec_only calls are serial whatever is asked."""
         opt = self.opt
+        if schedule is None:
+            schedule = os.environ.get("CCVS_GENERATE_VID_SCHEDULE", "serial")
+        if schedule == "stream" and not (opt.step_by_step or opt.rec_only):
+            from ccvs_amd.helpers.pipeline import PipelinedRun
+            run = PipelinedRun(self, [data], first_iter=global_iter, lanes=1, chains=1,
+                               rec_pass=not opt.gen_from_img and getattr(opt, "rec_pass", True))
+            out = run.run()[0]
+            ev = self._pipeline_events[-1]
+            self._events_stream = ev
+            out = {"real": out["real"], "fake": out["fake"], "rec": out["rec"], "enc_code": out["enc_code"], "real_state": out["real_state"]}
+            if save:
+                self.save_results(out, global_iter)
+            return out
+        self._events_stream = None
         self._seed_sampler(data["vid"].shape[0], global_iter)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
@@ -446,6 +467,10 @@ class Generator:
         """encode / transformer / decode milliseconds of the last `generate_vid` (the reference's
         unused t0..t3, generator.py:68-165), from HIP events."""
         torch.cuda.synchronize()
+        ev = getattr(self, "_events_stream", None)
+        if ev is not None:      # schedule "stream": the stages overlap in time (HIP events on the stages' own streams)
+            return {"encode": ev["e0"].elapsed_time(ev["e1"]), "transformer": ev["t0"].elapsed_time(ev["t1"]),
+                    "decode": sum(a.elapsed_time(b) for a, b in ev["segs"])}
         e = self._events
         return {"encode": e[0].elapsed_time(e[1]), "transformer": e[1].elapsed_time(e[2]), "decode": e[2].elapsed_time(e[3])}
 
