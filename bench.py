@@ -502,7 +502,7 @@ def main():
             gathered = [None] * world
             dist.all_gather_object(gathered, rank_stages[0])
             rank_stages = gathered
-        alone, self_check, alone_passes = None, None, None
+        alone, self_check, alone_passes, single_call = None, None, None, None
         if engine.is_main and args.schedule == "pipelined":
             # timed batch 0 once more, ALONE on the serial schedule (generate_vid: same inputs, same iteration index, the process
             # generator re-seeded as in front of the timed pass -- batch 0 is its first consumer in both), outside the timed region:
@@ -514,13 +514,16 @@ def main():
             # after the timed region single passes of one box came out between 183 and 266 TFLOP/s (the same pass in a process of
             # its own: 266-267 every time, tools/r05/alone_var.py) -- the first pass runs into whatever the timed region left behind
             # (clock state; worker threads winding down on the host side of the launch-bound small convolutions).
-            passes = []
+            passes, serial_call_s = [], []
             for _ in range(3):       # ALONE_PASSES
                 timer_p = ops.KernelTimer()
                 ops.KERNEL_TIMER = timer_p
                 torch.manual_seed(rank_seed)
+                torch.cuda.synchronize()
+                t_call = time.perf_counter()
                 out_p = gen.generate_vid({k: v.clone() for k, v in batches[0].items()}, 0, schedule="serial")
                 torch.cuda.synchronize()
+                serial_call_s.append(time.perf_counter() - t_call)
                 ops.KERNEL_TIMER = None
                 n_p, f_p, ms_p = timer_p.summary("conv2d_" + ops.CONV_PRECISION)
                 passes.append((f_p / (ms_p * 1e-3) / 1e12 if ms_p > 0 else 0.0, timer_p, (n_p, f_p, ms_p)))
@@ -541,6 +544,28 @@ def main():
                 if not self_check["pipelined_equals_serial"]:
                     print(f"bench.py: SELF-CHECK FAILED: {self_check}", file=sys.stderr, flush=True)
             kept.pop("fake", None)
+            # the single-call drop-in (Generator.generate_vid, ONE batch, nothing else in flight): the three passes above are that call in the
+            # reference's order (token loop, then decode); the same call with the decoder following its own token loop frame by frame
+            # (schedule="stream", the default of generate_vid since round 6): one untimed call (its decode step's capture key), two timed
+            stream_call_s, same_stream = [], None
+            for rep in range(3):
+                torch.manual_seed(rank_seed)
+                torch.cuda.synchronize()
+                t_call = time.perf_counter()
+                out_q = gen.generate_vid({k: v.clone() for k, v in batches[0].items()}, 0, schedule="stream")
+                torch.cuda.synchronize()
+                if rep:
+                    stream_call_s.append(time.perf_counter() - t_call)
+                else:
+                    same_stream = bool(torch.equal(out_q["fake"]["code"], out_s["fake"]["code"]) and torch.equal(out_q["fake"]["vid"], out_s["fake"]["vid"]))
+                del out_q
+            single_call = {"serial_frames_per_s": predicted * args.batch / min(serial_call_s), "stream_frames_per_s": predicted * args.batch / min(stream_call_s),
+                           "serial_ms_per_call": [round(1e3 * v) for v in serial_call_s], "stream_ms_per_call": [round(1e3 * v) for v in stream_call_s],
+                           "stream_equals_serial": same_stream,
+                           "note": "Generator.generate_vid on ONE batch with nothing else in flight, wall time per call (best of the calls listed): `serial` = encode, "
+                                   "the whole token loop, then the decode (the reference's order; these are the three alone passes of the convolution roofline, "
+                                   "HIP-event timers on); `stream` = the decoder follows the call's own token loop frame by frame (generate_vid's default); "
+                                   "same clips bit for bit"}
             del out_s
         if engine.is_main:
             n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -609,6 +634,7 @@ def main():
                            "conv_intermediates": ("packed split-bf16 (hi + lo, 4 bytes per element like fp32; bit-identical results) between the convolutions of "
                                                   "Matching / Subpixel" if (ops.CONV_P8 and kind == "bf16x3") else "fp32")},
                 "self_check": self_check,
+                "single_call": single_call,
                 "stage_ms_per_step": {k: v / args.steps for k, v in stage.items() if k != "timeline"},
                 "timeline_ms": stage.get("timeline"),
                 "stage_note": "per-batch stage durations from HIP events on the stage's own stream" +

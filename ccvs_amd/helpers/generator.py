@@ -256,10 +256,11 @@ class Generator:
                     frame t, quantized_video_model.py:868-903): the one-batch case of `run_pipelined` (its token stream + one decode stream,
                     the call's host noise pre-drawn by the noise threads instead of inline) -- same clips, bit for bit, the call returns when
                     everything is enqueued on the caller's stream as before;
-        None = `CCVS_GENERATE_VID_SCHEDULE` (default "serial").  step_by_step / rec_only calls are serial whatever is asked."""
+        None = `CCVS_GENERATE_VID_SCHEDULE` (default "stream": BAIR batch 16, one call, 2.02 s against 2.23 s = 119 against 107 frames/s,
+        profiles/r06_single_call_probe.txt).  step_by_step / rec_only calls are serial whatever is asked."""
         opt = self.opt
         if schedule is None:
-            schedule = os.environ.get("CCVS_GENERATE_VID_SCHEDULE", "serial")
+            schedule = os.environ.get("CCVS_GENERATE_VID_SCHEDULE", "stream")
         if schedule == "stream" and not (opt.step_by_step or opt.rec_only):
             from ccvs_amd.helpers.pipeline import PipelinedRun
             run = PipelinedRun(self, [data], first_iter=global_iter, lanes=1, chains=1,

@@ -98,7 +98,7 @@ def test_pipelined_host_noise_equals_serial_and_oracle(tiny, monkeypatch, lanes,
         gen.vid_model, gen.transformer_model = tiny["qv"], tiny["tr"]
         batches = [gen.synthetic_batch(2, seed=70 + i)["vid"] for i in range(5)]
         torch.manual_seed(321)
-        serial = [gen.generate_vid({"vid": b.clone()}, global_iter=i) for i, b in enumerate(batches)]
+        serial = [gen.generate_vid({"vid": b.clone()}, global_iter=i, schedule="serial") for i, b in enumerate(batches)]
         torch.manual_seed(321)
         res = gen.run_pipelined(({"vid": b.clone()} for b in batches), lanes=lanes, chains=chains)
         torch.cuda.synchronize()
@@ -131,7 +131,7 @@ def test_cold_packed_weights_with_two_decode_streams(tiny, monkeypatch):
         gen = Generator(tiny["opt"])
         gen.vid_model, gen.transformer_model = tiny["qv"], tiny["tr"]
         batches = [gen.synthetic_batch(2, seed=40 + i)["vid"] for i in range(4)]
-        serial = [gen.generate_vid({"vid": b.clone()}, global_iter=i) for i, b in enumerate(batches)]
+        serial = [gen.generate_vid({"vid": b.clone()}, global_iter=i, schedule="serial") for i, b in enumerate(batches)]
         torch.cuda.synchronize()
         cleared = 0
         for mod in gen.vid_model.modules():          # start cold: every lazily built form is dropped
@@ -164,7 +164,7 @@ def test_pipelined_without_the_flow_guided_decoder(monkeypatch):
         cb = gen.vid_model.net_q.embedding.weight
         cb.copy_(torch.randn(cb.shape, generator=torch.Generator().manual_seed(4)).cuda())
     batches = [gen.synthetic_batch(2, seed=20 + i)["vid"] for i in range(3)]
-    serial = [gen.generate_vid({"vid": b.clone()}, global_iter=i) for i, b in enumerate(batches)]
+    serial = [gen.generate_vid({"vid": b.clone()}, global_iter=i, schedule="serial") for i, b in enumerate(batches)]
     res = gen.run_pipelined(({"vid": b.clone()} for b in batches), lanes=2, chains=1)
     torch.cuda.synchronize()
     for want, got in zip(serial, res):

@@ -29,7 +29,7 @@ def test_pipelined_equals_serial(tiny, monkeypatch, sample, cu_limit, lanes, cha
         gen = Generator(tiny["opt"])
         gen.vid_model, gen.transformer_model = tiny["qv"], tiny["tr"]
         batches = [gen.synthetic_batch(2, seed=80 + i)["vid"] for i in range(5)]
-        serial = [gen.generate_vid({"vid": b.clone()}, global_iter=10 + i) for i, b in enumerate(batches)]
+        serial = [gen.generate_vid({"vid": b.clone()}, global_iter=10 + i, schedule="serial") for i, b in enumerate(batches)]
         packed = []
         res = gen.run_pipelined(({"vid": b.clone()} for b in batches), first_iter=10, cu_limit=cu_limit, lanes=lanes, chains=chains, ramp=ramp,
                                 finish=lambda i, fake: packed.append((i, ops.pack_u8(fake["vid"]))))
@@ -53,6 +53,45 @@ def test_pipelined_equals_serial(tiny, monkeypatch, sample, cu_limit, lanes, cha
         tiny["tr"].sample_noise = old_noise
 
 
+@pytest.mark.parametrize("sample,noise,rec", [(False, "device", False), (True, "device", True), (True, "host", False), (True, "host", True)])
+def test_generate_vid_stream_equals_serial(tiny, sample, noise, rec):
+    """`generate_vid(schedule="stream")` -- the single call with the decoder following the token loop frame by frame, the default since
+    round 6 -- against `schedule="serial"` (token loop, then decode: the reference's order, helpers/generator.py:161-164): codes, fp32
+    pixels, the rec pass and the stage timers, greedy / Philox / the reference's host-drawn noise under one seed; and the default IS the
+    streamed schedule."""
+    from ccvs_amd.helpers.generator import Generator
+    xopt = tiny["xopt"]
+    xopt.sample, xopt.top_k, xopt.rec_pass = sample, 10, rec
+    old_noise = tiny["tr"].sample_noise
+    tiny["tr"].sample_noise = noise
+    try:
+        gen = Generator(tiny["opt"])
+        gen.vid_model, gen.transformer_model = tiny["qv"], tiny["tr"]
+        for i in range(3):
+            data = gen.synthetic_batch(2, seed=300 + i)["vid"]
+            torch.manual_seed(40 + i)
+            want = gen.generate_vid({"vid": data.clone()}, global_iter=7 + i, schedule="serial")
+            ms_serial = gen.stage_ms()
+            torch.manual_seed(40 + i)
+            got = gen.generate_vid({"vid": data.clone()}, global_iter=7 + i, schedule="stream")
+            ms_stream = gen.stage_ms()
+            torch.manual_seed(40 + i)
+            dflt = gen.generate_vid({"vid": data.clone()}, global_iter=7 + i)
+            torch.cuda.synchronize()
+            for out in (got, dflt):
+                assert torch.equal(out["enc_code"], want["enc_code"])
+                assert torch.equal(out["fake"]["code"], want["fake"]["code"])
+                assert torch.equal(out["fake"]["vid"], want["fake"]["vid"]), "streamed single call differs from the serial order"
+                assert (out["rec"] is None) == (want["rec"] is None)
+                if rec:
+                    assert torch.equal(out["rec"]["vid"], want["rec"]["vid"])
+            assert all(v > 0 for v in ms_serial.values()) and all(v > 0 for v in ms_stream.values())
+            assert len(gen._pipeline_events[-1]["segs"]) == 4          # the default went through the frame-by-frame decode: 1 + 3 pieces
+    finally:
+        xopt.sample, xopt.rec_pass = False, True
+        tiny["tr"].sample_noise = old_noise
+
+
 def test_pipelined_ragged_batch_sizes(tiny, monkeypatch):
     """Batches of another size in the middle of a run: they start their own token groups, their decode steps are captured from
     the calling thread once no worker is launching, and every clip still equals the serial schedule's."""
@@ -66,7 +105,7 @@ def test_pipelined_ragged_batch_sizes(tiny, monkeypatch):
         gen.vid_model, gen.transformer_model = tiny["qv"], tiny["tr"]
         sizes = [2, 2, 3, 3, 3, 1, 2]
         batches = [gen.synthetic_batch(n, seed=60 + i)["vid"] for i, n in enumerate(sizes)]
-        serial = [gen.generate_vid({"vid": b.clone()}, global_iter=50 + i) for i, b in enumerate(batches)]
+        serial = [gen.generate_vid({"vid": b.clone()}, global_iter=50 + i, schedule="serial") for i, b in enumerate(batches)]
         for tr, _ in gen._chains:            # the serial calls above left captured steps behind: start cold
             tr.net_t.drop_engine_state()
         gen.transformer_model.net_t.drop_engine_state()
@@ -96,7 +135,7 @@ def test_failed_token_stage_surfaces_and_the_next_run_is_clean(tiny, monkeypatch
         gen = G.Generator(tiny["opt"])
         gen.vid_model, gen.transformer_model = tiny["qv"], tiny["tr"]
         batches = [gen.synthetic_batch(2, seed=90 + i)["vid"] for i in range(5)]
-        serial = [gen.generate_vid({"vid": b.clone()}, global_iter=30 + i) for i, b in enumerate(batches)]
+        serial = [gen.generate_vid({"vid": b.clone()}, global_iter=30 + i, schedule="serial") for i, b in enumerate(batches)]
         real = G._FrameFeed.on_tokens
         calls = {"n": 0}
 

@@ -75,7 +75,8 @@ def test_decoder_stencils_of_the_profiles_are_in_the_table(widths):
     assert found
     for n in found:
         assert widths.read_bytes_per_lane(n) in (4, 16, None), n
-    assert widths.fetch_scale("backwarp4_kernel") == (1.0, 2.0)          # 8-byte gathers: uncalibrated, a bracket
+    lo, hi = widths.fetch_scale("backwarp4_kernel")                      # 8-byte gathers: calibrated on a known byte count in round 6
+    assert lo == hi and 1.15 < lo < 1.25
     assert widths.fetch_scale("void blur4x4_tile_kernel(FirK, int, GridWalk)") == (2.0, 2.0)
 
 

@@ -2,7 +2,7 @@
 # Counters of the decoder's non-convolution kernels over one BAIR decode (tools/decode_only.py): per kernel name the launches,
 # average duration, HBM-side bytes (FETCH_SIZE / WRITE_SIZE, KiB; FETCH_SIZE corrected per kernel by tools/pmc_widths.py: x2 for the
 # kernels that read 16 bytes per lane -- gfx950 tallies such a stream at half its bytes, MI355X_MICROARCH.md "HBM" --, x1 for dword
-# streams, and BOTH bounds [x1, x2] for the gather kernels whose 8-byte taps the guide does not calibrate),
+# streams, x1.20 for the gather kernels (8-byte tap pairs: calibrated on backwarp4 with a known byte count, profiles/r06_pmc_gather_calibrate.txt)),
 # LDS cycles and bank conflicts, busy cycles.  Separate --pmc passes, kernel trace only (no other tracing domains).
 # usage (on the GPU box): bash tools/pmc_decoder_kernels.sh [batch]
 B=${1:-16}
@@ -48,7 +48,8 @@ for k in names:
     lo, hi = pmc_widths.fetch_scale(full.get(k, k + "_kernel"))      # raises on a kernel the table does not know
     bl = pmc_widths.read_bytes_per_lane(full.get(k, k + "_kernel"))
     fs = f"{f*hi:.2f}" if lo == hi else f"{f*lo:.2f}-{f*hi:.2f}"
+    bl = bl if bl else "8 g"
     rs = f"{(f*hi+w)/t/1e3:.2f}" if lo == hi else f"{(f*lo+w)/t/1e3:.2f}-{(f*hi+w)/t/1e3:.2f}"
     lds = c["SQ_LDS_IDX_ACTIVE"]; busy = c["SQ_BUSY_CYCLES"]
-    print(f"{k:20s} {len(dur[k]):8d} {t*1e3:9.2f} {t/len(dur[k])*1e6:8.1f} {str(bl or 'mixed'):>6s} {f:12.2f} {fs:>15s} {w:9.2f} {rs:>15s} {lds/busy if busy else 0:13.3f} {c['SQ_LDS_BANK_CONFLICT']/lds if lds else 0:13.3f}")
+    print(f"{k:20s} {len(dur[k]):8d} {t*1e3:9.2f} {t/len(dur[k])*1e6:8.1f} {str(bl):>6s} {f:12.2f} {fs:>15s} {w:9.2f} {rs:>15s} {lds/busy if busy else 0:13.3f} {c['SQ_LDS_BANK_CONFLICT']/lds if lds else 0:13.3f}")
 PY

@@ -4,7 +4,7 @@
 MI355X_MICROARCH.md, "HBM": on gfx950 FETCH_SIZE (= TCC_EA0_RDREQ x 64 B) reports exactly HALF the bytes of a wide coalesced
 streaming read (16 bytes per lane: global_load_dwordx4 and buffer_load ... lds alike); WRITE_SIZE is exact for 16-byte-per-lane
 stores; "other access widths are uncalibrated".  So a raw FETCH_SIZE must be doubled for the kernels that read 16 bytes per lane,
-left alone for dword streams, and for everything else the honest answer is a bracket [raw, 2 x raw].
+left alone for dword streams; the gather kernels' pattern was calibrated on a known byte count in round 6 (x 1.20, below).
 
 Round 5's tools/pmc_conv_traffic.sh kept its own list of "wide" instantiations (NTY in {1, 3, -8}) and missed the packed 3 x 3 form
 NTY = -83 -- 42 % of all raw convolution fetch -- so the bench line printed 0.612 GB per launch where the corrected counters say
@@ -21,7 +21,7 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB = None
 
-# access width of the dominant READ stream of the non-convolution kernels (bytes per lane; None = mixed / gathers: uncalibrated)
+# access width of the dominant READ stream of the non-convolution kernels (bytes per lane; None = the gather pattern: x 1.20, calibrated)
 STENCIL_READ_BYTES = {
     "blur4x4_tile_kernel": 16,        # resample.hip: F32Quad rows into the LDS tile
     "down2_tile_kernel": 16, "down2_kernel": 16,
@@ -79,11 +79,18 @@ def read_bytes_per_lane(kernel_name):
     return STENCIL_READ_BYTES[stem]
 
 
+# Round 6 calibrated the gather pattern itself (tools/r06/gather_calibrate.py, profiles/r06_pmc_gather_calibrate.txt): backwarp4 on 48 x 96
+# planes of 256 x 256 with sub-pixel flows needs 1233.1 MB of reads per launch (every source byte once + the flows) and FETCH_SIZE says
+# 1026.6 MB -- 0.833 of the bytes (the 8-byte tap pairs are tallied in full, the 16-byte flow rows and whatever the L2 turns into wide
+# requests at half); WRITE_SIZE is exact (1208.0 = 1208.0 MB).  The kernels of that pattern take x 1.20 instead of a [x1, x2] bracket.
+GATHER_FETCH_SCALE = 1233.1 / 1026.6
+
+
 def fetch_scale(kernel_name):
     """(low, high) multipliers of the raw FETCH_SIZE of this kernel: (2, 2) for 16-byte-per-lane streams, (1, 1) for dword streams,
-    (1, 2) where the width is mixed and the guide gives no calibration."""
+    (1.2, 1.2) for the gather kernels (8-byte tap pairs from gathered addresses: calibrated on backwarp4, see above)."""
     b = read_bytes_per_lane(kernel_name)
-    return (2.0, 2.0) if b == 16 else ((1.0, 1.0) if b == 4 else (1.0, 2.0))
+    return (2.0, 2.0) if b == 16 else ((1.0, 1.0) if b == 4 else (GATHER_FETCH_SCALE, GATHER_FETCH_SCALE))
 
 
 if __name__ == "__main__":
