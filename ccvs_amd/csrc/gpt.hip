@@ -1565,16 +1565,21 @@ __device__ __forceinline__ void step_barrier(StepBar* bar, unsigned target, int 
         if (threadIdx.x == 0) __hip_atomic_fetch_add(&bar->shard[blockIdx.x & 7][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned* sp = &bar->shard[threadIdx.x & 7][0];
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        for (;;) {
+        for (unsigned spins = 1;; ++spins) {
             unsigned v = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             v += __shfl_xor(v, 1, 64);
             v += __shfl_xor(v, 2, 64);
             v += __shfl_xor(v, 4, 64);
             if ((int)(v - target) >= 0) break;
             __builtin_amdgcn_s_sleep(2);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > STEP_SPIN_TICKS) {
-                if (threadIdx.x == 0) __hip_atomic_store(&bar->err[0], (unsigned)(phase + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
+            if ((spins & 255u) == 0) {
+                // give up: after 5 s without the others, or AT ONCE when any workgroup of this workspace has given up before (the word is
+                // sticky until ccvs_gpt_decode_status clears the whole barrier block) -- a lost workgroup costs one time-out, not one per phase
+                const bool late = __builtin_amdgcn_s_memrealtime() - t0 > STEP_SPIN_TICKS;
+                if (late || __hip_atomic_load(&bar->err[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    if (late && threadIdx.x == 0) __hip_atomic_store(&bar->err[0], (unsigned)(phase + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
             }
         }
     }
@@ -1699,7 +1704,11 @@ extern "C" int ccvs_gpt_decode_status(const void* workspace, void* stream) {
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) { ccvs_set_error("ccvs_gpt_decode_status: %s", hipGetErrorString(e)); return CCVS_ERR_LAUNCH; }
     if (err) {
-        ccvs_set_error("ccvs_gpt_decode_status: a grid barrier of the persistent decode step gave up (phase %u): the tokens of that step are invalid", err - 1);
+        // the arrival counters of the failed launch are inconsistent: start the workspace's barrier block over (every later step would
+        // otherwise give up at once on the sticky word), then report
+        (void)hipMemsetAsync((void*)bar, 0, sizeof(StepBar), (hipStream_t)stream);
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        ccvs_set_error("ccvs_gpt_decode_status: a grid barrier of the persistent decode step gave up (phase %u): the tokens of the steps since the last check are invalid", err - 1);
         return CCVS_ERR_LAUNCH;
     }
     return CCVS_OK;
