@@ -1517,12 +1517,16 @@ extern "C" int ccvs_sample_topn(const float* logits, int64_t ld, const float* no
 //     loads of 4 / 16 bytes).  `base` = the arrivals counted before this launch, kept in a word of its own that workgroup 0 moves
 //     forward once per launch (read by the NEXT launch only: a kernel boundary apart), so nothing is zeroed between launches and a
 //     captured step replays unchanged; comparisons are on the wrapped difference.  A poll that sees nothing for 5 s gives up, sets
-//     StepBar.err and lets the workgroup run on -- the results of that launch are garbage and ccvs_gpt_decode_status reports it.
-// Residency: G = the number of CUs; a workgroup (256 threads, <= 48 registers, <= 18 KB of LDS at BAIR size) fits beside a
-// convolution workgroup of the frame decoder like the launch chain's kernels do, but it HOLDS that slot for the whole step: two
-// token chains' persistent steps cannot both be resident beside the decoder on one CU, and partially resident grids that wait
-// for each other's slots stall until convolution workgroups retire -- a schedule with ONE token chain is what this form is for
-// (DESIGN.md 4.2).
+//     StepBar.err and lets the workgroup run on; the word is sticky -- every later barrier of this workspace gives up at once, so a lost
+//     workgroup costs ONE time-out, not one per phase -- the tokens since are garbage, and ccvs_gpt_decode_status reports it and
+//     starts the barrier block over.
+// Residency: G = the number of CUs; a workgroup (256 threads, 64 registers, <= 18 KB of LDS at BAIR size) fits beside the 3 x 3
+// convolution workgroups of the frame decoder (two waves of 208 / 214 registers per SIMD) but not beside the 1 x 1 forms' 225, and it
+// HOLDS its slot for the whole step: two token chains' persistent steps cannot both be resident beside the decoder on one CU, and
+// partially resident grids that wait for each other's slots stall until convolution workgroups retire -- a schedule with ONE token
+// chain is what this form is for.  MEASURED (profiles/r06_persistent_step.txt): bit-identical and 1.4-1.9 x slower than the launch
+// chain, alone and in the run -- ~7 us per grid barrier against 1.5-2 per kernel boundary, and one workgroup per CU where the chain
+// oversubscribes the chip (the attention phases run at ~2 TB/s instead of 5.7).  An opt-in, not the default.
 // ---------------------------------------------------------------------------------------
 #define STEP_SPIN_TICKS 500000000ULL   // 5 s of the 100 MHz s_memrealtime counter
 struct StepBar {
