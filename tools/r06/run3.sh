@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round 6, GPU call 3: the whole GPU suite on the refactored decode kernels, the over-fetch experiment, and the gemm16 register
 # attribute as a second library (build/nv48, -DCCVS_GEMM16_NUM_VGPR=48) against the default one.
+# The second library is not kept in the tree: cp -r ccvs_amd/csrc build/nv48 && make -C build/nv48 clean all EXTRA=-DCCVS_GEMM16_NUM_VGPR=48
+# (ROOT in its Makefile pointing at the repository) before the call; the result is profiles/r06_gemm16_num_vgpr_ab.txt.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06c
 O=gpurun_out/r06c
