@@ -465,6 +465,7 @@ def main():
                 stages = gen.pipeline_stage_ms()       # every rank: the line reports the stages per rank
                 if engine.is_main:
                     stages["timeline"] = gen.pipeline_timeline()
+                    stages["token_groups"] = gen.pipeline_token_groups()   # of THIS run: later passes (single_call: generate_vid streams through the same machinery) replace the generator's record
             else:
                 ops.CONV_CU_LIMIT = args.cu_limit or 0     # (experiments: the cost of capping the convolutions, in isolation)
                 handles, stages = [], {"encode": 0.0, "transformer": 0.0, "decode": 0.0}
@@ -496,7 +497,7 @@ def main():
         assert clips.shape[0] == args.batch * world
 
         # per-rank stage times (rank order) for the line: which rank, and which stage of it, bounds a multi-GPU run
-        rank_stages = [{k: v / args.steps for k, v in stage.items() if k != "timeline"}]
+        rank_stages = [{k: v / args.steps for k, v in stage.items() if k not in ("timeline", "token_groups")}]
         if engine.distributed:
             import torch.distributed as dist
             gathered = [None] * world
@@ -635,7 +636,7 @@ def main():
                                                   "Matching / Subpixel" if (ops.CONV_P8 and kind == "bf16x3") else "fp32")},
                 "self_check": self_check,
                 "single_call": single_call,
-                "stage_ms_per_step": {k: v / args.steps for k, v in stage.items() if k != "timeline"},
+                "stage_ms_per_step": {k: v / args.steps for k, v in stage.items() if k not in ("timeline", "token_groups")},
                 "timeline_ms": stage.get("timeline"),
                 "stage_note": "per-batch stage durations from HIP events on the stage's own stream" +
                               ("; in the pipelined schedule encode+decode (stream D) and the transformer stages (one stream per lane) overlap" if args.schedule == "pipelined" else ""),
@@ -692,7 +693,7 @@ def main():
             w_bytes = 4.0 * sum(p_.numel() for n_, p_ in net_t.named_parameters() if n_.startswith("blocks.") and p_.dim() == 2) + 4.0 * net_t.head.weight.numel()
             kv_bytes = 8.0 * args.batch * net_t.config.n_embd * len(net_t.blocks) * (xopt.cond_len + xopt.z_len) / 2
             if args.schedule == "pipelined":
-                groups = gen.pipeline_token_groups()
+                groups = stage["token_groups"]        # (recorded with the timed run's stages)
                 n_chains = gen.last_chains
             else:
                 groups, n_chains = [(1, stage["transformer"] / args.steps)] * args.steps, 1
@@ -805,7 +806,7 @@ def main():
                     torch.cuda.synchronize()
                     dt = time.perf_counter() - t0
                     line["encode_cond_only"] = {"value": frames / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / args.steps,
-                                                "stage_ms_per_step": {k: v / args.steps for k, v in stage_c.items() if k != "timeline"},
+                                                "stage_ms_per_step": {k: v / args.steps for k, v in stage_c.items() if k not in ("timeline", "token_groups")},
                                                 "frames_encoded_per_clip": gen._frames_to_encode(xopt.vid_len, int(torch.prod(torch.tensor(opt["qvid_generator"].z_shape)))),
                                                 "note": f"same {args.steps} batches and schedule, `--encode_all false`: the encoder sees the conditioning frame(s) only; "
                                                         "the synthesized clips are the same bits (tests/test_features_gpu.py::test_encode_conditioning_frames_only)"}
@@ -826,7 +827,7 @@ def main():
                     dt = time.perf_counter() - t0
                     line["sampling_" + other + "_noise"] = {
                         "value": frames / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / args.steps, "vs_headline": (frames / dt) / line["value"],
-                        "stage_ms_per_step": {k: v / args.steps for k, v in stage_o.items() if k != "timeline"},
+                        "stage_ms_per_step": {k: v / args.steps for k, v in stage_o.items() if k not in ("timeline", "token_groups")},
                         "note": f"same {args.steps} batches, same schedule, noise={other}" + (
                             ": in-kernel Philox keyed by the global clip index (validated distributionally; world-size invariant)" if other == "device" else
                             ": the reference's seeded torch.multinomial stream, pre-drawn per batch by the noise thread")}
@@ -875,7 +876,7 @@ def main():
                         n_b, sched, stage32 = 2, "serial, 2 batches", None
                     line["strict_f32"] = {"frames_per_s": predicted * args.batch * n_b / dt, "vs_headline": (predicted * args.batch * n_b / dt) / line["value"],
                                           "schedule": sched, "ms_per_step": 1e3 * dt / n_b,
-                                          "stage_ms_per_step": ({k: v / n_b for k, v in stage32.items() if k != "timeline"} if stage32 else None),
+                                          "stage_ms_per_step": ({k: v / n_b for k, v in stage32.items() if k not in ("timeline", "token_groups")} if stage32 else None),
                                           "conv_tflops": tf, "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS, "conv_launches": n32,
                                           "conv_measured": "HIP events around every convolution launch of one batch (encode + 15-frame decode) with nothing beside it"}
                 finally:

@@ -263,10 +263,18 @@ class Generator:
             schedule = os.environ.get("CCVS_GENERATE_VID_SCHEDULE", "stream")
         if schedule == "stream" and not (opt.step_by_step or opt.rec_only):
             from ccvs_amd.helpers.pipeline import PipelinedRun
-            run = PipelinedRun(self, [data], first_iter=global_iter, lanes=1, chains=1,
-                               rec_pass=not opt.gen_from_img and getattr(opt, "rec_pass", True))
-            out = run.run()[0]
-            ev = self._pipeline_events[-1]
+            # (the records of the last run_pipelined -- its events, lanes, chains -- are the caller's to read afterwards: a single call
+            #  in between must not replace them)
+            keep = {k: getattr(self, k, None) for k in ("_pipeline_events", "last_cu_limit", "last_lanes", "last_chains", "last_dec_streams")}
+            try:
+                run = PipelinedRun(self, [data], first_iter=global_iter, lanes=1, chains=1,
+                                   rec_pass=not opt.gen_from_img and getattr(opt, "rec_pass", True))
+                out = run.run()[0]
+                ev = self._pipeline_events[-1]
+            finally:
+                for k, v in keep.items():
+                    if v is not None:
+                        setattr(self, k, v)
             self._events_stream = ev
             out = {"real": out["real"], "fake": out["fake"], "rec": out["rec"], "enc_code": out["enc_code"], "real_state": out["real_state"]}
             if save:

@@ -86,7 +86,14 @@ def test_generate_vid_stream_equals_serial(tiny, sample, noise, rec):
                 if rec:
                     assert torch.equal(out["rec"]["vid"], want["rec"]["vid"])
             assert all(v > 0 for v in ms_serial.values()) and all(v > 0 for v in ms_stream.values())
-            assert len(gen._pipeline_events[-1]["segs"]) == 4          # the default went through the frame-by-frame decode: 1 + 3 pieces
+            assert len(gen._events_stream["segs"]) == 4                # the default went through the frame-by-frame decode: 1 + 3 pieces
+        # a single call in between does not replace the records of the last run_pipelined (bench.py reads them after its single-call leg)
+        batches = [gen.synthetic_batch(2, seed=330 + i)["vid"] for i in range(4)]
+        gen.run_pipelined(({"vid": b.clone()} for b in batches), first_iter=0, lanes=2, chains=2)
+        groups, events = gen.pipeline_token_groups(), gen._pipeline_events
+        gen.generate_vid({"vid": batches[0].clone()}, global_iter=0)
+        assert (gen.last_lanes, gen.last_chains) == (2, 2) and gen._pipeline_events is events
+        assert [g for g, _ in gen.pipeline_token_groups()] == [g for g, _ in groups] == [2, 2]
     finally:
         xopt.sample, xopt.rec_pass = False, True
         tiny["tr"].sample_noise = old_noise
