@@ -460,7 +460,7 @@ def main():
             if args.schedule == "pipelined":
                 ramp = tuple(int(v) for v in args.ramp.split(",") if v) if args.ramp is not None else None
                 res = gen.run_pipelined(iter(batches), first_iter=first, cu_limit=args.cu_limit, finish=finish, lanes=args.lanes, chains=args.chains,
-                                        ramp=ramp)
+                                        ramp=ramp, n_batches=len(batches))
                 handles = [r["finished"] for r in res]
                 stages = gen.pipeline_stage_ms()       # every rank: the line reports the stages per rank
                 if engine.is_main:

@@ -397,7 +397,8 @@ class Generator:
         return self._chains[k]
 
     @torch.no_grad()
-    def run_pipelined(self, batches, first_iter=0, cu_limit=None, finish=None, lanes=None, chains=None, ramp=None, rec_pass=None, consume=None):
+    def run_pipelined(self, batches, first_iter=0, cu_limit=None, finish=None, lanes=None, chains=None, ramp=None, rec_pass=None, consume=None,
+                      n_batches=None):
         """generate_vid over a sequence of batches with SEVERAL batches in flight on one GPU (`helpers/pipeline.py` says how: token
         groups x chains beside the encode stream and the decode streams, the decoder following the token loops frame by frame,
         host-drawn sampling noise pre-drawn in the reference's order).  Per batch the work is exactly generate_vid's -- encode,
@@ -411,9 +412,11 @@ class Generator:
         concurrent token loops, sizes of the first groups.  `rec_pass` None: off (the benchmark's metric counts synthesized
         frames only); `run()` passes the option.  Returns the list of per-batch results ({"fake", "rec", "real", "enc_code",
         "real_state", "finished", "index"}); with `consume(out)` every such dict is handed to the caller instead, on the batch's
-        decode stream right behind `finish`, and only {"index", "finished"} stays in the list (a run of a thousand batches)."""
+        decode stream right behind `finish`, and only {"index", "finished"} stays in the list (a run of a thousand batches).
+        `n_batches`: the length of `batches` when it is an iterator and the caller knows it (the warm-up then prepares only the
+        token-group sizes that will occur)."""
         return PipelinedRun(self, batches, first_iter=first_iter, cu_limit=cu_limit, finish=finish, lanes=lanes, chains=chains, ramp=ramp,
-                            rec_pass=bool(rec_pass), consume=consume).run()
+                            rec_pass=bool(rec_pass), consume=consume, n_batches=n_batches).run()
 
     def pipeline_stage_ms(self):
         """Encode / transformer / decode milliseconds of the last run_pipelined, summed over its batches (the stages overlap in
@@ -528,7 +531,8 @@ class Generator:
             last = None
             try:
                 if pipelined:
-                    res = self.run_pipelined(batches(), finish=gather, rec_pass=rec, consume=writer.put if writer is not None else (lambda out: None))
+                    res = self.run_pipelined(batches(), finish=gather, rec_pass=rec, consume=writer.put if writer is not None else (lambda out: None),
+                                             n_batches=opt.n_iter)
                     last = res[-1]["finished"] if res else None
                 else:
                     for global_iter, data in enumerate(batches()):

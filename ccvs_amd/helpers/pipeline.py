@@ -242,7 +242,8 @@ class PipelinedRun:
     """One call of `Generator.run_pipelined`: the configuration, the streams, the token groups (`jobs`) and decodes (`tasks`)
     in flight, and one method per stage of the schedule."""
 
-    def __init__(self, gen, batches, first_iter=0, cu_limit=None, finish=None, lanes=None, chains=None, ramp=None, rec_pass=False, consume=None):
+    def __init__(self, gen, batches, first_iter=0, cu_limit=None, finish=None, lanes=None, chains=None, ramp=None, rec_pass=False, consume=None,
+                 n_batches=None):
         opt = gen.opt
         if opt.step_by_step or opt.rec_only:
             raise NotImplementedError("run_pipelined covers the plain synthesis schedule (use generate_vid for step_by_step / rec_only)")
@@ -258,11 +259,18 @@ class PipelinedRun:
         self.depth = max(1, int(env("CCVS_PIPELINE_DEPTH", "2")))
         self.debug = env("CCVS_PIPELINE_DEBUG", "0") == "1"
         self.stream_frames = env("CCVS_PIPELINE_STREAM", "1") != "0"   # 0: a batch is decoded when its whole token stage is done
+        # Batches whose decode has begun and not ended hold their context rings (BAIR: 8.5 GB per batch of 16 clips -- 15 slots x 6
+        # levels); with the decoder following the token loops frame by frame EVERY batch of the running token groups would begin at
+        # once.  At most this many are in decode at a time, the oldest first; the others' tokens wait in their FrameFeed (0: no cap)
+        self.max_decoding = int(env("CCVS_PIPELINE_MAX_DECODING", "0"))
         self.frame_tokens = int(gen.qvid_opt.z_shape[0]) * int(gen.qvid_opt.z_shape[1])
         # host-drawn sampling noise: pre-drawn per batch when the batch's draws are one plain stream of [B, V] blocks; otherwise the
         # token stages draw for themselves and must run one after the other, in batch order (one chain, one batch per group)
         self.host_noise = bool(getattr(opt, "sample", False)) and getattr(gen.transformer_model, "sample_noise", "host") != "device"
         self.noise_feed = None
+        # batches of the run when the caller knows (a list; `Generator.run`'s n_iter): the warm-up then captures the decode step of the
+        # group sizes that WILL occur instead of every size up to `lanes` (one KV cache each: lanes (lanes + 1) / 2 x 3.2 GB per chain at BAIR)
+        self.n_batches = n_batches if n_batches is not None else (len(batches) if hasattr(batches, "__len__") else None)
         self.it = iter(batches)
         self.held = []            # a batch read ahead: the first one (its size decides below), or one that did not fit its group (ragged size)
         first = next(self.it, None)
@@ -430,7 +438,7 @@ class PipelinedRun:
             print(f"[pipeline] {self.lanes} -> {fit} batches per token group: {self.lanes * (self.chains + 2)} batches of {nb} clips in flight would not fit "
                   "the device memory (CCVS_PIPELINE_MEM_FRAC)", file=sys.stderr, flush=True)
             self.lanes = gen.last_lanes = fit
-        sizes = sorted({gen._token_group_size(nb, g) for g in range(1, self.lanes + 1)})
+        sizes = sorted({gen._token_group_size(nb, g) for g in self._group_sizes_ahead()})
         cold = [(c, g) for c in range(self.chains) for g in sizes if self._is_cold(c, nb, g)]
         if not cold:
             return
@@ -438,6 +446,19 @@ class PipelinedRun:
             ws = gen.condition({k: (v.clone() if torch.is_tensor(v) else v) for k, v in first.items()}, draw=False)
         for c, g in cold:
             self._warm(c, nb, g, ws)
+
+    def _group_sizes_ahead(self):
+        """Sizes of the token groups this run will form: every size up to `lanes` when the number of batches is unknown (a ragged tail can
+        be any of them), else exactly the ones `_submit_group` will ask for -- the ramp, then `lanes`, then the remainder."""
+        if self.n_batches is None:
+            return range(1, self.lanes + 1)
+        left, sizes, i = self.n_batches, set(), 0
+        while left > 0:
+            want = min(self.ramp[i] if i < len(self.ramp) else self.lanes, self.lanes, left)
+            sizes.add(max(1, want))
+            left -= max(1, want)
+            i += 1
+        return sorted(sizes)
 
     # ------------------------------------------------------------------ stage 1: encode + crop, queue the token stage
     @staticmethod
@@ -637,7 +658,10 @@ class PipelinedRun:
         t_end = time.perf_counter() + self.timeout
         while True:
             blocked = None
+            begun = sum(1 for t in self.tasks if t["m"].get("segs")) if self.max_decoding > 0 else 0
             for task in self.tasks:
+                if self.max_decoding > 0 and begun >= self.max_decoding and not task["m"].get("segs"):
+                    continue          # would be one more batch holding a context ring: wait for one of the begun ones to end
                 if self._is_ready(task):
                     if self._has_room(task):
                         return task
