@@ -368,3 +368,26 @@ def test_noise_feed_failure_is_sticky(monkeypatch):
     with _pytest.raises(RuntimeError):
         feed.close()
     assert torch.equal(g.get_state(), before)            # the process generator was not moved to a wrong position
+
+
+def test_group_sizes_the_warm_up_prepares():
+    """`PipelinedRun._group_sizes_ahead`: with the number of batches known the warm-up captures the decode step of exactly the group sizes
+    `_submit_group` will form (ramp, then `lanes`, then the remainder) -- every size up to `lanes` otherwise (each is a KV cache)."""
+    from ccvs_amd.helpers.pipeline import PipelinedRun
+
+    class _Run:
+        _group_sizes_ahead = PipelinedRun._group_sizes_ahead
+
+    r = _Run()
+    r.lanes, r.ramp, r.n_batches = 4, (), None
+    assert list(r._group_sizes_ahead()) == [1, 2, 3, 4]
+    r.n_batches = 20
+    assert list(r._group_sizes_ahead()) == [4]
+    r.n_batches = 5
+    assert list(r._group_sizes_ahead()) == [1, 4]
+    r.lanes, r.ramp, r.n_batches = 8, (4, 4, 4, 8), 20
+    assert list(r._group_sizes_ahead()) == [4, 8]
+    r.lanes, r.ramp, r.n_batches = 10, (), 20
+    assert list(r._group_sizes_ahead()) == [10]
+    r.lanes, r.ramp, r.n_batches = 4, (1, 2), 6
+    assert list(r._group_sizes_ahead()) == [1, 2, 3]
