@@ -1828,6 +1828,9 @@ static int launch_step_persistent(const ccvs_gpt_decode* d, int D, hipStream_t s
         n_cu = prop.multiProcessorCount;
     }
     const StepArgs* a = (const StepArgs*)d->program;   // written by ccvs_gpt_decode_prepare
+    // workgroups per CU (an experiment, CCVS_STEP_WGS_PER_CU; default 1): more of them are all resident only with the chip to the step
+    // itself -- beside the frame decoder a CU has room for one -- and every grid barrier then waits for 2-4 x the arrivals
+    static const int per_cu = getenv_int("CCVS_STEP_WGS_PER_CU", 1) < 1 ? 1 : (getenv_int("CCVS_STEP_WGS_PER_CU", 1) > 4 ? 4 : getenv_int("CCVS_STEP_WGS_PER_CU", 1));
     const bool t2 = d->B > 32;
     size_t words = t2 ? STEP_GEMM_WORDS(2, 2) : STEP_GEMM_WORDS(1, 1);
     const size_t w_att = 16 + 4 * 256 + (size_t)d->Tmax, w_pick = PICK_SMEM_WORDS(d->V);
@@ -1841,7 +1844,7 @@ static int launch_step_persistent(const ccvs_gpt_decode* d, int D, hipStream_t s
             (void)hipFuncSetAttribute((const void*)gpt_step_kernel<Dv, T2v>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                                                          \
         }                                                                                                                             \
-        hipLaunchKernelGGL((gpt_step_kernel<Dv, T2v>), dim3(n_cu), dim3(256), smem, st, a);                                           \
+        hipLaunchKernelGGL((gpt_step_kernel<Dv, T2v>), dim3(n_cu * per_cu), dim3(256), smem, st, a);                                  \
     } while (0)
     if (D == 64) { if (t2) STEP_LAUNCH(64, true); else STEP_LAUNCH(64, false); }
     else if (D == 32) { if (t2) STEP_LAUNCH(32, true); else STEP_LAUNCH(32, false); }
