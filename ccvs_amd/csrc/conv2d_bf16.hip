@@ -25,6 +25,7 @@ extern "C" int ccvs_conv_fetch_bytes_per_lane(const char* kernel_name) {
         const int b = conv_nty_fetch_bytes(nty);
         return b ? b : -1;
     }
+    if (strstr(kernel_name, "conv2d_bf16x3_pt_kernel<")) return 16;   // persistent tiles (conv2d_bf16_pt.h): aligned dwordx4 rows or LDS-DMA, nothing else
     if (strstr(kernel_name, "conv2d_bf16x3_kernel<") || strstr(kernel_name, "conv2d_mfma_kernel")) return 4;
     return -1;
 }
@@ -88,10 +89,14 @@ extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const flo
     // (conv2d_bf16_kernels.h, WPC).  CCVS_CONV_WPC2 = largest Cin that takes this form (0: off).
     static const int wpc2_cin = getenv("CCVS_CONV_WPC2") ? atoi(getenv("CCVS_CONV_WPC2")) : 64;   // 49->128: +6...7 %; 99->128: none (tools/conv_one.py)
     int wpc2 = 0;
-    if (wpc2_cin > 0 && mb >= 2 && TW == 32 && d->Cin <= wpc2_cin && d->kh == 3 && d->kw == 3 && d->stride == 1 && !d->transposed && !d->in_p8 && !d->out_p8) {
+    static const int wpc2_p8out = getenv("CCVS_CONV_WPC2_P8OUT") ? atoi(getenv("CCVS_CONV_WPC2_P8OUT")) : 0;   // experiment: ... also when the layer writes packed output
+    if (wpc2_cin > 0 && mb >= 2 && TW == 32 && d->Cin <= wpc2_cin && d->kh == 3 && d->kw == 3 && d->stride == 1 && !d->transposed && !d->in_p8 && (!d->out_p8 || wpc2_p8out)) {
         mb = 2;
         wpc2 = 1;
     }
+    // experiment (CCVS_CONV_P8_WPC2): packed-input 3 x 3 layers as 64-channel workgroups, two per CU (see launch_conv_bf16)
+    static const int p8_wpc2 = getenv("CCVS_CONV_P8_WPC2") ? atoi(getenv("CCVS_CONV_P8_WPC2")) : 0;
+    if (p8_wpc2 && mb == 4 && TW == 32 && d->in_p8 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && k.cu_limit <= 0) mb = 2;
 #define CB_DISPATCH(TWv)                                                                                        \
     if (mb == 4) return ccvs_conv_bf16_launch_##TWv##_4(k, w_split, d->w_ktail, CinG, halo_h, halo_w, ntx_max, gz, st, wpc2);           \
     if (mb == 2) return ccvs_conv_bf16_launch_##TWv##_2(k, w_split, d->w_ktail, CinG, halo_h, halo_w, ntx_max, gz, st, wpc2);           \

@@ -1,6 +1,7 @@
 // One (tile width CB_TW, channel block CB_MB) instantiation of the split-bf16 convolution kernels and their launcher
 // (compiled once per pair by the Makefile: -DCB_TW=.. -DCB_MB=..).
 #include "conv2d_bf16_kernels.h"
+#include "conv2d_bf16_pt.h"
 
 #define CB_CAT_(a, b, c) ccvs_conv_bf16_launch_##a##_##b
 #define CB_CAT(a, b) CB_CAT_(a, b, 0)

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64 * NW) void conv2d_bf16x3_kernel(ConvK p, const u
 // staged once per 64 output channels instead of once per 128.
 template <int TW, int MB, int NTY, int PP = 2, int WPC = 1>
 __global__ __launch_bounds__(512, ((MB == 1 && PP == 2) || WPC == 2) ? 4 : 2) void conv2d_bf16x3_pc_kernel(ConvK p, const uint4* __restrict__ wsplit, int CinG, int ntx_max, int ablate) {
-    static_assert(WPC == 1 || (WPC == 2 && MB == 2 && PP == 2 && NTY == 3), "two workgroups per CU: the 64-channel 3 x 3 form only");
+    static_assert(WPC == 1 || (WPC == 2 && MB == 2 && PP == 2 && (NTY == 3 || NTY == -83)), "two workgroups per CU: the 64-channel 3 x 3 forms only");
     static_assert(PP == 2 || (PP == 4 && (NTY > 0 || NTY == -83) && MB == 2), "the 512-pixel tile exists for the VEC / packed staging modes and 64 output channels");
     static_assert(conv_nty_fetch_bytes(NTY) != 0, "unknown staging mode: classify it in conv_common.h (conv_nty_*)");
     constexpr bool VEC = conv_nty_vec(NTY);
@@ -1343,6 +1343,10 @@ static int conv_occupancy(const void* fn, int threads, size_t smem_bytes) {
     return occ;
 }
 
+#define CONV_PT_NOT_TAKEN (-12345)
+template <int MB>
+static int conv_pt_try(const ConvK& k, const void* wsplit, const void* wktail, int CinG, int gz, hipStream_t st, int pt_on);   // conv2d_bf16_pt.h
+
 template <int TW, int MB>
 static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* wktail, int CinG, int halo_h, int halo_w, int ntx_max, int gz, hipStream_t st, int wpc2) {
     constexpr int NT = 32 * MB;
@@ -1373,6 +1377,14 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
     k.dbg = getenv("CCVS_CONV_DBG") ? (long long*)strtoull(getenv("CCVS_CONV_DBG"), nullptr, 0) : nullptr;
     k.dbg_block = getenv("CCVS_CONV_DBG_BLOCK") ? atoi(getenv("CCVS_CONV_DBG_BLOCK")) : 0;
 #endif
+    if constexpr (TW == 32 && (MB == 4 || MB == 2)) {
+        // persistent tiles (conv2d_bf16_pt.h): resident workgroups walk the tiles, a tile's prologue runs under the step loop of the tile before
+        static const int pt_on = getenv("CCVS_CONV_PT") ? atoi(getenv("CCVS_CONV_PT")) : 0;   // bit 0: fp32-input 128-channel layers, bit 1: packed-input layers
+        if (pt_on) {
+            const int r = conv_pt_try<MB>(k, wsplit, wktail, CinG, gz, st, pt_on);
+            if (r != CONV_PT_NOT_TAKEN) return r;
+        }
+    }
     const dim3 grid3(k.tiles_x * k.tiles_y, k.CoutPad / NT, gz);
     // cu_limit > 0: the tiles go out as consecutive 1-D chunks of cu_limit x (workgroups of this instantiation that fit one
     // CU) workgroups -- launches on one stream run one after the other, so the convolution never holds more than cu_limit
@@ -1422,7 +1434,7 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
             }
         }
         if constexpr (TW == 32 && MB == 2) {   // 64 output channels: the 512-pixel tile (see below), packed input
-            static const int pp4p = getenv("CCVS_CONV_PP4") ? atoi(getenv("CCVS_CONV_PP4")) : 1;
+            static const int pp4p = (getenv("CCVS_CONV_PP4") ? atoi(getenv("CCVS_CONV_PP4")) : 1) && !(getenv("CCVS_CONV_P8_WPC2") && atoi(getenv("CCVS_CONV_P8_WPC2")));
             const int th4 = 16, halo_h4 = (th4 - 1) + k.kh, plane4 = halo_h4 * halo_w;
             const size_t smem_4 = (size_t)(2 * 4 * plane4 + 2 * ntx_max * 4 * NT) * 16;
             if (pp4p && k.out_p8 && k.kh == 3 && k.kw == 3 && k.pad == 1 && k.cu_limit <= 0 && k.Hout >= 2 * th4 && 4 * plane4 <= 10 * 256 && smem_4 <= 156 * 1024 &&
@@ -1443,6 +1455,22 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
             }
         }
         bool done3 = false;
+        if constexpr (TW == 32 && MB == 2) {
+            // two workgroups per CU on packed input (experiment, CCVS_CONV_P8_WPC2): staging is LDS-DMA only, so a second resident
+            // workgroup costs no conversion work -- one tile's prologue / epilogue beside the other's step loop
+            static const int p8w2 = getenv("CCVS_CONV_P8_WPC2") ? atoi(getenv("CCVS_CONV_P8_WPC2")) : 0;
+            const size_t smem_2 = smem_p > p8s2 ? smem_p : p8s2;
+            if (p8w2 && k.kh == 3 && k.kw == 3 && k.pad == 1 && smem_2 <= 79 * 1024 && k.cu_limit <= 0) {
+                static bool attr2p = false;
+                if (!attr2p) {
+                    CB_SET_LDS((conv2d_bf16x3_pc_kernel<TW, MB, -83, 2, 2>), 159 * 1024);
+                    attr2p = true;
+                }
+                CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, -83, 2, 2>), 512, smem_2, (const uint4*)wsplit, CinG, ntx_max, ablate);
+                CCVS_CHECK_LAUNCH("ccvs_conv2d_bf16x3");
+                return CCVS_OK;
+            }
+        }
         if constexpr (MB != 4) {
             if (k.kh == 3 && k.kw == 3 && k.pad == 1) {
                 CB_LAUNCH((conv2d_bf16x3_pc_kernel<TW, MB, -83>), 512, (smem_p > p8s2 ? smem_p : p8s2), (const uint4*)wsplit, CinG, ntx_max, ablate);

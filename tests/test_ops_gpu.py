@@ -829,3 +829,26 @@ def test_backwarp_proj_fused(ops, cin, cout, h, w, k):
     w_t, cpad = ops.pack_proj_weight(wt.cuda())
     got = ops.backwarp_proj([c.cuda() for c in ctxs], flow.cuda(), mult, w_t, cpad, bias.cuda(), cout)
     close(got, want, 1e-4)   # sample positions differ from grid_sample's by an ulp of the (scaled) coordinates
+
+
+def test_conv_persistent_tiles_are_bit_identical(tmp_path):
+    """`CCVS_CONV_PT` (conv2d_bf16_pt.h: resident workgroups walk their tiles, a tile's prologue under the step loop of the tile before)
+    against the producer / consumer kernel it replaces on the same inputs, by flipping the switch in two worker processes (the library
+    reads it once): fp32 input with and without the packed K tail, packed input (256- and 512-pixel tiles), fp32 and packed output,
+    every epilogue addend (pre-activation image with the shared-image tile order, residual + scale, accumulate), two channel blocks
+    per position, workgroups with odd and even tile counts -- and shapes the persistent form must refuse.  Same arithmetic per
+    output in the same order: the same bits.  (Reference of the layer: skip_autoencoder.py:53-59.)"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = []
+    for flag in ("0", "3"):
+        path = str(tmp_path / f"pt{flag}.npz")
+        env = dict(os.environ, CCVS_CONV_PT=flag)
+        subprocess.run([sys.executable, os.path.join(here, "conv_pt_worker.py"), path], env=env, check=True, timeout=900)
+        outs.append(np.load(path))
+    assert sorted(outs[0].files) == sorted(outs[1].files) and len(outs[0].files) == 5 * 8 + 3
+    for key in outs[0].files:
+        a, b = outs[0][key], outs[1][key]
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), key
+    assert np.isfinite(outs[0]["f32_99"]).all() and np.abs(outs[0]["f32_99"]).max() > 0.1

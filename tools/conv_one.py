@@ -38,3 +38,12 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 3
 print(f"{cin}->{cout} k{k} @{h} N={n}: {ms:.3f} ms, {2.0 * n * cout * cin * k * k * h * h / ms / 1e9:.1f} TFLOP/s")
+if os.environ.get("CCVS_CONV_ONE_SUM"):   # two position-dependent checksums of the output's words: A / B runs of two builds or switches must print the same pair
+    words = (y.data if hasattr(y, "data") and not torch.is_tensor(y) else y).reshape(-1).view(torch.int32)
+    s0 = s1 = 0
+    step = 1 << 26
+    for i in range(0, words.numel(), step):
+        c = words[i:i + step].to(torch.int64)
+        s0 += int(c.sum())
+        s1 += int((c * (torch.arange(c.numel(), device=c.device) % 8191 + 1)).sum())
+    print(f"   checksum {s0 & 0xffffffffffff:012x} {s1 & 0xffffffffffff:012x}")
