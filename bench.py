@@ -640,8 +640,12 @@ def main():
                 "timeline_ms": stage.get("timeline"),
                 "stage_note": "per-batch stage durations from HIP events on the stage's own stream" +
                               ("; in the pipelined schedule encode+decode (stream D) and the transformer stages (one stream per lane) overlap" if args.schedule == "pipelined" else ""),
-                "roofline": {"kernel": ("conv2d_bf16x3_pc_kernel<TW,MB,NTY> + conv2d_bf16x3_kernel<TW,MB> (every instantiation: all conv launches)"
+                "roofline": {"kernel": ("conv2d_bf16x3_pc_kernel<TW,MB,NTY> + conv2d_bf16x3_kernel<TW,MB> (every instantiation: all conv launches)" +
+                                        (" + conv2d_bf16x3_pt_kernel<MB,PP,P8IN> (CCVS_CONV_PT=" + os.environ["CCVS_CONV_PT"] + ")" if os.environ.get("CCVS_CONV_PT", "0") != "0" else "")
                                         if kind == "bf16x3" else "conv2d_mfma_kernel<TW,MB>"), "bound": "mfma",
+                             "clock_note": ("NOT measured by this command (profiles/r06_power_trace.txt, tools/power_trace.py around this command on another box): the pipelined "
+                                            "passes run power-managed -- 1319 W of the socket's 1400 W at a shader clock of 2209 MHz -- while one batch alone (the `alone_passes`) "
+                                            "runs at 1159 W and 2389 MHz; `peak` is the 2.4 GHz figure for both") if args.schedule == "pipelined" else None,
                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                              "frac_in_run": (shared["whole_job_frac"] if shared else achieved / peak),
                              "frac_note": ("`frac` = the kernel with the chip to itself (the alone pass below); `frac_in_run` = the same launches' algorithmic FLOP "
