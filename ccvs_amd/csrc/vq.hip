@@ -3,6 +3,7 @@
 // ccvs_vq_argmin   <- VectorQuantizer.forward, modules/quantize.py:40-50
 // ccvs_embed_gather <- VectorQuantizer.embed_code + transposes, quantize.py:76-83,
 //                      quantized_video_model.py:832-833
+// ccvs_l2_normalize_channels <- the encoder's `normalize_out`, skip_autoencoder.py:348-349
 #include "common.h"
 
 // One workgroup = 32 rows (latent positions).  Their C-vector tile [C][32] sits in LDS
@@ -149,5 +150,29 @@ extern "C" int ccvs_embed_gather(const int64_t* code, const float* codebook, flo
     const int blocks = (int)(cdiv64(total, 256) < 1048576 ? cdiv64(total, 256) : 1048576);
     hipLaunchKernelGGL(embed_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, code, codebook, z, total, C, HW, n_e);
     CCVS_CHECK_LAUNCH("ccvs_embed_gather");
+    return CCVS_OK;
+}
+
+// One lane = one latent position (consecutive lanes = consecutive positions: every channel plane is read coalesced); the channel
+// loop runs twice -- sum of squares in channel order, then the division -- the second pass finds the planes in L2 (the tensor is the
+// encoder's output: z_size x 8 x 8 ... 32 x 32 per frame).
+__global__ __launch_bounds__(256) void l2_normalize_channels_kernel(float* __restrict__ x, long rows, int C, long HW) {
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        const long n = r / HW, pix = r - n * HW;
+        float* xp = x + n * C * HW + pix;
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) { const float v = xp[(long)c * HW]; a += v * v; }
+        const float nrm = sqrtf(a);
+        for (int c = 0; c < C; ++c) xp[(long)c * HW] = xp[(long)c * HW] / nrm;
+    }
+}
+
+extern "C" int ccvs_l2_normalize_channels(float* x, int32_t N, int32_t C, int64_t HW, void* stream) {
+    CCVS_REQUIRE(x, "ccvs_l2_normalize_channels: null pointer");
+    CCVS_REQUIRE(N > 0 && C > 0 && HW > 0, "ccvs_l2_normalize_channels: empty tensor");
+    const long rows = (long)N * HW;
+    const int blocks = (int)(cdiv64(rows, 256) < 65536 ? cdiv64(rows, 256) : 65536);
+    hipLaunchKernelGGL(l2_normalize_channels_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, rows, C, (long)HW);
+    CCVS_CHECK_LAUNCH("ccvs_l2_normalize_channels");
     return CCVS_OK;
 }

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CCVS_LIB") or os.path.join(_HERE, "csrc", "libccvs_hi
 # every symbol include/ccvs_hip.h declares
 EXPORTS = [
     "ccvs_last_error", "ccvs_abi_version", "ccvs_conv2d", "ccvs_conv2d_bf16x3", "ccvs_conv_fetch_bytes_per_lane", "ccvs_upfirdn2d", "ccvs_dwconvT4x4s2",
-    "ccvs_correlation7x7", "ccvs_backwarp", "ccvs_backwarp_ctx", "ccvs_backwarp_p8_ctx", "ccvs_backwarp_proj_ctx", "ccvs_warp_fuse_blend", "ccvs_warp_fuse_blend_ctx", "ccvs_tap_shift_add", "ccvs_vq_argmin", "ccvs_embed_gather",
+    "ccvs_correlation7x7", "ccvs_backwarp", "ccvs_backwarp_ctx", "ccvs_backwarp_p8_ctx", "ccvs_backwarp_proj_ctx", "ccvs_warp_fuse_blend", "ccvs_warp_fuse_blend_ctx", "ccvs_tap_shift_add", "ccvs_vq_argmin", "ccvs_embed_gather", "ccvs_l2_normalize_channels",
     "ccvs_gpt_embed", "ccvs_layernorm", "ccvs_gemm_workspace_bytes", "ccvs_gemm_nt", "ccvs_gemm_ln", "ccvs_gemm_ln_qkv", "ccvs_attention", "ccvs_kv_append", "ccvs_sample_topk", "ccvs_sample_topk_philox", "ccvs_sample_topn",
     "ccvs_gpt_decode_step", "ccvs_gpt_decode_status", "ccvs_gpt_program_bytes", "ccvs_gpt_decode_prepare", "ccvs_pack_u8", "ccvs_pack_u8_norm", "ccvs_stream_cu_limit", "ccvs_psnr", "ccvs_ssim_workspace_bytes", "ccvs_ssim", "ccvs_resize_bilinear",
 ]
@@ -110,6 +110,7 @@ def load():
         "ccvs_tap_shift_add": [vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp],
         "ccvs_vq_argmin": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "ccvs_embed_gather": [vp, vp, vp, i32, i32, i32, i32, vp],
+        "ccvs_l2_normalize_channels": [vp, i32, i32, i64, vp],
         "ccvs_gpt_embed": [vp, i64, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, vp],
         "ccvs_layernorm": [vp, vp, vp, vp, i32, i32, vp],
         "ccvs_gemm_nt": [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp],

@@ -363,8 +363,9 @@ class SkipGANEncoder(nn.Module):
 
     def __init__(self, opt, blur_kernel=[1, 3, 3, 1], mode="rgb"):
         super().__init__()
-        if mode != "rgb" or getattr(opt, "normalize_out", False):
-            raise NotImplementedError("SkipGANEncoder (HIP): rgb mode without output normalisation only")
+        if mode != "rgb":
+            raise NotImplementedError("SkipGANEncoder (HIP): rgb mode only (layout conditioning is outside the path)")
+        self.normalize_out = bool(getattr(opt, "normalize_out", False))
         necf_mult, necf = opt.necf_mult, opt.necf
         self.num_resolutions = len(necf_mult)
         self.z_size, self.mode = opt.z_size, mode
@@ -390,6 +391,8 @@ class SkipGANEncoder(nn.Module):
             out = self.blocks[i](out)
             inter_enc.append(out[:, :self.inter_sizes[i]])
         out = self.blocks[self.num_resolutions](out)
+        if self.normalize_out:   # skip_autoencoder.py:348-349: out / torch.norm(out, p=2, dim=1, keepdim=True)
+            out = ops.l2_normalize_channels_(out.contiguous())
         return unflatten_vid(out, vid_size), [unflatten_vid(feat, vid_size) for feat in inter_enc]
 
 

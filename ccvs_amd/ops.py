@@ -457,6 +457,16 @@ def embed_gather(code, codebook, n, hw):
     return z
 
 
+def l2_normalize_channels_(x):
+    """x [n, C, h, w] (dense) /= its L2 norm over the channels, in place (`normalize_out`, skip_autoencoder.py:348-349)."""
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 4
+    n, c, h, w = x.shape
+    L = _lib.load()
+    _lib.check(L.ccvs_l2_normalize_channels(_p(x), n, c, h * w, _stream()), "ccvs_l2_normalize_channels")
+    return x
+
+
 # ------------------------------------------------------------------ transformer
 def gpt_embed(idx, tok_emb, pos_table, pos0=0, pos_off=None, pos_dev=None):
     """idx int64 [B,Tq] (row stride free) -> x [B*Tq, C]; positional row = pos_off[b] + pos0 (+ *pos_dev) + t."""

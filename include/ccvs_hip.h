@@ -209,6 +209,11 @@ int ccvs_vq_argmin(const float* z, const float* codebook_t, const float* e_sq, i
 int ccvs_embed_gather(const int64_t* code, const float* codebook, float* z, int32_t N, int32_t C, int32_t HW, int32_t n_e,
                       void* stream);
 
+/* The encoder's output normalisation, `opt.normalize_out` (models/skip_vid_generator/models/skip_autoencoder.py:348-349):
+ * x[n][c][p] /= sqrt(sum_c x[n][c][p]^2), in place; x [N,C,HW] (NCHW).  A position whose channels are all zero becomes NaN,
+ * as in the reference (0 / 0). */
+int ccvs_l2_normalize_channels(float* x, int32_t N, int32_t C, int64_t HW, void* stream);
+
 /* ---- transformer ---------------------------------------------------------------------
  * Together these replace GPT.forward (models/skip_vid_generator/models/mingpt.py:232-305)
  * and Transformer.get_icode (models/transformer_model.py:395-409), restructured around a

@@ -852,3 +852,35 @@ def test_conv_persistent_tiles_are_bit_identical(tmp_path):
         a, b = outs[0][key], outs[1][key]
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), key
     assert np.isfinite(outs[0]["f32_99"]).all() and np.abs(outs[0]["f32_99"]).max() > 0.1
+
+
+def test_l2_normalize_channels_and_the_encoder_with_normalize_out():
+    """`opt.normalize_out` (skip_autoencoder.py:348-349: out / torch.norm(out, p=2, dim=1, keepdim=True)): the kernel alone on odd sizes
+    against the torch expression, then the encoder with `--q_normalize_out` against the oracle's (oracle/ccvs_oracle.py:
+    encoder_forward) -- latents of unit length per position, within 1e-5 (fp32; the sum over the channels runs in channel order
+    here, in torch's reduction order there)."""
+    from ccvs_amd import ops
+    from ccvs_amd.tools.options import Options
+    from ccvs_amd.models.skip_vid_generator.models import skip_autoencoder as sae
+    from tests.test_capi_host import TINY_ARGV
+    g = torch.Generator().manual_seed(3)
+    for shape in ((5, 16, 7, 9), (1, 1, 1, 1), (3, 257, 8, 8), (2, 4, 33, 65)):
+        x = torch.randn(*shape, generator=g) * 3
+        want = x / torch.norm(x, p=2, dim=1, keepdim=True)
+        got = ops.l2_normalize_channels_(x.cuda().contiguous()).cpu()
+        assert (got - want).abs().max().item() < 1e-6, shape
+    z = torch.zeros(1, 4, 2, 2)
+    assert torch.isnan(ops.l2_normalize_channels_(z.cuda()).cpu()).all()      # 0 / 0, as in the reference
+    opt = Options().parse(True, True, argv=TINY_ARGV + ["--q_normalize_out"])["qvid_generator"]
+    assert opt.normalize_out
+    torch.manual_seed(0)
+    enc = sae.SkipGANEncoder(opt).cuda().eval()
+    vid = torch.rand(2, 3, 3, 32, 32, generator=g) * 2 - 1
+    with torch.no_grad():
+        got, inter = enc(vid.cuda())
+        sd = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+        want, winter = O.encoder_forward(sd, opt, vid)
+    assert got.shape == want.shape and (got.cpu() - want).abs().max().item() < 1e-5
+    assert (got.cpu().reshape(-1, *got.shape[2:]).pow(2).sum(1).sqrt() - 1).abs().max().item() < 1e-5
+    for a, b in zip(inter, winter):
+        assert (a.cpu() - b).abs().max().item() < 1e-4
