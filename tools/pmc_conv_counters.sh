@@ -14,11 +14,11 @@ if not f: print("no counter file"); print(open("/tmp/pmc.log").read()[-800:]); r
 rows=list(csv.DictReader(open(f[0])))
 agg=collections.defaultdict(list)
 for r in rows:
-    if "pc_kernel" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if "pc_kernel" in r["Kernel_Name"] or "pt_kernel" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in agg.items(): print(k, "n=%d avg=%.4g"%(len(v), sum(v)/len(v)))
 t=glob.glob("/tmp/pmc/**/*kernel_trace.csv",recursive=True)
 if t:
-    d=[int(r["End_Timestamp"])-int(r["Start_Timestamp"]) for r in csv.DictReader(open(t[0])) if "pc_kernel" in r["Kernel_Name"]]
+    d=[int(r["End_Timestamp"])-int(r["Start_Timestamp"]) for r in csv.DictReader(open(t[0])) if "pc_kernel" in r["Kernel_Name"] or "pt_kernel" in r["Kernel_Name"]]
     print("kernel ms avg %.3f"%(sum(d)/len(d)/1e6))
 PY
 done
