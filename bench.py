@@ -643,6 +643,13 @@ def main():
                 "roofline": {"kernel": ("conv2d_bf16x3_pc_kernel<TW,MB,NTY> + conv2d_bf16x3_kernel<TW,MB> (every instantiation: all conv launches)" +
                                         (" + conv2d_bf16x3_pt_kernel<MB,PP,P8IN> (CCVS_CONV_PT=" + os.environ["CCVS_CONV_PT"] + ")" if os.environ.get("CCVS_CONV_PT", "0") != "0" else "")
                                         if kind == "bf16x3" else "conv2d_mfma_kernel<TW,MB>"), "bound": "mfma",
+                             "power_limited_peak": {"note": "NOT measured by this command (profiles/r06_mfma_rate_probe.txt: tools/micro/mfma_rate_probe.hip, back-to-back "
+                                                            "v_mfma_f32_32x32x16_bf16 on all 256 CUs): on RANDOM data the chip runs bf16 matrix instructions at 1.63 GHz -- 1713 "
+                                                            "TFLOP/s dense (2459 on all-zero data = the guide's 2.5 PFLOP/s `peak` above); with a convolution tap's LDS operand "
+                                                            "fetches 1566, with a staging wave beside 1454.  Three bf16 products per algorithmic product: `achieved` x 3 is the "
+                                                            "bf16 matrix work actually executed",
+                                                    "dense_bf16_random_data_tflops": 1713.0, "with_lds_operand_fetches": 1566.0, "with_staging_wave": 1454.0, "zero_data": 2459.0,
+                                                    "frac_of_power_limited": (3.0 * achieved / 1454.0) if kind == "bf16x3" else None},
                              "clock_note": ("NOT measured by this command (profiles/r06_power_trace.txt, tools/power_trace.py around this command on another box): the pipelined "
                                             "passes run power-managed -- 1319 W of the socket's 1400 W at a shader clock of 2209 MHz -- while one batch alone (the `alone_passes`) "
                                             "runs at 1159 W and 2389 MHz; `peak` is the 2.4 GHz figure for both") if args.schedule == "pipelined" else None,
