@@ -641,7 +641,11 @@ def main():
                 "stage_note": "per-batch stage durations from HIP events on the stage's own stream" +
                               ("; in the pipelined schedule encode+decode (stream D) and the transformer stages (one stream per lane) overlap" if args.schedule == "pipelined" else ""),
                 "roofline": {"kernel": ("conv2d_bf16x3_pc_kernel<TW,MB,NTY> + conv2d_bf16x3_kernel<TW,MB> (every instantiation: all conv launches)" +
-                                        (" + conv2d_bf16x3_pt_kernel<MB,PP,P8IN> (CCVS_CONV_PT=" + os.environ["CCVS_CONV_PT"] + ")" if os.environ.get("CCVS_CONV_PT", "0") != "0" else "")
+                                        (" + conv2d_bf16x3_pt_kernel<MB,PP,P8IN> (CCVS_CONV_PT=" + os.environ["CCVS_CONV_PT"] + ": everywhere)" if os.environ.get("CCVS_CONV_PT", "") not in ("", "0") else
+                                         (" + conv2d_bf16x3_pt_kernel<4,2,false> in the ALONE passes only: a single generate call runs the fp32-input 128-channel 3 x 3 layers "
+                                          "as persistent tiles (ccvs_conv_persistent_tiles, mode " + str(ops.conv_persistent_tiles()) + "); while several batches are in flight "
+                                          "-- the timed region -- helpers/pipeline.py keeps the per-tile kernels, which are the faster ones there"
+                                          if "CCVS_CONV_PT" not in os.environ and ops.conv_persistent_tiles() else ""))
                                         if kind == "bf16x3" else "conv2d_mfma_kernel<TW,MB>"), "bound": "mfma",
                              "power_limited_peak": {"note": "NOT measured by this command (profiles/r06_mfma_rate_probe.txt: tools/micro/mfma_rate_probe.hip, back-to-back "
                                                             "v_mfma_f32_32x32x16_bf16 on all 256 CUs): on RANDOM data the chip runs bf16 matrix instructions at 1.63 GHz -- 1713 "

@@ -30,6 +30,16 @@ extern "C" int ccvs_conv_fetch_bytes_per_lane(const char* kernel_name) {
     return -1;
 }
 
+// Persistent tiles (conv2d_bf16_pt.h) by CONTEXT: alone on the chip the resident form is 6 % faster over a decode's convolutions (a single
+// generate call: +1...1.5 %), beside the token loops of other batches the chip is power-managed and the denser kernel costs everyone clock
+// (profiles/r06_conv_pt_bench_ab.txt) -- so the host switches it: 1 by default, 0 while a pipelined run has several batches in flight
+// (helpers/pipeline.py).  CCVS_CONV_PT in the environment overrides both.
+static int g_conv_pt_mode = 1;
+extern "C" int ccvs_conv_persistent_tiles(int32_t mode) {
+    const int prev = __atomic_exchange_n(&g_conv_pt_mode, mode < 0 ? __atomic_load_n(&g_conv_pt_mode, __ATOMIC_RELAXED) : (int)(mode & 3), __ATOMIC_RELAXED);
+    return prev;
+}
+
 extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const float* bias, const float* residual, float* y,
                                   const ccvs_conv_desc* d, void* stream) {
     CCVS_REQUIRE(x && w_split && y && d, "ccvs_conv2d_bf16x3: null pointer");
@@ -58,6 +68,8 @@ extern "C" int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const flo
     k.act = d->act; k.accumulate = d->accumulate; k.out_scale = d->out_scale;
     k.pre = d->pre; k.pre_sN = d->pre_sN; k.pre_sC = d->pre_sC; k.pre_div = d->pre_div > 0 ? d->pre_div : 1;
     k.in_p8 = d->in_p8 ? 1 : 0; k.out_p8 = d->out_p8 ? 1 : 0;
+    static const int pt_env = getenv("CCVS_CONV_PT") ? atoi(getenv("CCVS_CONV_PT")) : -1;
+    k.pt = pt_env >= 0 ? pt_env : __atomic_load_n(&g_conv_pt_mode, __ATOMIC_RELAXED);
     k.ktail = 0; k.nwork = 0; k.gx = k.gy = 1; k.work0 = 0; k.xcd_chunk = 0; k.cu_limit = d->cu_limit > 0 ? d->cu_limit : ccvs_cu_limit_of(stream);
     static const int pre_order = getenv("CCVS_CONV_PRE_ORDER") ? atoi(getenv("CCVS_CONV_PRE_ORDER")) : 1;   // 0: image-major tiles for every launch
     k.zi = (pre_order && d->pre && k.pre_div > 1 && !d->transposed && d->N % k.pre_div == 0) ? k.pre_div : 0;

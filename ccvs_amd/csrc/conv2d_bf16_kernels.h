@@ -1379,7 +1379,7 @@ static int launch_conv_bf16(const ConvK& k_in, const void* wsplit, const void* w
 #endif
     if constexpr (TW == 32 && (MB == 4 || MB == 2)) {
         // persistent tiles (conv2d_bf16_pt.h): resident workgroups walk the tiles, a tile's prologue runs under the step loop of the tile before
-        static const int pt_on = getenv("CCVS_CONV_PT") ? atoi(getenv("CCVS_CONV_PT")) : 0;   // bit 0: fp32-input 128-channel layers, bit 1: packed-input layers
+        const int pt_on = k.pt;   // bit 0: fp32-input 128-channel layers, bit 1: packed-input layers (set per launch by the dispatcher, conv2d_bf16.hip)
         if (pt_on) {
             const int r = conv_pt_try<MB>(k, wsplit, wktail, CinG, gz, st, pt_on);
             if (r != CONV_PT_NOT_TAKEN) return r;

@@ -38,6 +38,9 @@ __device__ __forceinline__ void pt_tile_coords(const ConvK& p, int w_, int& bx, 
     }
 }
 
+#ifndef PT_DMA_MID
+#define PT_DMA_MID 1   // the weight DMA of the next step between the first and the second tap (0: in front of the step)
+#endif
 #ifndef PT_NUM_VGPR
 #define PT_VGPR_ATTR
 #else
@@ -429,13 +432,21 @@ __global__ __launch_bounds__(512, 2) PT_VGPR_ATTR void conv2d_bf16x3_pt_kernel(C
                     for (int r = 0; r < 16; ++r) acc[m][pp][r] = 0.f;
             int ci = 0, a = 0;
             for (int s = 0; s < nloop; ++s) {
-                if (s + 1 < nsteps) {   // weights of step s + 1; hipcc drains them (vmcnt 0) at the barrier
-                    int a1 = a + 1, c1 = ci;
-                    if (a1 == 3) { a1 = 0; ++c1; }
-                    dma_w(n0, c1, a1, w_buf + (wp ^ 1) * w_sz);
-                } else if (has_next) {
-                    dma_w(n0n, 0, 0, w_buf + (wp ^ 1) * w_sz);   // ... or of the next tile's first step
-                }
+                // The weights of step s + 1 -- or of the next tile's first step, or (last step of the last tile) once more this tile's first row,
+                // never read: an UNCONDITIONAL request with selected scalars, so that it can sit between the taps (PT_MID_DMA: address arithmetic and
+                // issue in the shadow of the first tap's matrix instructions instead of in front of the step, where the matrix pipe idled 360-450
+                // cycles, profiles/r05_conv_step_stamps.txt) without a branch between the fragment reads and the matrix instructions
+                int a1 = a + 1, c1 = ci, n0w = n0;
+                if (a1 == 3) { a1 = 0; ++c1; }
+                if (s + 1 >= nsteps) { a1 = 0; c1 = 0; n0w = has_next ? n0n : n0; }
+                uint4* const wdst = w_buf + (wp ^ 1) * w_sz;
+                if (!PT_DMA_MID) dma_w(n0w, c1, a1, wdst);
+#define PT_MID_DMA()                                      \
+    if (PT_DMA_MID) {                                     \
+        __builtin_amdgcn_sched_barrier(0);                \
+        dma_w(n0w, c1, a1, wdst);                         \
+        __builtin_amdgcn_sched_barrier(0);                \
+    }
                 {
                     const uint4* it0 = smem4 + (ci == 0 ? 2 * in_sz + 2 * w_sz : (ci & 1) * in_sz) + (khalf * 2) * plane + a * IWS;
                     const uint4* wt0 = w_buf + wp * w_sz + (khalf * 2) * NT + (lane & 31);
@@ -477,6 +488,7 @@ __global__ __launch_bounds__(512, 2) PT_VGPR_ATTR void conv2d_bf16x3_pt_kernel(C
         }                                                                                                              \
     }
                         PT_TAP4(0, 0, true)
+                        PT_MID_DMA()
                         PT_TAP4(1, 1, true)
                         PT_TAP4(0, 2, false)
 #undef PT_TAP4
@@ -517,6 +529,7 @@ __global__ __launch_bounds__(512, 2) PT_VGPR_ATTR void conv2d_bf16x3_pt_kernel(C
                         PT_LD_B(0, 0)
                         PT_LD_A(0, 0, 0)
                         PT_TAP(0, 0, 0, true)
+                        PT_MID_DMA()
                         PT_TAP(1, (MB & 1), 1, true)
                         PT_TAP(0, 0, 2, false)
 #undef PT_LD_B
@@ -524,6 +537,7 @@ __global__ __launch_bounds__(512, 2) PT_VGPR_ATTR void conv2d_bf16x3_pt_kernel(C
 #undef PT_TAP
                     }
                 }
+#undef PT_MID_DMA
                 __syncthreads();
                 wp ^= 1;
                 if (++a == 3) { a = 0; ++ci; }

@@ -28,6 +28,7 @@ struct ConvK {
     int cu_limit;  // host side only: CUs this launch may occupy (0 = classic 3-D grid over all of them)
     int zi;        // > 1: the zi images that share one `pre` image run back to back per tile (see CONV_TILE_COORDS)
     int ktail;     // r = Cin % 16 in {1, 2, 3} and the weights are in the packed-tail form (ccvs_conv_desc.w_ktail); else 0
+    int pt;        // host side only: persistent tiles for this launch (conv2d_bf16_pt.h): bit 0 fp32-input 128-channel layers, bit 1 packed-input layers
 #ifdef CB_STAMPS   // debug build only (make EXTRA=-DCB_STAMPS; tools/r05/conv_stamps.py): s_memtime stamps of one MFMA wave's steps
     long long* dbg;
     int dbg_block;

@@ -316,10 +316,22 @@ class PipelinedRun:
 
     # ------------------------------------------------------------------ the run
     def run(self):
-        gen = self.gen
         side = set(self.dec_streams + [self.s_enc] + [st for _, st in self.chain_list])
         for st in side:
             st.wait_stream(self.entry)
+        # Several batches in flight: the chip is power-managed then, and the persistent-tile form of the convolutions -- faster alone -- costs
+        # every kernel beside it clock (profiles/r06_conv_pt_bench_ab.txt): the per-tile kernels for the duration of such a run.
+        # One batch (generate_vid's stream schedule) keeps the library's default.  Process-wide: restored in `finally`.
+        many = (self.n_batches or 2) > 1
+        pt_prev = ops.conv_persistent_tiles(0) if many else None
+        try:
+            return self._run(side)
+        finally:
+            if pt_prev is not None:
+                ops.conv_persistent_tiles(pt_prev)
+
+    def _run(self, side):
+        gen = self.gen
         self._warm_up()
         if self.noise_streams:
             self.noise_feed = NoiseFeed(gen.transformer_model.generator, self.dev)

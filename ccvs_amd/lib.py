@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CCVS_LIB") or os.path.join(_HERE, "csrc", "libccvs_hi
 
 # every symbol include/ccvs_hip.h declares
 EXPORTS = [
-    "ccvs_last_error", "ccvs_abi_version", "ccvs_conv2d", "ccvs_conv2d_bf16x3", "ccvs_conv_fetch_bytes_per_lane", "ccvs_upfirdn2d", "ccvs_dwconvT4x4s2",
+    "ccvs_last_error", "ccvs_abi_version", "ccvs_conv2d", "ccvs_conv2d_bf16x3", "ccvs_conv_fetch_bytes_per_lane", "ccvs_conv_persistent_tiles", "ccvs_upfirdn2d", "ccvs_dwconvT4x4s2",
     "ccvs_correlation7x7", "ccvs_backwarp", "ccvs_backwarp_ctx", "ccvs_backwarp_p8_ctx", "ccvs_backwarp_proj_ctx", "ccvs_warp_fuse_blend", "ccvs_warp_fuse_blend_ctx", "ccvs_tap_shift_add", "ccvs_vq_argmin", "ccvs_embed_gather", "ccvs_l2_normalize_channels",
     "ccvs_gpt_embed", "ccvs_layernorm", "ccvs_gemm_workspace_bytes", "ccvs_gemm_nt", "ccvs_gemm_ln", "ccvs_gemm_ln_qkv", "ccvs_attention", "ccvs_kv_append", "ccvs_sample_topk", "ccvs_sample_topk_philox", "ccvs_sample_topn",
     "ccvs_gpt_decode_step", "ccvs_gpt_decode_status", "ccvs_gpt_program_bytes", "ccvs_gpt_decode_prepare", "ccvs_pack_u8", "ccvs_pack_u8_norm", "ccvs_stream_cu_limit", "ccvs_psnr", "ccvs_ssim_workspace_bytes", "ccvs_ssim", "ccvs_resize_bilinear",
@@ -95,6 +95,8 @@ def load():
     lib.ccvs_gpt_program_bytes.argtypes = [C.c_int32]
     lib.ccvs_conv_fetch_bytes_per_lane.restype = C.c_int
     lib.ccvs_conv_fetch_bytes_per_lane.argtypes = [C.c_char_p]
+    lib.ccvs_conv_persistent_tiles.restype = C.c_int          # (returns the previous mode, not a status)
+    lib.ccvs_conv_persistent_tiles.argtypes = [C.c_int32]
     sigs = {
         "ccvs_conv2d": [vp, vp, vp, vp, vp, C.POINTER(ConvDesc), vp],
         "ccvs_conv2d_bf16x3": [vp, vp, vp, vp, vp, C.POINTER(ConvDesc), vp],

@@ -64,6 +64,13 @@ CONV_P8 = __import__("os").environ.get("CCVS_CONV_P8", "1") == "1"
 P8_WARP = __import__("os").environ.get("CCVS_P8_WARP", "0") == "1"
 
 
+def conv_persistent_tiles(mode=-1):
+    """Which 3 x 3 layers of the split-bf16 convolution run as resident workgroups (`ccvs_conv_persistent_tiles`: bit 0 fp32-input
+    128-channel layers, bit 1 packed-input layers); process-wide, returns the previous mode (mode < 0: query).  The library's default
+    is 1; `helpers/pipeline.py` sets 0 while a run has several batches in flight.  `CCVS_CONV_PT` in the environment overrides both."""
+    return int(_lib.load().ccvs_conv_persistent_tiles(int(mode)))
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

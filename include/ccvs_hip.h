@@ -108,6 +108,13 @@ int ccvs_conv2d_bf16x3(const float* x, const void* w_split, const float* bias, c
  * FETCH_SIZE correction with it (a 16-byte-per-lane stream is tallied at half its bytes, MI355X_MICROARCH.md "HBM"). */
 int ccvs_conv_fetch_bytes_per_lane(const char* kernel_name);
 
+/* Which 3 x 3 stride-1 layers of ccvs_conv2d_bf16x3 run as RESIDENT workgroups that walk their tiles (conv2d_bf16_pt.h; the same bits as
+ * the per-tile kernels): bit 0 the fp32-input 128-channel layers, bit 1 the packed-input layers; process-wide, returns the previous
+ * mode (mode < 0: query only).  Default 1.  The host lowers it to 0 while several batches are in flight (ccvs_amd/helpers/pipeline.py):
+ * alone on the chip the resident form is faster, beside the token loops of other batches it is not.  No reference
+ * counterpart: the reference's convolutions are cuDNN calls (models/skip_vid_generator/models/skip_autoencoder.py:53-59). */
+int ccvs_conv_persistent_tiles(int32_t mode);
+
 /* ---- FIR resampling ------------------------------------------------------------------
  * Replaces upfirdn2d(input, kernel, up, down, pad) (modules/upfirdn2d.py:145-159, CUDA
  * upfirdn2d_kernel.cu:107-207, pybind upfirdn2d.cpp:21-23) for the 4-tap separable

@@ -215,3 +215,36 @@ print("REDIRECT_OK")
 ''' % ROOT
     res = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "REDIRECT_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+def test_conv_persistent_tiles_mode_is_a_host_switch(built_lib, monkeypatch):
+    """`ccvs_conv_persistent_tiles` (include/ccvs_hip.h) is pure host state: query, set, the previous mode comes back, only bits 0-1
+    are kept -- and `PipelinedRun.run` lowers it to 0 for a run of several batches and restores it, also when the run fails
+    (no GPU call: the run is cut short at its first step)."""
+    from ccvs_amd import ops
+    from ccvs_amd.helpers import pipeline
+    start = ops.conv_persistent_tiles()
+    try:
+        assert ops.conv_persistent_tiles(1) == start and ops.conv_persistent_tiles() == 1
+        assert ops.conv_persistent_tiles(3) == 1 and ops.conv_persistent_tiles(7) == 3 and ops.conv_persistent_tiles() == 3
+        assert ops.conv_persistent_tiles(1) == 3
+
+        class Cut(Exception):
+            pass
+
+        seen = []
+        run = pipeline.PipelinedRun.__new__(pipeline.PipelinedRun)
+        run.dec_streams, run.s_enc, run.chain_list, run.entry = [], None, [], None
+        monkeypatch.setattr(pipeline.PipelinedRun, "_run", lambda self, side: (seen.append(ops.conv_persistent_tiles()), (_ for _ in ()).throw(Cut()))[1])
+
+        class NoStream:
+            def wait_stream(self, other):
+                pass
+        run.s_enc = NoStream()
+        for n_batches, want in ((20, 0), (None, 0), (1, 1)):
+            run.n_batches = n_batches
+            with pytest.raises(Cut):
+                run.run()
+            assert seen[-1] == want and ops.conv_persistent_tiles() == 1, (n_batches, seen)
+    finally:
+        ops.conv_persistent_tiles(start)
