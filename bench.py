@@ -454,13 +454,15 @@ def main():
 
         rank_seed = noise_seed_of_rank(engine.rank)    # this rank's own stream (rank 0: NOISE_SEED, as every round so far)
 
-        def run(first, batches):
-            """K batches from resident inputs to all-gathered uint8 clips; returns the gathered clips of the last one."""
+        def run(first, batches, then=None):
+            """K batches from resident inputs to all-gathered uint8 clips; returns the gathered clips of the last one.  `then`: the
+            length of the run that follows (the warm-up run captures the decode step of THAT run's token-group sizes too: with
+            --warmup 1 --steps 3 the timed run's group of three would otherwise be captured inside the clock)."""
             torch.manual_seed(rank_seed)
             if args.schedule == "pipelined":
                 ramp = tuple(int(v) for v in args.ramp.split(",") if v) if args.ramp is not None else None
                 res = gen.run_pipelined(iter(batches), first_iter=first, cu_limit=args.cu_limit, finish=finish, lanes=args.lanes, chains=args.chains,
-                                        ramp=ramp, n_batches=len(batches))
+                                        ramp=ramp, n_batches=(len(batches), then) if then else len(batches))
                 handles = [r["finished"] for r in res]
                 stages = gen.pipeline_stage_ms()       # every rank: the line reports the stages per rank
                 if engine.is_main:
@@ -480,7 +482,7 @@ def main():
             return clips, stages
 
         if args.warmup > 0:
-            run(-args.warmup, [make_batch(1000 + w) for w in range(args.warmup)])
+            run(-args.warmup, [make_batch(1000 + w) for w in range(args.warmup)], then=args.steps)
         batches = [make_batch(i) for i in range(args.steps)]   # inputs resident in HBM before the clock starts
         timer = ops.KernelTimer()
         kept["step"] = 0

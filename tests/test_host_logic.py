@@ -379,15 +379,24 @@ def test_group_sizes_the_warm_up_prepares():
         _group_sizes_ahead = PipelinedRun._group_sizes_ahead
 
     r = _Run()
-    r.lanes, r.ramp, r.n_batches = 4, (), None
+    r.lanes, r.ramp, r.warm_counts = 4, (), (None,)
     assert list(r._group_sizes_ahead()) == [1, 2, 3, 4]
-    r.n_batches = 20
+    r.warm_counts = (20,)
     assert list(r._group_sizes_ahead()) == [4]
-    r.n_batches = 5
+    r.warm_counts = (5,)
     assert list(r._group_sizes_ahead()) == [1, 4]
-    r.lanes, r.ramp, r.n_batches = 8, (4, 4, 4, 8), 20
+    r.lanes, r.ramp, r.warm_counts = 8, (4, 4, 4, 8), (20,)
     assert list(r._group_sizes_ahead()) == [4, 8]
-    r.lanes, r.ramp, r.n_batches = 10, (), 20
+    r.lanes, r.ramp, r.warm_counts = 10, (), (20,)
     assert list(r._group_sizes_ahead()) == [10]
-    r.lanes, r.ramp, r.n_batches = 4, (1, 2), 6
+    r.lanes, r.ramp, r.warm_counts = 4, (1, 2), (6,)
     assert list(r._group_sizes_ahead()) == [1, 2, 3]
+    # a warm-up run told the length of the run that follows (bench.py: --warmup 1 --steps 3; --warmup 5 --steps 20) captures that run's sizes too
+    r.lanes, r.ramp, r.warm_counts = 4, (), (1, 3)
+    assert list(r._group_sizes_ahead()) == [1, 3]
+    r.warm_counts = (5, 20)
+    assert list(r._group_sizes_ahead()) == [1, 4]
+    r.warm_counts = (2, 6)
+    assert list(r._group_sizes_ahead()) == [2, 4]
+    r.warm_counts = (2, None)
+    assert list(r._group_sizes_ahead()) == [1, 2, 3, 4]
