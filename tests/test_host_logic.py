@@ -1,6 +1,7 @@
 """not gpu: host-side logic of the path that needs no device -- the sliding token windows of `Transformer.generate_fake`
 (transformer_model.py:301-326), the token-group sizing of `Generator.run_pipelined`, the merged frame / ancillary token order of
 `GPT.stream_kinds` (mingpt.py:246-282) against the oracle's merge, and the reference launch-line presets."""
+import os
 import types
 
 import pytest
@@ -400,3 +401,18 @@ def test_group_sizes_the_warm_up_prepares():
     assert list(r._group_sizes_ahead()) == [2, 4]
     r.warm_counts = (2, None)
     assert list(r._group_sizes_ahead()) == [1, 2, 3, 4]
+
+
+def test_power_trace_reads_rocm_smi_records():
+    """tools/power_trace.py: the record rocm-smi printed on the GPU box (profiles/r06_power_trace.txt was reduced from such samples) -> power,
+    cap, clocks, junction temperature; and the percentile helper."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("power_trace", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "power_trace.py"))
+    pt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pt)
+    card = {"Temperature (Sensor junction) (C)": "44.0", "Temperature (Sensor memory) (C)": "32.0", "fclk clock speed:": "(1250Mhz)", "fclk clock level:": "0",
+            "mclk clock speed:": "(2000Mhz)", "mclk clock level:": "0", "sclk clock speed:": "(2209Mhz)", "sclk clock level:": "S", "socclk clock speed:": "(38Mhz)",
+            "socclk clock level:": "S", "Max Graphics Package Power (W)": "1400.0", "Current Socket Graphics Package Power (W)": "1319.0"}
+    rec = pt.parse(card)
+    assert rec == {"tj_c": 44.0, "mclk_mhz": 2000.0, "sclk_mhz": 2209.0, "cap_w": 1400.0, "power_w": 1319.0}
+    assert pt.pct([5, 1, 3, 2, 4], 0.5) == 3 and pt.pct([], 0.5) is None

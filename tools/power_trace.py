@@ -14,13 +14,8 @@ import time
 SEEN = []
 
 
-def sample():
-    try:
-        out = subprocess.run(["/opt/rocm/bin/rocm-smi", "-P", "-c", "-t", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=10).stdout
-        d = json.loads(out)
-        card = d[sorted(d)[0]]
-    except Exception as e:      # a failed sample is a hole in the trace, not an error of the run
-        return {"error": str(e)}
+def parse(card):
+    """One card's record of `rocm-smi -P -c -t --showmaxpower --json` -> {power_w, cap_w, sclk_mhz, mclk_mhz, tj_c} (what is there)."""
     rec = {}
     for k, v in card.items():
         kl = k.lower()
@@ -34,6 +29,17 @@ def sample():
             rec["mclk_mhz"] = float(str(v).strip("()").lower().replace("mhz", ""))
         elif "temperature" in kl and "junction" in kl:
             rec["tj_c"] = float(v)
+    return rec
+
+
+def sample():
+    try:
+        out = subprocess.run(["/opt/rocm/bin/rocm-smi", "-P", "-c", "-t", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=10).stdout
+        d = json.loads(out)
+        card = d[sorted(d)[0]]
+    except Exception as e:      # a failed sample is a hole in the trace, not an error of the run
+        return {"error": str(e)}
+    rec = parse(card)
     if not SEEN:
         SEEN.append(1)
         rec["raw"] = card      # the first sample keeps rocm-smi's own record (key names differ between releases)
@@ -74,4 +80,5 @@ def main():
     sys.exit(rc)
 
 
-main()
+if __name__ == "__main__":
+    main()
